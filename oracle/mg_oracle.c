@@ -1,0 +1,1064 @@
+/*
+ * mg_oracle.c -- CPU restatement (plain C + OpenMP) of the reference's matrix-free geometric
+ * multigrid Laplace path for poisson_cube.  TEST INFRASTRUCTURE ONLY -- see mg_oracle.h for the
+ * usage rule and the parity status ("parity unpinned" by reference tests; pinned against the
+ * README transcript and mathematical properties in tests/).
+ *
+ * Reference files followed (relative to /root/reference/):
+ *   common/laplace_operator.h        operator, quadrature-point kernel, residual, diagonal, rhs
+ *   common/vector_access_reduced.h   27-entry compressed gather/scatter
+ *   common/multigrid_solver.h:54-782 FMG / V-cycle / PCG driver
+ *   poisson_cube/program.cc          problem definition (domain, solution, rhs, mesh sizes)
+ * deal.II parts (FEEvaluation, PreconditionChebyshev, MGTransferMatrixFree, SolverCG) are not
+ * vendored; they are restated from SURVEY.md 8a rows E, R, S, T / Appendix D.
+ */
+#include "mg_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#  include <omp.h>
+#endif
+
+#ifndef M_PI
+#  define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * 1D basis: FE_Q(p) = Lagrange polynomials on the p+1 Gauss-Lobatto nodes
+ * (poisson_cube/program.cc:175,199); quadrature QGauss<1>(p+1) (multigrid_solver.h:160,186).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+{
+  int    p, n;
+  double gll[ORC_MAXN], gq[ORC_MAXN], gw[ORC_MAXN];
+  double S[ORC_MAXN * ORC_MAXN];        /* S[q*n+i] = l_i^GLL(x_q)                     */
+  double D[ORC_MAXN * ORC_MAXN];        /* D[q*n+r] = d/dx l_r^Gauss(x_q)              */
+  double G[ORC_MAXN * ORC_MAXN];        /* G[q*n+i] = d/dx l_i^GLL(x_q) (dense check)  */
+  double P1[2 * ORC_MAXN * ORC_MAXN];   /* P1[a*n+i]: coarse basis i at fine patch pt a */
+} orc_basis;
+
+static void legendre(int n, long double x, long double *P, long double *dP)
+{
+  long double p0 = 1, p1 = x;
+  if (n == 0)
+    {
+      *P  = 1;
+      *dP = 0;
+      return;
+    }
+  for (int k = 2; k <= n; ++k)
+    {
+      long double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+      p0             = p1;
+      p1             = pk;
+    }
+  *P  = p1;
+  *dP = n * (x * p1 - p0) / (x * x - 1);
+}
+
+static long double lagrange(const long double *nodes, int n, int i, long double x)
+{
+  long double v = 1;
+  for (int j = 0; j < n; ++j)
+    if (j != i)
+      v *= (x - nodes[j]) / (nodes[i] - nodes[j]);
+  return v;
+}
+
+static long double lagrange_deriv(const long double *nodes, int n, int i, long double x)
+{
+  long double s = 0;
+  for (int k = 0; k < n; ++k)
+    if (k != i)
+      {
+        long double t = 1 / (nodes[i] - nodes[k]);
+        for (int j = 0; j < n; ++j)
+          if (j != i && j != k)
+            t *= (x - nodes[j]) / (nodes[i] - nodes[j]);
+        s += t;
+      }
+  return s;
+}
+
+static void basis_init(orc_basis *b, int p)
+{
+  const int   n = p + 1;
+  long double gll[ORC_MAXN], gq[ORC_MAXN], gw[ORC_MAXN];
+  b->p = p;
+  b->n = n;
+  /* Gauss-Legendre: roots of P_n on (-1,1), Newton from Chebyshev guesses */
+  for (int i = 0; i < n; ++i)
+    {
+      long double x = -cosl((long double)M_PI * (i + 0.75L) / (n + 0.5L)), P, dP;
+      for (int it = 0; it < 100; ++it)
+        {
+          legendre(n, x, &P, &dP);
+          long double dx = P / dP;
+          x -= dx;
+          if (fabsl(dx) < 1e-19L)
+            break;
+        }
+      legendre(n, x, &P, &dP);
+      gq[i] = (x + 1) / 2;
+      gw[i] = 1 / ((1 - x * x) * dP * dP); /* (2/((1-x^2)P'^2))/2 */
+    }
+  /* Gauss-Lobatto: +-1 and the roots of P_p' ; Newton on q(x) = P_p'(x) using
+   * (1-x^2) P'' = 2x P' - p(p+1) P */
+  gll[0] = 0;
+  gll[p] = 1;
+  for (int i = 1; i < p; ++i)
+    {
+      long double x = -cosl((long double)M_PI * i / p), P, dP;
+      for (int it = 0; it < 100; ++it)
+        {
+          legendre(p, x, &P, &dP);
+          long double d2P = (2 * x * dP - (long double)p * (p + 1) * P) / (1 - x * x);
+          long double dx  = dP / d2P;
+          x -= dx;
+          if (fabsl(dx) < 1e-19L)
+            break;
+        }
+      gll[i] = (x + 1) / 2;
+    }
+  for (int i = 0; i < n; ++i)
+    {
+      b->gll[i] = (double)gll[i];
+      b->gq[i]  = (double)gq[i];
+      b->gw[i]  = (double)gw[i];
+    }
+  for (int q = 0; q < n; ++q)
+    for (int i = 0; i < n; ++i)
+      {
+        b->S[q * n + i] = (double)lagrange(gll, n, i, gq[q]);
+        b->G[q * n + i] = (double)lagrange_deriv(gll, n, i, gq[q]);
+        b->D[q * n + i] = (double)lagrange_deriv(gq, n, i, gq[q]);
+      }
+  /* embedding of the parent's basis into the 2 children: fine patch point a = child*p + local */
+  for (int a = 0; a <= 2 * p; ++a)
+    {
+      const int         child = a < p ? 0 : 1;
+      const int         loc   = a - child * p;
+      const long double xi    = (child + gll[loc]) / 2;
+      for (int i = 0; i < n; ++i)
+        {
+          long double v = lagrange(gll, n, i, xi);
+          /* nodes of parent and child coincide at a = 0, p (if p even: also the midpoint), 2p:
+           * make those rows exact unit vectors */
+          if (fabsl(v) < 1e-18L)
+            v = 0;
+          if (fabsl(v - 1) < 1e-18L)
+            v = 1;
+          b->P1[a * n + i] = (double)v;
+        }
+    }
+}
+
+/* extreme eigenvalues of a symmetric tridiagonal matrix by Sturm-sequence bisection */
+static int sturm_count(int n, const double *d, const double *e, double x)
+{
+  int    count = 0;
+  double q     = d[0] - x;
+  if (q < 0)
+    ++count;
+  for (int i = 1; i < n; ++i)
+    {
+      if (q == 0)
+        q = 1e-300;
+      q = d[i] - x - e[i - 1] * e[i - 1] / q;
+      if (q < 0)
+        ++count;
+    }
+  return count; /* number of eigenvalues < x */
+}
+
+static void tridiag_extreme_eigs(int n, const double *d, const double *e, double *lo, double *hi)
+{
+  double gl = d[0], gu = d[0];
+  for (int i = 0; i < n; ++i)
+    {
+      const double r = (i > 0 ? fabs(e[i - 1]) : 0) + (i < n - 1 ? fabs(e[i]) : 0);
+      if (d[i] - r < gl)
+        gl = d[i] - r;
+      if (d[i] + r > gu)
+        gu = d[i] + r;
+    }
+  for (int which = 0; which < 2; ++which)
+    {
+      const int k = which == 0 ? 1 : n; /* k-th smallest eigenvalue */
+      double    a = gl, b = gu;
+      for (int it = 0; it < 200; ++it)
+        {
+          const double m = 0.5 * (a + b);
+          if (m == a || m == b)
+            break;
+          if (sturm_count(n, d, e, m) >= k)
+            b = m;
+          else
+            a = m;
+        }
+      if (which == 0)
+        *lo = 0.5 * (a + b);
+      else
+        *hi = 0.5 * (a + b);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Mesh level: uniform N^3 cells of [-0.9,1]^3 (poisson_cube/program.cc:542), cells in
+ * forest/Morton order (p4est order of the reference), DoFs numbered entity by entity in
+ * first-touch order so that every mesh entity's DoFs are contiguous and lexicographic
+ * (the contract asserted in laplace_operator.h:272-340); Dirichlet DoFs are numbered last
+ * (Appendix A: constrained DoFs after all unconstrained ones).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+{
+  int       level, N;
+  uint32_t  n_cells, n_dofs, n_constrained;
+  uint32_t *idx27, *idx27_plain, *constrained, *cell_coords, *dof_grid;
+  uint32_t  colour_start[9];
+  uint32_t *colour_cells;
+  uint32_t *children_of_parent; /* [n_cells(level-1)*8] -> cell index on this level */
+  double    h, coef[6];
+} orc_level;
+
+struct orc_problem
+{
+  int        p, n_subdiv, n_levels, degree, n_cycles, vfloat;
+  orc_basis  basis;
+  orc_level *levels;
+  void      *Bd, *Bf; /* basis_d / basis_f  */
+  void      *vd, *vf; /* vlevel_d[] / vlevel_f[] : V-cycle data in the V-cycle number type */
+  void      *cd;      /* cheb_d[] on the double operator (only used when vfloat==0: == vd) */
+  /* fp64 outer vectors (multigrid_solver.h:709-719) */
+  double **solution, **rhs, **residual;
+  /* inhomogeneous boundary values (multigrid_solver.h:225-253) */
+  uint32_t *bc_count;
+  uint32_t **bc_idx;
+  double  **bc_val;
+};
+
+static inline uint32_t morton_compact(uint32_t m)
+{ /* gather every third bit */
+  uint32_t r = 0;
+  for (int b = 0; b < 10; ++b)
+    r |= ((m >> (3 * b)) & 1u) << b;
+  return r;
+}
+
+static void level_init(orc_level *L, int p, int n_subdiv, int level)
+{
+  const int N  = n_subdiv << level;
+  L->level     = level;
+  L->N         = N;
+  L->n_cells   = (uint32_t)N * N * N;
+  L->h         = 1.9 / N;
+  /* merged_coefficient = a * JxW * J^-T J^-1 = h^3 / h^2 (laplace_operator.h:374-387) */
+  L->coef[0] = L->coef[1] = L->coef[2] = L->h;
+  L->coef[3] = L->coef[4] = L->coef[5] = 0.;
+  const uint32_t nc = L->n_cells;
+  L->cell_coords    = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (size_t)nc);
+  const uint32_t per_root = 1u << (3 * level);
+  for (uint32_t c = 0; c < nc; ++c)
+    {
+      const uint32_t r = c / per_root, m = c % per_root;
+      const uint32_t rx = r % n_subdiv, ry = (r / n_subdiv) % n_subdiv, rz = r / (n_subdiv * n_subdiv);
+      L->cell_coords[3 * (size_t)c + 0] = (rx << level) + morton_compact(m);
+      L->cell_coords[3 * (size_t)c + 1] = (ry << level) + morton_compact(m >> 1);
+      L->cell_coords[3 * (size_t)c + 2] = (rz << level) + morton_compact(m >> 2);
+    }
+  /* colour lists */
+  uint32_t cnt[8] = {0};
+  for (uint32_t c = 0; c < nc; ++c)
+    cnt[(L->cell_coords[3 * (size_t)c] & 1) | ((L->cell_coords[3 * (size_t)c + 1] & 1) << 1) |
+        ((L->cell_coords[3 * (size_t)c + 2] & 1) << 2)]++;
+  L->colour_start[0] = 0;
+  for (int i = 0; i < 8; ++i)
+    L->colour_start[i + 1] = L->colour_start[i] + cnt[i];
+  L->colour_cells = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nc);
+  uint32_t pos[8];
+  for (int i = 0; i < 8; ++i)
+    pos[i] = L->colour_start[i];
+  for (uint32_t c = 0; c < nc; ++c)
+    {
+      const int col = (L->cell_coords[3 * (size_t)c] & 1) | ((L->cell_coords[3 * (size_t)c + 1] & 1) << 1) |
+                      ((L->cell_coords[3 * (size_t)c + 2] & 1) << 2);
+      L->colour_cells[pos[col]++] = c;
+    }
+  /* entity numbering: entity grid (2N+1)^3, even coordinate = vertex plane, odd = cell interior */
+  const size_t E   = (size_t)(2 * N + 1);
+  uint32_t    *ent = (uint32_t *)malloc(sizeof(uint32_t) * E * E * E);
+  for (size_t i = 0; i < E * E * E; ++i)
+    ent[i] = ORC_INVALID;
+  L->idx27       = (uint32_t *)malloc(sizeof(uint32_t) * 27 * (size_t)nc);
+  L->idx27_plain = (uint32_t *)malloc(sizeof(uint32_t) * 27 * (size_t)nc);
+  uint32_t next = 0;
+  for (int pass = 0; pass < 2; ++pass) /* 0: unconstrained entities, 1: Dirichlet boundary */
+    {
+      for (uint32_t c = 0; c < nc; ++c)
+        {
+          const uint32_t X = L->cell_coords[3 * (size_t)c], Y = L->cell_coords[3 * (size_t)c + 1],
+                         Z = L->cell_coords[3 * (size_t)c + 2];
+          for (int cz = 0; cz < 3; ++cz)
+            for (int cy = 0; cy < 3; ++cy)
+              for (int cx = 0; cx < 3; ++cx)
+                {
+                  const size_t ex = 2 * X + cx, ey = 2 * Y + cy, ez = 2 * Z + cz;
+                  const int    bdry = ex == 0 || ex == 2 * (size_t)N || ey == 0 ||
+                                   ey == 2 * (size_t)N || ez == 0 || ez == 2 * (size_t)N;
+                  if (bdry != pass)
+                    continue;
+                  const size_t eid = (ez * E + ey) * E + ex;
+                  if (ent[eid] == ORC_INVALID)
+                    {
+                      ent[eid] = next;
+                      next += (uint32_t)((cx == 1 ? p - 1 : 1) * (cy == 1 ? p - 1 : 1) *
+                                         (cz == 1 ? p - 1 : 1));
+                    }
+                }
+        }
+      if (pass == 0)
+        L->n_constrained = next; /* temporarily: number of unconstrained dofs */
+    }
+  L->n_dofs               = next;
+  const uint32_t n_uncons = L->n_constrained;
+  L->n_constrained        = L->n_dofs - n_uncons;
+  L->constrained          = (uint32_t *)malloc(sizeof(uint32_t) * (L->n_constrained + 1));
+  for (uint32_t i = 0; i < L->n_constrained; ++i)
+    L->constrained[i] = n_uncons + i;
+  /* tables + dof -> lexicographic grid id map */
+  const size_t G = (size_t)N * p + 1;
+  L->dof_grid    = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)L->n_dofs);
+  for (uint32_t c = 0; c < nc; ++c)
+    {
+      const uint32_t X = L->cell_coords[3 * (size_t)c], Y = L->cell_coords[3 * (size_t)c + 1],
+                     Z = L->cell_coords[3 * (size_t)c + 2];
+      for (int cz = 0; cz < 3; ++cz)
+        for (int cy = 0; cy < 3; ++cy)
+          for (int cx = 0; cx < 3; ++cx)
+            {
+              const size_t   ex = 2 * X + cx, ey = 2 * Y + cy, ez = 2 * Z + cz;
+              const uint32_t base = ent[(ez * E + ey) * E + ex];
+              const int      e    = 9 * cz + 3 * cy + cx;
+              L->idx27_plain[27 * (size_t)c + e] = base;
+              L->idx27[27 * (size_t)c + e]       = base >= n_uncons ? ORC_INVALID : base;
+              const int nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
+              for (int oz = 0; oz < nz; ++oz)
+                for (int oy = 0; oy < ny; ++oy)
+                  for (int ox = 0; ox < nx; ++ox)
+                    {
+                      const size_t gx = (size_t)X * p + (cx == 0 ? 0 : (cx == 2 ? p : 1 + ox));
+                      const size_t gy = (size_t)Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
+                      const size_t gz = (size_t)Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
+                      L->dof_grid[base + (uint32_t)((oz * ny + oy) * nx + ox)] =
+                        (uint32_t)((gz * G + gy) * G + gx);
+                    }
+            }
+    }
+  free(ent);
+  L->children_of_parent = NULL;
+  if (level > 0)
+    {
+      const uint32_t npar   = nc / 8;
+      L->children_of_parent = (uint32_t *)malloc(sizeof(uint32_t) * 8 * (size_t)npar);
+      for (uint32_t pc = 0; pc < npar; ++pc)
+        for (uint32_t ch = 0; ch < 8; ++ch)
+          L->children_of_parent[8 * (size_t)pc + ch] = 8 * pc + ch; /* Morton order */
+    }
+}
+
+static void level_free(orc_level *L)
+{
+  free(L->idx27);
+  free(L->idx27_plain);
+  free(L->constrained);
+  free(L->cell_coords);
+  free(L->dof_grid);
+  free(L->colour_cells);
+  free(L->children_of_parent);
+}
+
+/* number-type instantiations */
+#define NUM double
+#define SUF d
+#include "mg_oracle_num.inc"
+#undef NUM
+#undef SUF
+#define NUM float
+#define SUF f
+#include "mg_oracle_num.inc"
+#undef NUM
+#undef SUF
+
+/* V-cycle level data (multigrid_solver.h:725-735, 751) in either number type */
+typedef struct
+{
+  double *defect, *t, *solution_update; /* used when vfloat == 0 */
+  float  *defect_f, *t_f, *solution_update_f;
+  cheb_d  cheb;
+  cheb_f  cheb_f_;
+} vlevel;
+
+#define VL(P) ((vlevel *)(P)->vd)
+#define BD(P) ((const basis_d *)(P)->Bd)
+#define BF(P) ((const basis_f *)(P)->Bf)
+
+/* Problem definition: poisson_cube/program.cc:98-104 (solution), :140-144 (rhs) */
+static double u_exact(double x, double y, double z)
+{
+  return sin(M_PI * x * 3.) * sin(M_PI * y * 3.) * sin(M_PI * z * 3.);
+}
+static double f_rhs(double x, double y, double z)
+{
+  return 3. * M_PI * 3. * M_PI * 3. * u_exact(x, y, z);
+}
+
+static void grid_to_xyz(const orc_problem *P, const orc_level *L, uint32_t gid, double xyz[3])
+{
+  const int    p = P->p;
+  const size_t G = (size_t)L->N * p + 1;
+  size_t       g[3] = {gid % G, (gid / G) % G, gid / (G * G)};
+  for (int d = 0; d < 3; ++d)
+    {
+      size_t cell = g[d] / p, loc = g[d] % p;
+      if (cell == (size_t)L->N)
+        {
+          cell = L->N - 1;
+          loc  = p;
+        }
+      xyz[d] = -0.9 + L->h * ((double)cell + P->basis.gll[loc]);
+    }
+}
+
+/* LaplaceOperator::compute_residual (laplace_operator.h:804-845): dst = int f phi - int C grad
+ * u_bc . grad phi ; src holds the Dirichlet values (read through the unconstrained index table,
+ * :814,820), the result is scattered through the constrained one. */
+static void compute_rhs(const orc_problem *P, const orc_level *L, double *dst, const double *src)
+{
+  const int      p = P->p, n = p + 1, n3 = n * n * n;
+  const basis_d *B = BD(P);
+  memset(dst, 0, sizeof(double) * L->n_dofs);
+  for (int col = 0; col < 8; ++col)
+    {
+      const uint32_t  nc   = L->colour_start[col + 1] - L->colour_start[col];
+      const uint32_t *list = L->colour_cells + L->colour_start[col];
+#pragma omp parallel
+      {
+        double *u = (double *)malloc(sizeof(double) * 5 * n3), *t0 = u + n3, *gx = t0 + n3,
+               *gy = gx + n3, *gz = gy + n3;
+#pragma omp for schedule(static)
+        for (uint32_t kk = 0; kk < nc; ++kk)
+          {
+            const uint32_t c = list[kk];
+            gather27_d(p, L->idx27_plain + 27 * (size_t)c, src, u);
+            for (int i = 0; i < n3; ++i) /* :823-824 */
+              u[i] *= -1.0;
+            sweep_d(n, 0, B->S, u, t0, 0);
+            sweep_d(n, 1, B->S, t0, u, 0);
+            sweep_d(n, 2, B->S, u, t0, 0);
+            sweep_d(n, 0, B->D, t0, gx, 0);
+            sweep_d(n, 1, B->D, t0, gy, 0);
+            sweep_d(n, 2, B->D, t0, gz, 0);
+            const double x0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c],
+                         y0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 1],
+                         z0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 2];
+            for (int k = 0, q = 0; k < n; ++k)
+              for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i, ++q)
+                  {
+                    const double w = B->w[i] * B->w[j] * B->w[k];
+                    const double a = gx[q], b = gy[q], cc = gz[q];
+                    gx[q] = (L->coef[0] * a + L->coef[3] * b + L->coef[4] * cc) * w;
+                    gy[q] = (L->coef[3] * a + L->coef[1] * b + L->coef[5] * cc) * w;
+                    gz[q] = (L->coef[4] * a + L->coef[5] * b + L->coef[2] * cc) * w;
+                    /* submit_value(rhs_val) multiplies by JxW = h^3 w_q (:839) */
+                    t0[q] = f_rhs(x0 + L->h * P->basis.gq[i], y0 + L->h * P->basis.gq[j],
+                                  z0 + L->h * P->basis.gq[k]) *
+                            (L->h * L->h * L->h) * w;
+                  }
+            sweep_d(n, 0, B->Dt, gx, t0, 1);
+            sweep_d(n, 1, B->Dt, gy, t0, 1);
+            sweep_d(n, 2, B->Dt, gz, t0, 1);
+            sweep_d(n, 0, B->St, t0, u, 0);
+            sweep_d(n, 1, B->St, u, t0, 0);
+            sweep_d(n, 2, B->St, t0, u, 0);
+            scatter27_d(p, L->idx27 + 27 * (size_t)c, dst, u);
+          }
+        free(u);
+      }
+    }
+}
+
+static void set_bc(const orc_problem *P, int level, double *v, int zero)
+{
+  for (uint32_t i = 0; i < P->bc_count[level]; ++i)
+    v[P->bc_idx[level][i]] = zero ? 0. : P->bc_val[level][i];
+}
+
+orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cycles, int vfloat)
+{
+  if (p < 1 || p > 9 || n_subdiv < 1 || n_refine < 0)
+    return NULL;
+  /* the 27-entry compressed path is what the reference uses for fe_degree > 2
+   * (laplace_operator.h:230,540); for p <= 2 it degenerates gracefully (empty interiors for p=1) */
+  orc_problem *P = (orc_problem *)calloc(1, sizeof(orc_problem));
+  P->p           = p;
+  P->n_subdiv    = n_subdiv;
+  P->n_levels    = n_refine + 1;
+  P->degree      = degree;
+  P->n_cycles    = n_cycles;
+  P->vfloat      = vfloat;
+  basis_init(&P->basis, p);
+  P->Bd = malloc(sizeof(basis_d));
+  P->Bf = malloc(sizeof(basis_f));
+  basis_init_d((basis_d *)P->Bd, &P->basis);
+  basis_init_f((basis_f *)P->Bf, &P->basis);
+  P->levels = (orc_level *)calloc(P->n_levels, sizeof(orc_level));
+  for (int l = 0; l < P->n_levels; ++l)
+    level_init(&P->levels[l], p, n_subdiv, l);
+  P->solution = (double **)calloc(P->n_levels, sizeof(double *));
+  P->rhs      = (double **)calloc(P->n_levels, sizeof(double *));
+  P->residual = (double **)calloc(P->n_levels, sizeof(double *));
+  P->bc_count = (uint32_t *)calloc(P->n_levels, sizeof(uint32_t));
+  P->bc_idx   = (uint32_t **)calloc(P->n_levels, sizeof(uint32_t *));
+  P->bc_val   = (double **)calloc(P->n_levels, sizeof(double *));
+  vlevel *V   = (vlevel *)calloc(P->n_levels, sizeof(vlevel));
+  P->vd       = V;
+  for (int l = 0; l < P->n_levels; ++l)
+    {
+      orc_level *L   = &P->levels[l];
+      P->solution[l] = (double *)calloc(L->n_dofs, sizeof(double));
+      P->rhs[l]      = (double *)calloc(L->n_dofs, sizeof(double));
+      P->residual[l] = (double *)calloc(L->n_dofs, sizeof(double));
+      /* inhomogeneous boundary values: u at the support points of boundary DoFs, stored only
+       * if nonzero (multigrid_solver.h:245-252) */
+      P->bc_idx[l] = (uint32_t *)malloc(sizeof(uint32_t) * (L->n_constrained + 1));
+      P->bc_val[l] = (double *)malloc(sizeof(double) * (L->n_constrained + 1));
+      uint32_t cnt = 0;
+      for (uint32_t i = 0; i < L->n_constrained; ++i)
+        {
+          const uint32_t dof = L->constrained[i];
+          double         x[3];
+          grid_to_xyz(P, L, L->dof_grid[dof], x);
+          const double v = u_exact(x[0], x[1], x[2]);
+          if (v != 0.0)
+            {
+              P->bc_idx[l][cnt] = dof;
+              P->bc_val[l][cnt] = v;
+              ++cnt;
+            }
+        }
+      P->bc_count[l] = cnt;
+      set_bc(P, l, P->solution[l], 0);                      /* multigrid_solver.h:257-259 */
+      compute_rhs(P, L, P->rhs[l], P->solution[l]);         /* :261 */
+      /* V-cycle vectors and smoother (multigrid_solver.h:168-170, 269-289) */
+      if (!vfloat)
+        {
+          V[l].defect          = (double *)calloc(L->n_dofs, sizeof(double));
+          V[l].t               = (double *)calloc(L->n_dofs, sizeof(double));
+          V[l].solution_update = (double *)calloc(L->n_dofs, sizeof(double));
+          V[l].cheb.inv_diag   = (double *)malloc(sizeof(double) * L->n_dofs);
+          V[l].cheb.x_old      = (double *)calloc(L->n_dofs, sizeof(double));
+          V[l].cheb.tmp        = (double *)calloc(L->n_dofs, sizeof(double));
+          compute_inv_diag_d(P, L, BD(P), V[l].cheb.inv_diag);
+          if (l > 0)
+            cheb_setup_d(P, L, BD(P), &V[l].cheb, 20., degree, 15);
+          else
+            cheb_setup_d(P, L, BD(P), &V[l].cheb, 1e-3, -1, (int)L->n_dofs);
+        }
+      else
+        {
+          V[l].defect_f          = (float *)calloc(L->n_dofs, sizeof(float));
+          V[l].t_f               = (float *)calloc(L->n_dofs, sizeof(float));
+          V[l].solution_update_f = (float *)calloc(L->n_dofs, sizeof(float));
+          V[l].cheb_f_.inv_diag  = (float *)malloc(sizeof(float) * L->n_dofs);
+          V[l].cheb_f_.x_old     = (float *)calloc(L->n_dofs, sizeof(float));
+          V[l].cheb_f_.tmp       = (float *)calloc(L->n_dofs, sizeof(float));
+          compute_inv_diag_f(P, L, BF(P), V[l].cheb_f_.inv_diag);
+          if (l > 0)
+            cheb_setup_f(P, L, BF(P), &V[l].cheb_f_, 20., degree, 15);
+          else
+            cheb_setup_f(P, L, BF(P), &V[l].cheb_f_, 1e-3, -1, (int)L->n_dofs);
+          /* keep a double copy of the diagonal for the accessor */
+          V[l].cheb.inv_diag = (double *)malloc(sizeof(double) * L->n_dofs);
+          for (uint32_t i = 0; i < L->n_dofs; ++i)
+            V[l].cheb.inv_diag[i] = V[l].cheb_f_.inv_diag[i];
+          V[l].cheb.lambda_min = V[l].cheb_f_.lambda_min;
+          V[l].cheb.lambda_max = V[l].cheb_f_.lambda_max;
+          V[l].cheb.theta      = V[l].cheb_f_.theta;
+          V[l].cheb.delta      = V[l].cheb_f_.delta;
+          V[l].cheb.degree     = V[l].cheb_f_.degree;
+          V[l].cheb.cg_its     = V[l].cheb_f_.cg_its;
+        }
+    }
+  return P;
+}
+
+void orc_destroy(orc_problem *P)
+{
+  if (!P)
+    return;
+  vlevel *V = VL(P);
+  for (int l = 0; l < P->n_levels; ++l)
+    {
+      level_free(&P->levels[l]);
+      free(P->solution[l]);
+      free(P->rhs[l]);
+      free(P->residual[l]);
+      free(P->bc_idx[l]);
+      free(P->bc_val[l]);
+      free(V[l].defect);
+      free(V[l].t);
+      free(V[l].solution_update);
+      free(V[l].defect_f);
+      free(V[l].t_f);
+      free(V[l].solution_update_f);
+      free(V[l].cheb.inv_diag);
+      free(V[l].cheb.x_old);
+      free(V[l].cheb.tmp);
+      free(V[l].cheb_f_.inv_diag);
+      free(V[l].cheb_f_.x_old);
+      free(V[l].cheb_f_.tmp);
+    }
+  free(P->levels);
+  free(P->solution);
+  free(P->rhs);
+  free(P->residual);
+  free(P->bc_count);
+  free(P->bc_idx);
+  free(P->bc_val);
+  free(P->vd);
+  free(P->Bd);
+  free(P->Bf);
+  free(P);
+}
+
+/* ---- accessors ---- */
+int orc_n_levels(const orc_problem *P) { return P->n_levels; }
+int orc_degree(const orc_problem *P) { return P->p; }
+uint32_t orc_n_cells(const orc_problem *P, int l) { return P->levels[l].n_cells; }
+uint32_t orc_n_dofs(const orc_problem *P, int l) { return P->levels[l].n_dofs; }
+uint32_t orc_n_constrained(const orc_problem *P, int l) { return P->levels[l].n_constrained; }
+int orc_cells_per_dim(const orc_problem *P, int l) { return P->levels[l].N; }
+const uint32_t *orc_idx27(const orc_problem *P, int l) { return P->levels[l].idx27; }
+const uint32_t *orc_idx27_plain(const orc_problem *P, int l) { return P->levels[l].idx27_plain; }
+const uint32_t *orc_constrained(const orc_problem *P, int l) { return P->levels[l].constrained; }
+const uint32_t *orc_cell_coords(const orc_problem *P, int l) { return P->levels[l].cell_coords; }
+const uint32_t *orc_dof_grid(const orc_problem *P, int l) { return P->levels[l].dof_grid; }
+const double *orc_shape_values(const orc_problem *P) { return P->basis.S; }
+const double *orc_colloc_grad(const orc_problem *P) { return P->basis.D; }
+const double *orc_qweights(const orc_problem *P) { return P->basis.gw; }
+const double *orc_qpoints(const orc_problem *P) { return P->basis.gq; }
+const double *orc_gll(const orc_problem *P) { return P->basis.gll; }
+const double *orc_prolong_1d(const orc_problem *P) { return P->basis.P1; }
+const double *orc_rhs(const orc_problem *P, int l) { return P->rhs[l]; }
+const double *orc_inv_diag(const orc_problem *P, int l) { return VL(P)[l].cheb.inv_diag; }
+double orc_h(const orc_problem *P, int l) { return P->levels[l].h; }
+const double *orc_solution(orc_problem *P, int l) { return P->solution[l]; }
+
+void orc_cheb_info(const orc_problem *P, int l, double *lambda_min, double *lambda_max, double *theta,
+                   double *delta, int *degree, int *cg_its)
+{
+  const cheb_d *C = &VL(P)[l].cheb;
+  *lambda_min     = C->lambda_min;
+  *lambda_max     = C->lambda_max;
+  *theta          = C->theta;
+  *delta          = C->delta;
+  *degree         = C->degree;
+  *cg_its         = C->cg_its;
+}
+
+uint32_t orc_bc(const orc_problem *P, int l, uint32_t *idx, double *val)
+{
+  if (idx)
+    memcpy(idx, P->bc_idx[l], sizeof(uint32_t) * P->bc_count[l]);
+  if (val)
+    memcpy(val, P->bc_val[l], sizeof(double) * P->bc_count[l]);
+  return P->bc_count[l];
+}
+
+/* ---- operator entry points (fp64 = matrix_dp) ---- */
+void orc_vmult(const orc_problem *P, int l, double *dst, const double *src)
+{
+  vmult_d(P, &P->levels[l], BD(P), dst, src);
+}
+
+void orc_vmult_residual(const orc_problem *P, int l, const double *rhs, const double *lhs, double *res)
+{
+  vmult_residual_d(P, &P->levels[l], BD(P), rhs, lhs, res);
+}
+
+/* Independent check: dense element matrix from plain nodal gradients G (no collocation trick, no
+ * sum factorisation), applied on the lexicographic grid with explicit Dirichlet identity rows. */
+void orc_vmult_dense_lex(const orc_problem *P, int l, double *dst, const double *src)
+{
+  const orc_level *L = &P->levels[l];
+  const orc_basis *b = &P->basis;
+  const int        p = P->p, n = p + 1, n3 = n * n * n;
+  const size_t     G = (size_t)L->N * p + 1;
+  double          *A = (double *)calloc((size_t)n3 * n3, sizeof(double));
+  /* A_ij = h sum_q w_q grad phi_i . grad phi_j */
+  for (int qz = 0; qz < n; ++qz)
+    for (int qy = 0; qy < n; ++qy)
+      for (int qx = 0; qx < n; ++qx)
+        {
+          const double w = b->gw[qx] * b->gw[qy] * b->gw[qz] * L->h;
+          for (int i = 0; i < n3; ++i)
+            {
+              const int ix = i % n, iy = (i / n) % n, iz = i / (n * n);
+              const double gi[3] = {b->G[qx * n + ix] * b->S[qy * n + iy] * b->S[qz * n + iz],
+                                    b->S[qx * n + ix] * b->G[qy * n + iy] * b->S[qz * n + iz],
+                                    b->S[qx * n + ix] * b->S[qy * n + iy] * b->G[qz * n + iz]};
+              for (int j = 0; j < n3; ++j)
+                {
+                  const int jx = j % n, jy = (j / n) % n, jz = j / (n * n);
+                  const double gj[3] = {b->G[qx * n + jx] * b->S[qy * n + jy] * b->S[qz * n + jz],
+                                        b->S[qx * n + jx] * b->G[qy * n + jy] * b->S[qz * n + jz],
+                                        b->S[qx * n + jx] * b->S[qy * n + jy] * b->G[qz * n + jz]};
+                  A[(size_t)i * n3 + j] += w * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]);
+                }
+            }
+        }
+  memset(dst, 0, sizeof(double) * G * G * G);
+  for (int Z = 0; Z < L->N; ++Z)
+    for (int Y = 0; Y < L->N; ++Y)
+      for (int X = 0; X < L->N; ++X)
+        for (int i = 0; i < n3; ++i)
+          {
+            const size_t gi = (((size_t)Z * p + i / (n * n)) * G + ((size_t)Y * p + (i / n) % n)) * G +
+                              (size_t)X * p + i % n;
+            const size_t ix = gi % G, iy = (gi / G) % G, iz = gi / (G * G);
+            if (ix == 0 || ix == G - 1 || iy == 0 || iy == G - 1 || iz == 0 || iz == G - 1)
+              continue;
+            double s = 0;
+            for (int j = 0; j < n3; ++j)
+              {
+                const size_t jx = (size_t)X * p + j % n, jy = (size_t)Y * p + (j / n) % n,
+                             jz = (size_t)Z * p + j / (n * n);
+                if (jx == 0 || jx == G - 1 || jy == 0 || jy == G - 1 || jz == 0 || jz == G - 1)
+                  continue;
+                s += A[(size_t)i * n3 + j] * src[(jz * G + jy) * G + jx];
+              }
+            dst[gi] += s;
+          }
+  for (size_t iz = 0; iz < G; ++iz)
+    for (size_t iy = 0; iy < G; ++iy)
+      for (size_t ix = 0; ix < G; ++ix)
+        if (ix == 0 || ix == G - 1 || iy == 0 || iy == G - 1 || iz == 0 || iz == G - 1)
+          dst[(iz * G + iy) * G + ix] = src[(iz * G + iy) * G + ix];
+  free(A);
+}
+
+/* ---- helpers converting the double interface to the V-cycle number type ---- */
+static float *to_float(uint32_t n, const double *a)
+{
+  float *f = (float *)malloc(sizeof(float) * n);
+  for (uint32_t i = 0; i < n; ++i)
+    f[i] = (float)a[i];
+  return f;
+}
+static void from_float(uint32_t n, double *a, const float *f)
+{
+  for (uint32_t i = 0; i < n; ++i)
+    a[i] = f[i];
+}
+
+void orc_cheb_vmult(orc_problem *P, int l, double *x, const double *b)
+{
+  const orc_level *L = &P->levels[l];
+  if (!P->vfloat)
+    cheb_vmult_d(P, L, BD(P), &VL(P)[l].cheb, x, b);
+  else
+    {
+      float *bf = to_float(L->n_dofs, b), *xf = (float *)calloc(L->n_dofs, sizeof(float));
+      cheb_vmult_f(P, L, BF(P), &VL(P)[l].cheb_f_, xf, bf);
+      from_float(L->n_dofs, x, xf);
+      free(bf);
+      free(xf);
+    }
+}
+
+void orc_cheb_step(orc_problem *P, int l, double *x, const double *b)
+{
+  const orc_level *L = &P->levels[l];
+  if (!P->vfloat)
+    cheb_step_d(P, L, BD(P), &VL(P)[l].cheb, x, b);
+  else
+    {
+      float *bf = to_float(L->n_dofs, b), *xf = to_float(L->n_dofs, x);
+      cheb_step_f(P, L, BF(P), &VL(P)[l].cheb_f_, xf, bf);
+      from_float(L->n_dofs, x, xf);
+      free(bf);
+      free(xf);
+    }
+}
+
+void orc_prolongate(const orc_problem *P, int l, double *fine, const double *coarse, int add, int with_bc)
+{
+  prolongate_d(P, &P->levels[l - 1], &P->levels[l], BD(P), fine, coarse, add, with_bc);
+}
+
+void orc_restrict_and_add(const orc_problem *P, int l, double *coarse, const double *fine, int with_bc)
+{
+  restrict_and_add_d(P, &P->levels[l - 1], &P->levels[l], BD(P), coarse, fine, with_bc);
+}
+
+/* MultigridSolver::v_cycle (multigrid_solver.h:641-681) */
+static void v_cycle(orc_problem *P, int level, int my_n_cycles)
+{
+  vlevel          *V = VL(P);
+  const orc_level *L = &P->levels[level];
+  if (level == 0) /* :644-651  coarse = smooth[0].vmult (:72-91) */
+    {
+      if (!P->vfloat)
+        cheb_vmult_d(P, L, BD(P), &V[0].cheb, V[0].solution_update, V[0].defect);
+      else
+        cheb_vmult_f(P, L, BF(P), &V[0].cheb_f_, V[0].solution_update_f, V[0].defect_f);
+      return;
+    }
+  const orc_level *Lc = &P->levels[level - 1];
+  for (int c = 0; c < my_n_cycles; ++c)
+    {
+      if (!P->vfloat)
+        {
+          if (c == 0) /* :656-659 */
+            cheb_vmult_d(P, L, BD(P), &V[level].cheb, V[level].solution_update, V[level].defect);
+          else
+            cheb_step_d(P, L, BD(P), &V[level].cheb, V[level].solution_update, V[level].defect);
+          vmult_residual_d(P, L, BD(P), V[level].defect, V[level].solution_update, V[level].t); /* :663 */
+          memset(V[level - 1].defect, 0, sizeof(double) * Lc->n_dofs);                           /* :667 */
+          restrict_and_add_d(P, Lc, L, BD(P), V[level - 1].defect, V[level].t, 1);               /* :668 */
+          v_cycle(P, level - 1, 1);                                                              /* :671 */
+          prolongate_d(P, Lc, L, BD(P), V[level].solution_update, V[level - 1].solution_update, 1, 1); /* :674 */
+          cheb_step_d(P, L, BD(P), &V[level].cheb, V[level].solution_update, V[level].defect);   /* :678 */
+        }
+      else
+        {
+          if (c == 0)
+            cheb_vmult_f(P, L, BF(P), &V[level].cheb_f_, V[level].solution_update_f, V[level].defect_f);
+          else
+            cheb_step_f(P, L, BF(P), &V[level].cheb_f_, V[level].solution_update_f, V[level].defect_f);
+          vmult_residual_f(P, L, BF(P), V[level].defect_f, V[level].solution_update_f, V[level].t_f);
+          memset(V[level - 1].defect_f, 0, sizeof(float) * Lc->n_dofs);
+          restrict_and_add_f(P, Lc, L, BF(P), V[level - 1].defect_f, V[level].t_f, 1);
+          v_cycle(P, level - 1, 1);
+          prolongate_f(P, Lc, L, BF(P), V[level].solution_update_f, V[level - 1].solution_update_f, 1, 1);
+          cheb_step_f(P, L, BF(P), &V[level].cheb_f_, V[level].solution_update_f, V[level].defect_f);
+        }
+    }
+}
+
+/* defect[level] = v (precision cast, multigrid_solver.h:437, 503) */
+static void set_defect(orc_problem *P, int level, const double *v)
+{
+  vlevel        *V = VL(P);
+  const uint32_t n = P->levels[level].n_dofs;
+  if (!P->vfloat)
+    memcpy(V[level].defect, v, sizeof(double) * n);
+  else
+    for (uint32_t i = 0; i < n; ++i)
+      V[level].defect_f[i] = (float)v[i];
+}
+
+void orc_vcycle_apply(orc_problem *P, double *dst, const double *src)
+{
+  const int      lmax = P->n_levels - 1;
+  vlevel        *V    = VL(P);
+  const uint32_t n    = P->levels[lmax].n_dofs;
+  set_defect(P, lmax, src); /* :503 */
+  v_cycle(P, lmax, 1);      /* :505 */
+  if (!P->vfloat)           /* :507 */
+    memcpy(dst, V[lmax].solution_update, sizeof(double) * n);
+  else
+    for (uint32_t i = 0; i < n; ++i)
+      dst[i] = V[lmax].solution_update_f[i];
+}
+
+static double l2_norm(uint32_t n, const double *a) { return sqrt(dot_d(n, a, a)); }
+
+double orc_l2_error(orc_problem *P, int level)
+{
+  const orc_level *L = &P->levels[level];
+  const int        p = P->p, n = p + 1, n3 = n * n * n;
+  const basis_d   *B = BD(P);
+  set_bc(P, level, P->solution[level], 0); /* :301-302 */
+  double err = 0, vol = 0;
+#pragma omp parallel reduction(+ : err, vol)
+  {
+    double *u = (double *)malloc(sizeof(double) * 2 * n3), *t0 = u + n3;
+#pragma omp for schedule(static)
+    for (uint32_t c = 0; c < L->n_cells; ++c)
+      {
+        gather27_d(p, L->idx27_plain + 27 * (size_t)c, P->solution[level], u); /* read_dof_values_plain */
+        sweep_d(n, 0, B->S, u, t0, 0);
+        sweep_d(n, 1, B->S, t0, u, 0);
+        sweep_d(n, 2, B->S, u, t0, 0);
+        const double x0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c],
+                     y0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 1],
+                     z0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 2];
+        for (int k = 0, q = 0; k < n; ++k)
+          for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i, ++q)
+              {
+                const double JxW = B->w[i] * B->w[j] * B->w[k] * L->h * L->h * L->h;
+                const double d   = t0[q] - u_exact(x0 + L->h * P->basis.gq[i], y0 + L->h * P->basis.gq[j],
+                                                   z0 + L->h * P->basis.gq[k]);
+                err += d * d * JxW;
+                vol += JxW;
+              }
+      }
+    free(u);
+  }
+  return sqrt(err / vol);
+}
+
+/* MultigridSolver::solve (multigrid_solver.h:387-476) */
+double orc_solve(orc_problem *P, int do_analyze, double *trace)
+{
+  vlevel *V              = VL(P);
+  double  reduction_rate = 1.;
+  const orc_level *L0    = &P->levels[0];
+  /* coarse solver invoked twice (:397-400) */
+  set_defect(P, 0, P->rhs[0]);
+  if (!P->vfloat)
+    {
+      cheb_vmult_d(P, L0, BD(P), &V[0].cheb, V[0].t, V[0].defect);
+      cheb_step_d(P, L0, BD(P), &V[0].cheb, V[0].t, V[0].defect);
+      memcpy(P->solution[0], V[0].t, sizeof(double) * L0->n_dofs);
+    }
+  else
+    {
+      cheb_vmult_f(P, L0, BF(P), &V[0].cheb_f_, V[0].t_f, V[0].defect_f);
+      cheb_step_f(P, L0, BF(P), &V[0].cheb_f_, V[0].t_f, V[0].defect_f);
+      from_float(L0->n_dofs, P->solution[0], V[0].t_f);
+    }
+  for (int level = 1; level < P->n_levels; ++level)
+    {
+      const orc_level *L = &P->levels[level];
+      set_bc(P, level - 1, P->solution[level - 1], 0);                                    /* :408-409 */
+      prolongate_d(P, &P->levels[level - 1], L, BD(P), P->solution[level], P->solution[level - 1], 0,
+                   0);                                                                    /* :415 */
+      double init_residual = 1.;
+      if (do_analyze && trace)
+        trace[4 * level + 0] = orc_l2_error(P, level);                                    /* :422 */
+      set_bc(P, level, P->solution[level], 1);                                            /* :427-428 */
+      vmult_residual_d(P, L, BD(P), P->rhs[level], P->solution[level], P->residual[level]); /* :432 */
+      set_defect(P, level, P->residual[level]);                                           /* :437 */
+      if (do_analyze)
+        {
+          init_residual = l2_norm(L->n_dofs, P->residual[level]);                         /* :444 */
+          if (trace)
+            trace[4 * level + 1] = init_residual;
+        }
+      v_cycle(P, level, P->n_cycles);                                                     /* :451 */
+      if (!P->vfloat)                                                                     /* :456 */
+        for (uint32_t i = 0; i < L->n_dofs; ++i)
+          P->solution[level][i] += V[level].solution_update[i];
+      else
+        for (uint32_t i = 0; i < L->n_dofs; ++i)
+          P->solution[level][i] += V[level].solution_update_f[i];
+      if (do_analyze)
+        {
+          set_bc(P, level, P->solution[level], 1);                                        /* :462-463 */
+          vmult_d(P, L, BD(P), P->residual[level], P->solution[level]);                   /* :464 */
+          for (uint32_t i = 0; i < L->n_dofs; ++i)                                        /* :465 */
+            P->residual[level][i] = P->rhs[level][i] - P->residual[level][i];
+          const double res_norm = l2_norm(L->n_dofs, P->residual[level]);                 /* :466 */
+          reduction_rate        = pow(res_norm / init_residual, 1. / P->n_cycles);        /* :467 */
+          if (trace)
+            {
+              trace[4 * level + 2] = res_norm;
+              trace[4 * level + 3] = orc_l2_error(P, level);                              /* :470 */
+            }
+        }
+    }
+  return reduction_rate;
+}
+
+/* MultigridSolver::solve_cg (multigrid_solver.h:483-493) with deal.II's SolverCG restated
+ * (SURVEY 8a row T): ReductionControl(1000, 1e-16, 1e-9), zero start, V-cycle preconditioner */
+int orc_solve_cg(orc_problem *P, double *reduction)
+{
+  const int        lmax = P->n_levels - 1;
+  const orc_level *L    = &P->levels[lmax];
+  const uint32_t   n    = L->n_dofs;
+  double          *x    = P->solution[lmax];
+  double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n),
+         *d = (double *)malloc(sizeof(double) * n), *h = (double *)malloc(sizeof(double) * n);
+  memset(x, 0, sizeof(double) * n); /* :488 */
+  memcpy(r, P->rhs[lmax], sizeof(double) * n);
+  const double res0 = l2_norm(n, r);
+  double       res  = res0, rz = 0, rz_old;
+  int          it   = 0;
+  while (res > 1e-16 && res > 1e-9 * res0 && it < 1000)
+    {
+      ++it;
+      orc_vcycle_apply(P, z, r);
+      rz_old = rz;
+      rz     = dot_d(n, r, z);
+      if (it > 1)
+        {
+          const double beta = rz / rz_old;
+          for (uint32_t i = 0; i < n; ++i)
+            d[i] = z[i] + beta * d[i];
+        }
+      else
+        memcpy(d, z, sizeof(double) * n);
+      vmult_d(P, L, BD(P), h, d);
+      const double alpha = rz / dot_d(n, d, h);
+      for (uint32_t i = 0; i < n; ++i)
+        {
+          x[i] += alpha * d[i];
+          r[i] -= alpha * h[i];
+        }
+      res = l2_norm(n, r);
+    }
+  if (reduction)
+    *reduction = it > 0 ? pow(res / res0, 1. / it) : 1.; /* :491-492 */
+  free(r);
+  free(z);
+  free(d);
+  free(h);
+  return it;
+}
+
+/* ---- timing helpers for the cpu_baseline leg of bench.py ---- */
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+double orc_time_vmult(orc_problem *P, int level, int n)
+{
+  /* MultigridSolver::do_matvec (multigrid_solver.h:624-628) */
+  const double t0 = now_s();
+  for (int i = 0; i < n; ++i)
+    vmult_d(P, &P->levels[level], BD(P), P->residual[level], P->solution[level]);
+  return now_s() - t0;
+}
+
+double orc_time_vcycle(orc_problem *P, int n)
+{
+  const int lmax = P->n_levels - 1;
+  double   *dst  = (double *)malloc(sizeof(double) * P->levels[lmax].n_dofs);
+  const double t0 = now_s();
+  for (int i = 0; i < n; ++i)
+    orc_vcycle_apply(P, dst, P->rhs[lmax]);
+  const double t = now_s() - t0;
+  free(dst);
+  return t;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
