@@ -1,0 +1,220 @@
+/*
+ * mgx.h -- C ABI of the MI355X-native matrix-free multigrid Laplace path (libmgx.so).
+ *
+ * The reference has no FFI seam; the de-facto interface of the path are the public members of two
+ * C++ class templates:
+ *     multigrid::LaplaceOperator<dim,p,number>         common/laplace_operator.h:56-164
+ *     multigrid::MultigridSolver<dim,p,Number,Number2> common/multigrid_solver.h:96-782
+ * plus the deal.II objects they drive (PreconditionChebyshev, MGTransferMatrixFree, SolverCG).
+ * Every entry point below names the reference member (file:line, relative to the reference root)
+ * it replaces.  include/multigrid_shim.hpp re-creates the two classes on top of this ABI.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (MGX_OK == 0) and never throws;
+ *     mgx_last_error() gives the message of the last failure on the calling thread.
+ *   - "device pointer" arguments are HIP device allocations of the level's number type
+ *     (float for MGX_F32, double for MGX_F64) holding n_dofs entries laid out exactly like the
+ *     locally-owned range of deal.II's LinearAlgebra::distributed::Vector.
+ *   - all work is enqueued on the context's HIP stream; results that are returned to the host
+ *     (norms, iteration counts) synchronise that stream, everything else is asynchronous
+ *     until mgx_sync().
+ *   - one host thread per context (the reference is single-threaded per MPI rank,
+ *     multigrid_solver.h:153,176).
+ *   - there is NO CPU fallback: without a HIP device mgx_context_create() fails.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_OK 0
+#define MGX_ERR_INVALID_ARGUMENT (-1)
+#define MGX_ERR_NO_DEVICE (-2)
+#define MGX_ERR_HIP (-3)
+#define MGX_ERR_UNSUPPORTED (-4)
+#define MGX_ERR_NOT_CONVERGED (-5)
+
+#define MGX_F32 0
+#define MGX_F64 1
+
+#define MGX_INVALID_INDEX 0xFFFFFFFFu /* dealii::numbers::invalid_unsigned_int */
+#define MGX_MAX_DEGREE 9              /* poisson_cube/program.cc:69 */
+
+typedef struct mgx_context_s  *mgx_context_t;
+typedef struct mgx_operator_s *mgx_operator_t;  /* LaplaceOperator<3,p,number> of one level */
+typedef struct mgx_smoother_s *mgx_smoother_t;  /* PreconditionChebyshev<LaplaceOperator,...> */
+typedef struct mgx_transfer_s *mgx_transfer_t;  /* one level pair of MGTransferMatrixFree */
+typedef struct mgx_solver_s   *mgx_solver_t;    /* MultigridSolver<3,p,Number,double> */
+
+const char *mgx_last_error(void);
+const char *mgx_version(void);
+
+/* ---- context: device + stream (replaces MPI_InitFinalize / the implicit host execution
+ * context, poisson_cube/program.cc:664) ---- */
+int mgx_context_create(mgx_context_t *ctx, int device);
+int mgx_context_destroy(mgx_context_t ctx);
+int mgx_sync(mgx_context_t ctx);
+/* raw HIP stream (hipStream_t) the context enqueues on, for callers that time with HIP events */
+void *mgx_context_stream(mgx_context_t ctx);
+
+/* ---- device vectors (LinearAlgebra::distributed::Vector<number> storage) ---- */
+int mgx_malloc(mgx_context_t ctx, void **dptr, size_t bytes);
+int mgx_free(mgx_context_t ctx, void *dptr);
+int mgx_upload(mgx_context_t ctx, void *dptr, const void *hptr, size_t bytes);
+int mgx_download(mgx_context_t ctx, void *hptr, const void *dptr, size_t bytes);
+int mgx_memset_zero(mgx_context_t ctx, void *dptr, size_t bytes); /* Vector::operator=(0) */
+
+/* vector kernels used by the driver; `number` = MGX_F32 / MGX_F64 */
+/* dst = src with precision cast: multigrid_solver.h:437,503,507 */
+int mgx_copy_cast(mgx_context_t ctx, void *dst, int dst_number, const void *src, int src_number, size_t n);
+/* dst += src with precision cast: internal::add_vector multigrid_solver.h:54-67 */
+int mgx_add_cast(mgx_context_t ctx, void *dst, int dst_number, const void *src, int src_number, size_t n);
+/* x = s*x + a*v : Vector::sadd, multigrid_solver.h:465 */
+int mgx_sadd(mgx_context_t ctx, int number, void *x, double s, double a, const void *v, size_t n);
+/* x . y and ||x||_2 (Vector::l2_norm multigrid_solver.h:263,444,466; operator* in SolverCG) */
+int mgx_dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *result);
+int mgx_l2_norm(mgx_context_t ctx, int number, const void *x, size_t n, double *result);
+/* v[idx[i]] = val[i] (host index/value lists): multigrid_solver.h:257-259,408-409,427-428 */
+int mgx_set_entries(mgx_context_t ctx, int number, void *v, const uint32_t *idx_host,
+                    const double *val_host, uint32_t count);
+
+/* ---- LaplaceOperator ---- */
+typedef struct
+{
+  int      degree;  /* fe_degree p, 1..9 */
+  int      number;  /* MGX_F32 / MGX_F64: template parameter `number` */
+  uint32_t n_cells; /* MatrixFree::n_cell_batches() * lanes, real cells only */
+  uint32_t n_dofs;  /* locally owned size of the level vector */
+  /* LaplaceOperator::get_compressed_dof_indices() (laplace_operator.h:114-118, built by
+   * extract_compressed_indices :224-353) de-interleaved to one row of 27 per cell:
+   * idx27[27*cell + 9*cz+3*cy+cx] = first DoF of that mesh entity, MGX_INVALID_INDEX where
+   * the entity is constrained.  Host pointer, copied. */
+  const uint32_t *idx27;
+  /* the same table built without constraints (dof-handler slot 1 of matrix_dp,
+   * multigrid_solver.h:180-190); needed by the transfers.  Host pointer, copied; may be NULL
+   * if the operator is never used in a transfer. */
+  const uint32_t *idx27_plain;
+  /* MatrixFree::get_constrained_dofs() (laplace_operator.h:592,632,736) */
+  const uint32_t *constrained;
+  uint32_t        n_constrained;
+  /* merged_coefficient of the affine / constant-coefficient branch, [xx,yy,zz,xy,xz,yz]
+   * (laplace_operator.h:127, 374-387); the quadrature weight is applied per point (:456-457) */
+  double coef[6];
+  /* 1D data of FEEvaluation<3,p,p+1>, row-major (p+1)x(p+1):
+   * shape_values[q*(p+1)+i] = GLL-Lagrange basis i at Gauss point q;
+   * colloc_grad[q*(p+1)+r] = derivative of the Gauss-point Lagrange basis r at Gauss point q;
+   * qweights[q] = Gauss weights on [0,1]. */
+  const double *shape_values;
+  const double *colloc_grad;
+  const double *qweights;
+} mgx_operator_desc;
+
+/* LaplaceOperator::initialize + evaluate_coefficient (laplace_operator.h:184-220, 357-432) */
+int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_operator_t *op);
+int mgx_operator_destroy(mgx_operator_t op);
+uint32_t mgx_operator_n_dofs(mgx_operator_t op); /* Base::m() */
+int mgx_operator_number(mgx_operator_t op);
+/* LaplaceOperator::vmult(dst, src) laplace_operator.h:573-601 */
+int mgx_vmult(mgx_operator_t op, void *dst, const void *src);
+/* LaplaceOperator::vmult_residual(rhs, lhs, residual) laplace_operator.h:605-634 */
+int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void *residual);
+/* LaplaceOperator::compute_diagonal() laplace_operator.h:745-800; the inverse diagonal is kept
+ * by the operator (Base::get_matrix_diagonal_inverse()) */
+int mgx_compute_diagonal(mgx_operator_t op);
+int mgx_get_inverse_diagonal(mgx_operator_t op, const void **dptr);
+
+/* ---- PreconditionChebyshev (deal.II; configured at multigrid_solver.h:269-289) ---- */
+/* SmootherType::initialize(matrix, additional_data) + estimate_eigenvalues.
+ * degree < 0 == numbers::invalid_unsigned_int (determine from smoothing_range, level 0) */
+int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree,
+                        int eig_cg_n_iterations, mgx_smoother_t *smoother);
+int mgx_smoother_destroy(mgx_smoother_t smoother);
+typedef struct
+{
+  double lambda_min, lambda_max, theta, delta;
+  int    degree, cg_iterations;
+} mgx_smoother_info;
+int mgx_smoother_get_info(mgx_smoother_t smoother, mgx_smoother_info *info);
+/* PreconditionChebyshev::vmult (zero start) / ::step (multigrid_solver.h:399,657-659,678) */
+int mgx_smoother_vmult(mgx_smoother_t smoother, void *x, const void *b);
+int mgx_smoother_step(mgx_smoother_t smoother, void *x, const void *b);
+
+/* ---- MGTransferMatrixFree, one level pair (built at multigrid_solver.h:209-222) ---- */
+typedef struct
+{
+  /* children[8*parent + c] = fine-level cell index of child c (c = x + 2y + 4z) of coarse cell
+   * `parent` (deal.II: cell->child(c)); host pointer, copied */
+  const uint32_t *children;
+  /* prolong_1d[a*(p+1)+i], a in [0,2p]: coarse 1D basis i at the fine patch point a */
+  const double *prolong_1d;
+} mgx_transfer_desc;
+int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_transfer_desc *desc,
+                        mgx_transfer_t *transfer);
+int mgx_transfer_destroy(mgx_transfer_t transfer);
+/* prolongate (add==0, multigrid_solver.h:415) / prolongate_and_add (add!=0, :674);
+ * with_constraints != 0: the level's Dirichlet entries are treated as zero
+ * (transfer.initialize_constraints, :220) */
+int mgx_prolongate(mgx_transfer_t transfer, void *fine, const void *coarse, int add, int with_constraints);
+/* restrict_and_add (multigrid_solver.h:668) */
+int mgx_restrict_and_add(mgx_transfer_t transfer, void *coarse, const void *fine, int with_constraints);
+
+/* ---- MultigridSolver ---- */
+typedef struct
+{
+  int n_levels;      /* maxlevel + 1 (multigrid_solver.h:108-109) */
+  int degree_pre;    /* ctor argument degree_pre == degree_post (:126) */
+  int n_cycles;      /* ctor argument n_cycles */
+  /* per level: the V-cycle-precision operator `matrix` (:740) and the fp64 operator
+   * `matrix_dp` (:745).  If the V-cycle number type is fp64, matrix[l] may equal matrix_dp[l]. */
+  const mgx_operator_t *matrix;
+  const mgx_operator_t *matrix_dp;
+  /* per level l >= 1 (entry 0 unused): the level pair (l-1, l) in V-cycle precision with
+   * constraints (`transfer`, :691) and in fp64 without (`mg_transfer_no_boundary`, :690).
+   * The two may be the same object when the number types coincide. */
+  const mgx_transfer_t *transfer;
+  const mgx_transfer_t *transfer_dp;
+  /* per level: rhs[level] as computed by compute_residual (:261), host fp64, n_dofs entries */
+  const double *const *rhs;
+  /* per level: inhomogeneous_bc[level] (:225-253) as index/value lists (host) */
+  const uint32_t *const *bc_index;
+  const double *const   *bc_value;
+  const uint32_t        *bc_count;
+} mgx_solver_desc;
+
+/* MultigridSolver ctor from the smoother set-up on (:269-289): computes diagonals, estimates
+ * eigenvalues, allocates the level vectors (:709-735) */
+int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver_t *solver);
+int mgx_solver_destroy(mgx_solver_t solver);
+/* MultigridSolver::solve(do_analyze) :387-476.  trace (may be NULL) receives for every level
+ * l >= 1 the residual norms {start, end} at trace[2*l], trace[2*l+1] when do_analyze != 0
+ * (the L2 errors printed next to them need the analytic solution and are computed by the
+ * caller from mgx_solver_get_solution, as the reference does on the host, :298-343). */
+int mgx_solver_solve(mgx_solver_t solver, int do_analyze, double *reduction_rate, double *trace);
+/* MultigridSolver::solve_cg() :483-493: SolverCG with ReductionControl(1000,1e-16,1e-9) */
+int mgx_solver_solve_cg(mgx_solver_t solver, unsigned int *iterations, double *reduction_rate);
+/* MultigridSolver::vmult(dst, src) :498-510: one V-cycle; dst/src fp64 device vectors */
+int mgx_solver_vmult(mgx_solver_t solver, double *dst, const double *src);
+/* MultigridSolver::do_matvec() :624-628 / do_matvec_smoother() :633-637 */
+int mgx_solver_do_matvec(mgx_solver_t solver);
+int mgx_solver_do_matvec_smoother(mgx_solver_t solver);
+/* MultigridSolver::get_solution() :376-382 (boundary values inserted); device fp64 pointer of
+ * solution[level] */
+int mgx_solver_get_solution(mgx_solver_t solver, int level, int insert_bc, const double **dptr);
+/* device pointers of the level vectors, for tests: which = 0 rhs, 1 residual (fp64);
+ * 2 defect, 3 t, 4 solution_update (V-cycle precision) */
+int mgx_solver_get_vector(mgx_solver_t solver, int level, int which, void **dptr);
+int mgx_solver_get_smoother(mgx_solver_t solver, int level, mgx_smoother_t *smoother);
+/* MultigridSolver::print_wall_times() :348-371: per level 6 accumulated times
+ * {mg_mv, restrict, prolongate, inhomBC, mg_vec, smoother} in seconds (HIP events); resets */
+int mgx_solver_get_timings(mgx_solver_t solver, double *timings /* n_levels*6 */);
+int mgx_solver_enable_timings(mgx_solver_t solver, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+/*
+ * mgx_cube.h -- host-side discretisation provider for the poisson_cube problem.
+ *
+ * In the reference everything in this header is supplied by deal.II (p4est mesh, DoFHandler,
+ * MatrixFree, FE_Q shape info) and by the constructor of MultigridSolver; deal.II is not
+ * available to this build, so the structured-cube equivalent is provided here and feeds the
+ * device ABI of mgx.h.  A deal.II based caller would fill the mgx_* descriptors from
+ * LaplaceOperator::get_compressed_dof_indices() etc. instead.
+ *
+ *   mesh              GridGenerator::subdivided_hyper_cube(tria, n_subdiv, -0.9, 1.0) +
+ *                     refine_global(n_refine)            poisson_cube/program.cc:542,570
+ *   cell order        forest/Morton order (p4est), children of cell c are 8c..8c+7
+ *   DoF numbering     entity-contiguous, lexicographic inside an entity, Dirichlet DoFs last
+ *                     (contract of laplace_operator.h:272-340)
+ *   problem           u = prod sin(3 pi x_d), f = 27 pi^2 u, coefficient 1, Dirichlet on all
+ *                     faces                              poisson_cube/program.cc:98-144,266
+ */
+#ifndef MGX_CUBE_H
+#define MGX_CUBE_H
+
+#include "mgx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_cube_s *mgx_cube_t;
+
+int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *cube);
+int mgx_cube_destroy(mgx_cube_t cube);
+
+int      mgx_cube_n_levels(mgx_cube_t cube);
+int      mgx_cube_degree(mgx_cube_t cube);
+uint32_t mgx_cube_n_cells(mgx_cube_t cube, int level);
+uint32_t mgx_cube_n_dofs(mgx_cube_t cube, int level);
+uint32_t mgx_cube_n_constrained(mgx_cube_t cube, int level);
+uint32_t mgx_cube_cells_per_dim(mgx_cube_t cube, int level);
+double   mgx_cube_cell_size(mgx_cube_t cube, int level);
+
+/* tables (host memory owned by the cube) */
+const uint32_t *mgx_cube_idx27(mgx_cube_t cube, int level);
+const uint32_t *mgx_cube_idx27_plain(mgx_cube_t cube, int level);
+const uint32_t *mgx_cube_constrained(mgx_cube_t cube, int level);
+const uint32_t *mgx_cube_children(mgx_cube_t cube, int level); /* level >= 1: [n_cells(level-1)*8] */
+const uint32_t *mgx_cube_cell_coords(mgx_cube_t cube, int level);
+/* dof -> lexicographic grid id ((gz*G+gy)*G+gx, G = N*p+1); computed on first use */
+const uint32_t *mgx_cube_dof_grid(mgx_cube_t cube, int level);
+const double   *mgx_cube_shape_values(mgx_cube_t cube);
+const double   *mgx_cube_colloc_grad(mgx_cube_t cube);
+const double   *mgx_cube_qweights(mgx_cube_t cube);
+const double   *mgx_cube_qpoints(mgx_cube_t cube);
+const double   *mgx_cube_gll(mgx_cube_t cube);
+const double   *mgx_cube_prolong_1d(mgx_cube_t cube);
+
+/* MultigridSolver ctor pieces computed on the host (multigrid_solver.h:225-261):
+ * inhomogeneous boundary values and rhs = int f phi - int grad u_bc . grad phi */
+const double   *mgx_cube_rhs(mgx_cube_t cube, int level);
+uint32_t        mgx_cube_bc_count(mgx_cube_t cube, int level);
+const uint32_t *mgx_cube_bc_index(mgx_cube_t cube, int level);
+const double   *mgx_cube_bc_value(mgx_cube_t cube, int level);
+
+/* fills desc for LaplaceOperator<3,p,number> on `level` (pointers stay owned by the cube) */
+int mgx_cube_operator_desc(mgx_cube_t cube, int level, int number, mgx_operator_desc *desc);
+
+/* MultigridSolver::compute_l2_error (multigrid_solver.h:298-343) for a host copy of
+ * solution[level] (boundary values already inserted) */
+double mgx_cube_l2_error(mgx_cube_t cube, int level, const double *solution_host);
+
+/* seeded benchmark vector of SURVEY.md 8d: value depends only on the global grid index, uniform
+ * in [-1,1) (splitmix64 of seed+grid id), written in the level's DoF numbering */
+int mgx_cube_seeded_vector(mgx_cube_t cube, int level, uint64_t seed, double *out_host);
+
+/* Convenience: everything MultigridSolver's constructor builds, on the device.
+ * vcycle_number = MGX_F32 (reference default, program.cc:76) or MGX_F64. */
+typedef struct
+{
+  int             n_levels;
+  mgx_operator_t *matrix;     /* [n_levels] V-cycle precision */
+  mgx_operator_t *matrix_dp;  /* [n_levels] fp64 (== matrix[l] if vcycle_number is fp64) */
+  mgx_transfer_t *transfer;    /* [n_levels], entry 0 NULL */
+  mgx_transfer_t *transfer_dp; /* [n_levels], entry 0 NULL (== transfer[l] if fp64) */
+  mgx_solver_t    solver;
+} mgx_cube_solver;
+
+int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vcycle_number, int degree_pre, int n_cycles,
+                           mgx_cube_solver *out);
+int mgx_cube_solver_destroy(mgx_cube_solver *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

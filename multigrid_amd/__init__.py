@@ -1,0 +1,386 @@
+"""multigrid_amd -- MI355X-native matrix-free geometric multigrid for the Laplace operator.
+
+Host-side mirror (Python, for tests and bench.py) of the reference's operator / solver interface
+for the poisson_cube path on top of the C ABI in include/mgx.h:
+
+    LaplaceOperator  <-> multigrid::LaplaceOperator   common/laplace_operator.h:56-164
+    MultigridSolver  <-> multigrid::MultigridSolver   common/multigrid_solver.h:96-782
+    Cube             <-> the deal.II mesh / DoFHandler / MatrixFree data of poisson_cube/program.cc
+
+All numerical work runs in hand-written HIP kernels inside libmgx.so; nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import F32, F64, INVALID_INDEX, MgxError, check
+
+__all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
+           "F32", "F64", "INVALID_INDEX", "MgxError"]
+
+_DT = {F32: np.float32, F64: np.float64}
+
+
+class Context:
+    """HIP device + stream (mgx_context_t)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.mgx_context_create(C.byref(h), device))
+        self.h = h
+
+    def sync(self):
+        check(self.lib.mgx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.mgx_context_stream(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mgx_context_destroy(self.h)
+            self.h = None
+
+    def vector(self, n, number=F64, data=None):
+        return DeviceVector(self, n, number, data)
+
+    def dot(self, x, y):
+        r = C.c_double()
+        check(self.lib.mgx_dot(self.h, x.number, x.ptr, y.ptr, x.n, C.byref(r)))
+        return r.value
+
+    def l2_norm(self, x):
+        r = C.c_double()
+        check(self.lib.mgx_l2_norm(self.h, x.number, x.ptr, x.n, C.byref(r)))
+        return r.value
+
+
+class DeviceVector:
+    """Device storage of one level vector (LinearAlgebra::distributed::Vector<number>)."""
+
+    def __init__(self, ctx, n, number=F64, data=None, ptr=None):
+        self.ctx, self.n, self.number = ctx, int(n), number
+        self.owned = ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            check(ctx.lib.mgx_malloc(ctx.h, C.byref(p), self.nbytes))
+            self.ptr = p
+            if data is None:
+                self.zero()
+        else:
+            self.ptr = C.c_void_p(ptr) if not isinstance(ptr, C.c_void_p) else ptr
+        if data is not None:
+            self.upload(data)
+
+    @property
+    def nbytes(self):
+        return self.n * (8 if self.number == F64 else 4)
+
+    def zero(self):
+        check(self.ctx.lib.mgx_memset_zero(self.ctx.h, self.ptr, self.nbytes))
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=_DT[self.number])
+        assert a.size == self.n
+        check(self.ctx.lib.mgx_upload(self.ctx.h, self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes))
+
+    def download(self):
+        a = np.empty(self.n, dtype=_DT[self.number])
+        check(self.ctx.lib.mgx_download(self.ctx.h, a.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return a
+
+    def free(self):
+        if self.owned and self.ptr:
+            self.ctx.lib.mgx_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Cube:
+    """Host-side discretisation of poisson_cube (include/mgx_cube.h): what deal.II supplies."""
+
+    def __init__(self, degree, n_subdiv=1, n_refine=3):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.mgx_cube_create(degree, n_subdiv, n_refine, C.byref(h)))
+        self.h = h
+        self.degree = degree
+        self.n_levels = self.lib.mgx_cube_n_levels(h)
+        self.max_level = self.n_levels - 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mgx_cube_destroy(self.h)
+            self.h = None
+
+    def n_cells(self, l):
+        return self.lib.mgx_cube_n_cells(self.h, l)
+
+    def n_dofs(self, l):
+        return self.lib.mgx_cube_n_dofs(self.h, l)
+
+    def n_constrained(self, l):
+        return self.lib.mgx_cube_n_constrained(self.h, l)
+
+    def cells_per_dim(self, l):
+        return self.lib.mgx_cube_cells_per_dim(self.h, l)
+
+    def cell_size(self, l):
+        return self.lib.mgx_cube_cell_size(self.h, l)
+
+    def _arr(self, fn, shape, *args):
+        p = getattr(self.lib, fn)(self.h, *args)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype=np.uint32 if "u32" in str(type(p)) else np.float64)
+        return np.ctypeslib.as_array(p, shape=(n,)).reshape(shape).copy()
+
+    def idx27(self, l):
+        return self._arr("mgx_cube_idx27", (self.n_cells(l), 27), l)
+
+    def idx27_plain(self, l):
+        return self._arr("mgx_cube_idx27_plain", (self.n_cells(l), 27), l)
+
+    def constrained(self, l):
+        return self._arr("mgx_cube_constrained", (self.n_constrained(l),), l)
+
+    def children(self, l):
+        return self._arr("mgx_cube_children", (self.n_cells(l - 1), 8), l)
+
+    def cell_coords(self, l):
+        return self._arr("mgx_cube_cell_coords", (self.n_cells(l), 3), l)
+
+    def dof_grid(self, l):
+        return self._arr("mgx_cube_dof_grid", (self.n_dofs(l),), l)
+
+    def shape_values(self):
+        n = self.degree + 1
+        return self._arr("mgx_cube_shape_values", (n, n))
+
+    def colloc_grad(self):
+        n = self.degree + 1
+        return self._arr("mgx_cube_colloc_grad", (n, n))
+
+    def qweights(self):
+        return self._arr("mgx_cube_qweights", (self.degree + 1,))
+
+    def qpoints(self):
+        return self._arr("mgx_cube_qpoints", (self.degree + 1,))
+
+    def gll(self):
+        return self._arr("mgx_cube_gll", (self.degree + 1,))
+
+    def prolong_1d(self):
+        n = self.degree + 1
+        return self._arr("mgx_cube_prolong_1d", (2 * n - 1, n))
+
+    def rhs(self, l):
+        return self._arr("mgx_cube_rhs", (self.n_dofs(l),), l)
+
+    def bc(self, l):
+        n = self.lib.mgx_cube_bc_count(self.h, l)
+        return self._arr("mgx_cube_bc_index", (n,), l), self._arr("mgx_cube_bc_value", (n,), l)
+
+    def operator_desc(self, l, number=F64):
+        d = _lib.OperatorDesc()
+        check(self.lib.mgx_cube_operator_desc(self.h, l, number, C.byref(d)))
+        return d
+
+    def l2_error(self, l, solution):
+        s = np.ascontiguousarray(solution, dtype=np.float64)
+        assert s.size == self.n_dofs(l)
+        return self.lib.mgx_cube_l2_error(self.h, l, s.ctypes.data_as(_lib.f64p))
+
+    def seeded_vector(self, l, seed=42):
+        out = np.empty(self.n_dofs(l))
+        check(self.lib.mgx_cube_seeded_vector(self.h, l, seed, out.ctypes.data_as(_lib.f64p)))
+        return out
+
+
+class LaplaceOperator:
+    """multigrid::LaplaceOperator<3,p,number> of one level (laplace_operator.h:56-164)."""
+
+    def __init__(self, ctx, desc=None, handle=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.owned = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            check(self.lib.mgx_operator_create(ctx.h, C.byref(desc), C.byref(h)))
+            self.h = h
+        else:
+            self.h = C.c_void_p(handle)
+        self.number = self.lib.mgx_operator_number(self.h)
+
+    @classmethod
+    def from_cube(cls, ctx, cube, level, number=F64):
+        return cls(ctx, cube.operator_desc(level, number))
+
+    def m(self):
+        return self.lib.mgx_operator_n_dofs(self.h)
+
+    def initialize_dof_vector(self):
+        return DeviceVector(self.ctx, self.m(), self.number)
+
+    def vmult(self, dst, src):
+        check(self.lib.mgx_vmult(self.h, dst.ptr, src.ptr))
+
+    def vmult_residual(self, rhs, lhs, residual):
+        check(self.lib.mgx_vmult_residual(self.h, rhs.ptr, lhs.ptr, residual.ptr))
+
+    def compute_diagonal(self):
+        check(self.lib.mgx_compute_diagonal(self.h))
+
+    def get_matrix_diagonal_inverse(self):
+        p = C.c_void_p()
+        check(self.lib.mgx_get_inverse_diagonal(self.h, C.byref(p)))
+        return DeviceVector(self.ctx, self.m(), self.number, ptr=p)
+
+    def clear(self):
+        if self.owned and self.h:
+            self.lib.mgx_operator_destroy(self.h)
+            self.h = None
+
+
+class Chebyshev:
+    """dealii::PreconditionChebyshev<LaplaceOperator, Vector> (multigrid_solver.h:269-289)."""
+
+    def __init__(self, op, smoothing_range=20., degree=3, eig_cg_n_iterations=15, handle=None):
+        self.op, self.lib = op, op.lib
+        self.owned = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            check(self.lib.mgx_smoother_create(op.h, smoothing_range, degree, eig_cg_n_iterations, C.byref(h)))
+            self.h = h
+        else:
+            self.h = C.c_void_p(handle)
+
+    def info(self):
+        i = _lib.SmootherInfo()
+        check(self.lib.mgx_smoother_get_info(self.h, C.byref(i)))
+        return dict(lambda_min=i.lambda_min, lambda_max=i.lambda_max, theta=i.theta, delta=i.delta,
+                    degree=i.degree, cg_its=i.cg_iterations)
+
+    def vmult(self, x, b):
+        check(self.lib.mgx_smoother_vmult(self.h, x.ptr, b.ptr))
+
+    def step(self, x, b):
+        check(self.lib.mgx_smoother_step(self.h, x.ptr, b.ptr))
+
+    def clear(self):
+        if self.owned and self.h:
+            self.lib.mgx_smoother_destroy(self.h)
+            self.h = None
+
+
+class Transfer:
+    """One level pair of dealii::MGTransferMatrixFree (multigrid_solver.h:209-222)."""
+
+    def __init__(self, coarse, fine, children, prolong_1d):
+        self.lib = coarse.lib
+        self._children = np.ascontiguousarray(children, dtype=np.uint32)
+        self._p1 = np.ascontiguousarray(prolong_1d, dtype=np.float64)
+        d = _lib.TransferDesc(self._children.ctypes.data_as(_lib.u32p), self._p1.ctypes.data_as(_lib.f64p))
+        h = C.c_void_p()
+        check(self.lib.mgx_transfer_create(coarse.h, fine.h, C.byref(d), C.byref(h)))
+        self.h = h
+
+    def prolongate(self, fine, coarse, with_constraints=False):
+        check(self.lib.mgx_prolongate(self.h, fine.ptr, coarse.ptr, 0, int(with_constraints)))
+
+    def prolongate_and_add(self, fine, coarse, with_constraints=True):
+        check(self.lib.mgx_prolongate(self.h, fine.ptr, coarse.ptr, 1, int(with_constraints)))
+
+    def restrict_and_add(self, coarse, fine, with_constraints=True):
+        check(self.lib.mgx_restrict_and_add(self.h, coarse.ptr, fine.ptr, int(with_constraints)))
+
+    def clear(self):
+        if self.h:
+            self.lib.mgx_transfer_destroy(self.h)
+            self.h = None
+
+
+class MultigridSolver:
+    """multigrid::MultigridSolver<3,p,Number,double> for poisson_cube (multigrid_solver.h:96-782).
+
+    ctor arguments follow the reference: (dof_handler -> cube, degree_pre, degree_post, n_cycles);
+    `vcycle_number` is the template parameter Number (program.cc:76: float; BASELINE: double)."""
+
+    def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64):
+        assert degree_pre == degree_post  # multigrid_solver.h:126
+        self.ctx, self.cube, self.lib = ctx, cube, ctx.lib
+        self.vnumber = vcycle_number
+        self.s = _lib.CubeSolver()
+        check(self.lib.mgx_cube_solver_create(ctx.h, cube.h, vcycle_number, degree_pre, n_cycles, C.byref(self.s)))
+        self.n_levels = self.s.n_levels
+        self.max_level = self.n_levels - 1
+        self.h = C.c_void_p(self.s.solver)
+
+    def matrix_dp(self, level):
+        return LaplaceOperator(self.ctx, handle=self.s.matrix_dp[level])
+
+    def matrix(self, level):
+        return LaplaceOperator(self.ctx, handle=self.s.matrix[level])
+
+    def smoother(self, level):
+        p = C.c_void_p()
+        check(self.lib.mgx_solver_get_smoother(self.h, level, C.byref(p)))
+        return Chebyshev(self.matrix(level), handle=p.value)
+
+    def solve(self, do_analyze=False):
+        """returns (reduction_rate, trace[n_levels,2] = residual norm start/end per level)"""
+        rate = C.c_double(1.0)
+        trace = np.zeros(2 * self.n_levels)
+        check(self.lib.mgx_solver_solve(self.h, int(do_analyze), C.byref(rate), trace.ctypes.data_as(_lib.f64p)))
+        return rate.value, trace.reshape(-1, 2)
+
+    def solve_cg(self):
+        its = C.c_uint()
+        red = C.c_double()
+        check(self.lib.mgx_solver_solve_cg(self.h, C.byref(its), C.byref(red)))
+        return its.value, red.value
+
+    def vmult(self, dst, src):
+        check(self.lib.mgx_solver_vmult(self.h, dst.ptr, src.ptr))
+
+    def do_matvec(self):
+        check(self.lib.mgx_solver_do_matvec(self.h))
+
+    def do_matvec_smoother(self):
+        check(self.lib.mgx_solver_do_matvec_smoother(self.h))
+
+    def get_solution(self, level=None, insert_bc=True):
+        level = self.max_level if level is None else level
+        p = C.c_void_p()
+        check(self.lib.mgx_solver_get_solution(self.h, level, int(insert_bc), C.byref(p)))
+        return DeviceVector(self.ctx, self.cube.n_dofs(level), F64, ptr=p)
+
+    def get_vector(self, level, which):
+        ids = dict(rhs=0, residual=1, defect=2, t=3, solution_update=4)
+        p = C.c_void_p()
+        check(self.lib.mgx_solver_get_vector(self.h, level, ids[which], C.byref(p)))
+        number = F64 if ids[which] < 2 else self.vnumber
+        return DeviceVector(self.ctx, self.cube.n_dofs(level), number, ptr=p)
+
+    def compute_l2_error(self, level=None):
+        level = self.max_level if level is None else level
+        return self.cube.l2_error(level, self.get_solution(level, True).download())
+
+    def enable_timings(self, on=True):
+        check(self.lib.mgx_solver_enable_timings(self.h, int(on)))
+
+    def wall_times(self):
+        t = np.zeros(6 * self.n_levels)
+        check(self.lib.mgx_solver_get_timings(self.h, t.ctypes.data_as(_lib.f64p)))
+        return t.reshape(-1, 6)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mgx_cube_solver_destroy(C.byref(self.s))
+            self.h = None

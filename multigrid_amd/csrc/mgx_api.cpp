@@ -1,0 +1,1149 @@
+// mgx_api.cpp -- implementation of the C ABI declared in include/mgx.h: host-side control flow of
+// LaplaceOperator / PreconditionChebyshev / MGTransferMatrixFree / MultigridSolver on top of the
+// HIP kernels.  Reference citations (file:line) are relative to the reference root; deal.II
+// semantics follow SURVEY.md 8a rows R, S, T and Appendix D.
+#include "../../include/mgx.h"
+#include "mgx_internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace mgx;
+
+namespace
+{
+  thread_local std::string g_last_error;
+
+  int fail(int code, const std::string &msg)
+  {
+    g_last_error = msg;
+    return code;
+  }
+
+#define MGX_HIP(call)                                                                               \
+  do                                                                                                \
+    {                                                                                               \
+      hipError_t e_ = (call);                                                                       \
+      if (e_ != hipSuccess)                                                                         \
+        return fail(MGX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                                   std::to_string(__LINE__) + ")");                                 \
+    }                                                                                               \
+  while (0)
+
+#define MGX_TRY(call)     \
+  do                      \
+    {                     \
+      int s_ = (call);    \
+      if (s_ != MGX_OK)   \
+        return s_;        \
+    }                     \
+  while (0)
+
+#define MGX_REQUIRE(cond, msg)                        \
+  do                                                  \
+    {                                                 \
+      if (!(cond))                                    \
+        return fail(MGX_ERR_INVALID_ARGUMENT, (msg)); \
+    }                                                 \
+  while (0)
+
+  inline size_t number_size(int number) { return number == MGX_F64 ? 8 : 4; }
+} // namespace
+
+struct mgx_context_s
+{
+  int         device = 0;
+  hipStream_t stream = nullptr;
+  double     *partial_dev = nullptr; // kDotBlocks block partials
+  double     *result_dev  = nullptr; // 4 scalars
+  double     *result_host = nullptr; // pinned
+};
+
+struct mgx_operator_s
+{
+  mgx_context_t ctx = nullptr;
+  OperatorData  d;
+  double        S[kMaxN * kMaxN], D[kMaxN * kMaxN], w[kMaxN];
+  bool          has_diag = false;
+};
+
+struct mgx_smoother_s
+{
+  mgx_operator_t    op = nullptr;
+  mgx_smoother_info info{};
+  void             *x_old = nullptr, *tmp = nullptr;
+};
+
+struct mgx_transfer_s
+{
+  mgx_operator_t coarse = nullptr, fine = nullptr;
+  TransferData   d;
+};
+
+struct mgx_solver_s
+{
+  mgx_context_t               ctx = nullptr;
+  int                         n_levels = 0, degree = 0, n_cycles = 1, vnumber = MGX_F64;
+  std::vector<mgx_operator_t> matrix, matrix_dp;
+  std::vector<mgx_transfer_t> transfer, transfer_dp;
+  std::vector<mgx_smoother_t> smooth;
+  std::vector<double *>       solution, rhs, residual;         // fp64 (multigrid_solver.h:709-719)
+  std::vector<void *>         defect, t, solution_update;      // V-cycle precision (:725-735)
+  std::vector<uint32_t *>     bc_index_dev;
+  std::vector<double *>       bc_value_dev, bc_zero_dev;
+  std::vector<uint32_t>       bc_count;
+  double                     *cg_r = nullptr, *cg_z = nullptr, *cg_d = nullptr, *cg_h = nullptr;
+  bool                        timing = false;
+  std::vector<double>         timings; // n_levels*6
+};
+
+namespace
+{
+  int read_result(mgx_context_t ctx, double *out)
+  {
+    MGX_HIP(hipMemcpyAsync(ctx->result_host, ctx->result_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MGX_HIP(hipStreamSynchronize(ctx->stream));
+    *out = ctx->result_host[0];
+    return MGX_OK;
+  }
+
+  int dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *out)
+  {
+    launch_dot(ctx->stream, number, x, y, n, ctx->partial_dev, ctx->result_dev);
+    return read_result(ctx, out);
+  }
+
+  struct Stopwatch
+  {
+    mgx_solver_t s;
+    int          level, slot;
+    std::chrono::steady_clock::time_point t0;
+    Stopwatch(mgx_solver_t s, int level, int slot)
+      : s(s)
+      , level(level)
+      , slot(slot)
+    {
+      if (s->timing)
+        {
+          (void)hipStreamSynchronize(s->ctx->stream);
+          t0 = std::chrono::steady_clock::now();
+        }
+    }
+    ~Stopwatch()
+    {
+      if (s->timing)
+        {
+          (void)hipStreamSynchronize(s->ctx->stream);
+          s->timings[6 * level + slot] +=
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+  };
+
+  // extreme eigenvalues of a symmetric tridiagonal matrix (Sturm bisection)
+  int sturm_count(int n, const double *d, const double *e, double x)
+  {
+    int    count = 0;
+    double q     = d[0] - x;
+    if (q < 0)
+      ++count;
+    for (int i = 1; i < n; ++i)
+      {
+        if (q == 0)
+          q = 1e-300;
+        q = d[i] - x - e[i - 1] * e[i - 1] / q;
+        if (q < 0)
+          ++count;
+      }
+    return count;
+  }
+
+  void tridiag_extreme(int n, const double *d, const double *e, double &lo, double &hi)
+  {
+    double gl = d[0], gu = d[0];
+    for (int i = 0; i < n; ++i)
+      {
+        const double r = (i > 0 ? std::fabs(e[i - 1]) : 0) + (i < n - 1 ? std::fabs(e[i]) : 0);
+        gl             = std::min(gl, d[i] - r);
+        gu             = std::max(gu, d[i] + r);
+      }
+    for (int which = 0; which < 2; ++which)
+      {
+        const int k = which == 0 ? 1 : n;
+        double    a = gl, b = gu;
+        for (int it = 0; it < 200; ++it)
+          {
+            const double m = 0.5 * (a + b);
+            if (m == a || m == b)
+              break;
+            if (sturm_count(n, d, e, m) >= k)
+              b = m;
+            else
+              a = m;
+          }
+        (which == 0 ? lo : hi) = 0.5 * (a + b);
+      }
+  }
+} // namespace
+
+extern "C" {
+
+const char *mgx_last_error(void) { return g_last_error.c_str(); }
+const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+
+int mgx_context_create(mgx_context_t *out, int device)
+{
+  MGX_REQUIRE(out != nullptr, "mgx_context_create: null output");
+  int        count = 0;
+  hipError_t e     = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(MGX_ERR_NO_DEVICE, "mgx_context_create: no HIP device available (there is no CPU fallback)");
+  MGX_REQUIRE(device >= 0 && device < count, "mgx_context_create: device index out of range");
+  MGX_HIP(hipSetDevice(device));
+  auto ctx    = new mgx_context_s;
+  ctx->device = device;
+  MGX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  MGX_HIP(hipMalloc((void **)&ctx->partial_dev, sizeof(double) * kDotBlocks));
+  MGX_HIP(hipMalloc((void **)&ctx->result_dev, sizeof(double) * 4));
+  MGX_HIP(hipHostMalloc((void **)&ctx->result_host, sizeof(double) * 4));
+  *out = ctx;
+  return MGX_OK;
+}
+
+int mgx_context_destroy(mgx_context_t ctx)
+{
+  if (!ctx)
+    return MGX_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->partial_dev);
+  (void)hipFree(ctx->result_dev);
+  (void)hipHostFree(ctx->result_host);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MGX_OK;
+}
+
+int mgx_sync(mgx_context_t ctx)
+{
+  MGX_REQUIRE(ctx, "mgx_sync: null context");
+  MGX_HIP(hipStreamSynchronize(ctx->stream));
+  return MGX_OK;
+}
+
+void *mgx_context_stream(mgx_context_t ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int mgx_malloc(mgx_context_t ctx, void **dptr, size_t bytes)
+{
+  MGX_REQUIRE(ctx && dptr, "mgx_malloc: null argument");
+  MGX_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+  return MGX_OK;
+}
+
+int mgx_free(mgx_context_t ctx, void *dptr)
+{
+  MGX_REQUIRE(ctx, "mgx_free: null context");
+  if (dptr)
+    {
+      MGX_HIP(hipStreamSynchronize(ctx->stream));
+      MGX_HIP(hipFree(dptr));
+    }
+  return MGX_OK;
+}
+
+int mgx_upload(mgx_context_t ctx, void *dptr, const void *hptr, size_t bytes)
+{
+  MGX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "mgx_upload: null argument");
+  if (bytes)
+    {
+      MGX_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+      MGX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  return MGX_OK;
+}
+
+int mgx_download(mgx_context_t ctx, void *hptr, const void *dptr, size_t bytes)
+{
+  MGX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "mgx_download: null argument");
+  if (bytes)
+    {
+      MGX_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      MGX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  return MGX_OK;
+}
+
+int mgx_memset_zero(mgx_context_t ctx, void *dptr, size_t bytes)
+{
+  MGX_REQUIRE(ctx && (bytes == 0 || dptr), "mgx_memset_zero: null argument");
+  if (bytes)
+    MGX_HIP(hipMemsetAsync(dptr, 0, bytes, ctx->stream));
+  return MGX_OK;
+}
+
+int mgx_copy_cast(mgx_context_t ctx, void *dst, int dn, const void *src, int sn, size_t n)
+{
+  MGX_REQUIRE(ctx && (n == 0 || (dst && src)), "mgx_copy_cast: null argument");
+  launch_copy_cast(ctx->stream, dst, dn, src, sn, n);
+  return MGX_OK;
+}
+
+int mgx_add_cast(mgx_context_t ctx, void *dst, int dn, const void *src, int sn, size_t n)
+{
+  MGX_REQUIRE(ctx && (n == 0 || (dst && src)), "mgx_add_cast: null argument");
+  launch_add_cast(ctx->stream, dst, dn, src, sn, n);
+  return MGX_OK;
+}
+
+int mgx_sadd(mgx_context_t ctx, int number, void *x, double s, double a, const void *v, size_t n)
+{
+  MGX_REQUIRE(ctx && (n == 0 || (x && v)), "mgx_sadd: null argument");
+  launch_sadd(ctx->stream, number, x, s, a, v, n);
+  return MGX_OK;
+}
+
+int mgx_dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *result)
+{
+  MGX_REQUIRE(ctx && result && (n == 0 || (x && y)), "mgx_dot: null argument");
+  return dot(ctx, number, x, y, n, result);
+}
+
+int mgx_l2_norm(mgx_context_t ctx, int number, const void *x, size_t n, double *result)
+{
+  MGX_REQUIRE(ctx && result && (n == 0 || x), "mgx_l2_norm: null argument");
+  double s = 0;
+  MGX_TRY(dot(ctx, number, x, x, n, &s));
+  *result = std::sqrt(s);
+  return MGX_OK;
+}
+
+int mgx_set_entries(mgx_context_t ctx, int number, void *v, const uint32_t *idx_host, const double *val_host,
+                    uint32_t count)
+{
+  MGX_REQUIRE(ctx && (count == 0 || (v && idx_host && val_host)), "mgx_set_entries: null argument");
+  if (count == 0)
+    return MGX_OK;
+  uint32_t *idx_dev = nullptr;
+  double   *val_dev = nullptr;
+  MGX_HIP(hipMalloc((void **)&idx_dev, sizeof(uint32_t) * count));
+  MGX_HIP(hipMalloc((void **)&val_dev, sizeof(double) * count));
+  MGX_HIP(hipMemcpyAsync(idx_dev, idx_host, sizeof(uint32_t) * count, hipMemcpyHostToDevice, ctx->stream));
+  MGX_HIP(hipMemcpyAsync(val_dev, val_host, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+  launch_scatter_values(ctx->stream, number, v, idx_dev, val_dev, count);
+  MGX_HIP(hipStreamSynchronize(ctx->stream));
+  MGX_HIP(hipFree(idx_dev));
+  MGX_HIP(hipFree(val_dev));
+  return MGX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * LaplaceOperator
+ * ------------------------------------------------------------------------------------------ */
+int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_operator_t *out)
+{
+  MGX_REQUIRE(ctx && desc && out, "mgx_operator_create: null argument");
+  MGX_REQUIRE(desc->degree >= 1 && desc->degree <= MGX_MAX_DEGREE, "mgx_operator_create: degree must be 1..9");
+  MGX_REQUIRE(desc->number == MGX_F32 || desc->number == MGX_F64, "mgx_operator_create: bad number type");
+  MGX_REQUIRE(desc->n_cells > 0 && desc->n_dofs > 0, "mgx_operator_create: empty level");
+  MGX_REQUIRE(desc->idx27 && desc->shape_values && desc->colloc_grad && desc->qweights,
+              "mgx_operator_create: missing table");
+  MGX_REQUIRE(desc->n_constrained == 0 || desc->constrained, "mgx_operator_create: missing constrained list");
+  if (desc->coef[3] != 0. || desc->coef[4] != 0. || desc->coef[5] != 0.)
+    return fail(MGX_ERR_UNSUPPORTED, "mgx_operator_create: off-diagonal merged coefficient (non-Cartesian affine "
+                                     "geometry) is not implemented yet");
+  const int    p = desc->degree, n = p + 1;
+  const size_t n_entries = 27 * (size_t)desc->n_cells;
+  // host-side validation of operand shapes before any kernel can touch them
+  {
+    const uint32_t sizes[3] = {1u, (uint32_t)(p - 1), (uint32_t)((p - 1) * (p - 1))};
+    for (int pass = 0; pass < 2; ++pass)
+      {
+        const uint32_t *tab = pass == 0 ? desc->idx27 : desc->idx27_plain;
+        if (!tab)
+          continue;
+        for (size_t i = 0; i < n_entries; ++i)
+          {
+            const uint32_t b = tab[i];
+            if (b == MGX_INVALID_INDEX)
+              continue;
+            const int e = (int)(i % 27), cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+            const int kind = (cx == 1) + (cy == 1) + (cz == 1);
+            uint32_t  len  = kind == 3 ? sizes[2] * (uint32_t)(p - 1) : sizes[kind];
+            if (kind == 0)
+              len = 1;
+            if ((uint64_t)b + len > desc->n_dofs)
+              return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: compressed index out of range");
+          }
+      }
+    for (uint32_t i = 0; i < desc->n_constrained; ++i)
+      if (desc->constrained[i] >= desc->n_dofs)
+        return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: constrained index out of range");
+  }
+  auto op          = std::make_unique<mgx_operator_s>();
+  op->ctx          = ctx;
+  OperatorData &d  = op->d;
+  d.p              = p;
+  d.number         = desc->number;
+  d.n_cells        = desc->n_cells;
+  d.n_dofs         = desc->n_dofs;
+  d.n_constrained  = desc->n_constrained;
+  for (int i = 0; i < 6; ++i)
+    d.coef[i] = desc->coef[i];
+  std::memcpy(op->S, desc->shape_values, sizeof(double) * n * n);
+  std::memcpy(op->D, desc->colloc_grad, sizeof(double) * n * n);
+  std::memcpy(op->w, desc->qweights, sizeof(double) * n);
+  MGX_HIP(hipSetDevice(ctx->device));
+  MGX_HIP(hipMalloc((void **)&d.idx27, sizeof(uint32_t) * n_entries));
+  MGX_HIP(hipMemcpy(d.idx27, desc->idx27, sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice));
+  if (desc->idx27_plain)
+    {
+      MGX_HIP(hipMalloc((void **)&d.idx27_plain, sizeof(uint32_t) * n_entries));
+      MGX_HIP(hipMemcpy(d.idx27_plain, desc->idx27_plain, sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice));
+    }
+  MGX_HIP(hipMalloc((void **)&d.constrained, sizeof(uint32_t) * (desc->n_constrained + 1)));
+  if (desc->n_constrained)
+    MGX_HIP(hipMemcpy(d.constrained, desc->constrained, sizeof(uint32_t) * desc->n_constrained,
+                      hipMemcpyHostToDevice));
+  if (d.number == MGX_F64)
+    {
+      Basis1D<double> b{};
+      for (int i = 0; i < n * n; ++i)
+        {
+          b.S[i] = op->S[i];
+          b.D[i] = op->D[i];
+        }
+      for (int i = 0; i < n; ++i)
+        b.w[i] = op->w[i];
+      MGX_HIP(hipMalloc(&d.basis, sizeof(b)));
+      MGX_HIP(hipMemcpy(d.basis, &b, sizeof(b), hipMemcpyHostToDevice));
+    }
+  else
+    {
+      Basis1D<float> b{};
+      for (int i = 0; i < n * n; ++i)
+        {
+          b.S[i] = (float)op->S[i];
+          b.D[i] = (float)op->D[i];
+        }
+      for (int i = 0; i < n; ++i)
+        b.w[i] = (float)op->w[i];
+      MGX_HIP(hipMalloc(&d.basis, sizeof(b)));
+      MGX_HIP(hipMemcpy(d.basis, &b, sizeof(b), hipMemcpyHostToDevice));
+    }
+  MGX_HIP(hipMalloc(&d.inv_diag, number_size(d.number) * d.n_dofs));
+  *out = op.release();
+  return MGX_OK;
+}
+
+int mgx_operator_destroy(mgx_operator_t op)
+{
+  if (!op)
+    return MGX_OK;
+  (void)hipStreamSynchronize(op->ctx->stream);
+  (void)hipFree(op->d.idx27);
+  (void)hipFree(op->d.idx27_plain);
+  (void)hipFree(op->d.constrained);
+  (void)hipFree(op->d.basis);
+  (void)hipFree(op->d.inv_diag);
+  delete op;
+  return MGX_OK;
+}
+
+uint32_t mgx_operator_n_dofs(mgx_operator_t op) { return op ? op->d.n_dofs : 0; }
+int      mgx_operator_number(mgx_operator_t op) { return op ? op->d.number : -1; }
+
+int mgx_vmult(mgx_operator_t op, void *dst, const void *src)
+{
+  MGX_REQUIRE(op && dst && src, "mgx_vmult: null argument");
+  MGX_REQUIRE(dst != src, "mgx_vmult: dst and src must not alias (laplace_operator.h:573-601)");
+  hipStream_t s = op->ctx->stream;
+  // "zero dst within the loop" (laplace_operator.h:590)
+  MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
+  launch_cell_loop(s, op->d, dst, src);
+  // dst[c] = src[c] on constrained rows (:592-593)
+  launch_constrained_copy(s, op->d.number, dst, src, op->d.constrained, op->d.n_constrained);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void *res)
+{
+  MGX_REQUIRE(op && rhs && lhs && res, "mgx_vmult_residual: null argument");
+  MGX_REQUIRE(res != lhs && res != rhs, "mgx_vmult_residual: residual must not alias rhs/lhs");
+  hipStream_t s = op->ctx->stream;
+  MGX_HIP(hipMemsetAsync(res, 0, number_size(op->d.number) * op->d.n_dofs, s)); // :617-623
+  launch_cell_loop(s, op->d, res, lhs);
+  launch_rhs_minus(s, op->d.number, res, rhs, op->d.n_dofs); // :624-631
+  // res[c] -= lhs[c] on constrained rows (:632-633); the loop never touches them
+  launch_constrained_residual(s, op->d.number, res, rhs, lhs, op->d.constrained, op->d.n_constrained);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_compute_diagonal(mgx_operator_t op)
+{
+  MGX_REQUIRE(op, "mgx_compute_diagonal: null argument");
+  hipStream_t s = op->ctx->stream;
+  const int   n = op->d.p + 1;
+  // 1D diagonal factors: G = D*S is the gradient of the nodal basis at the quadrature points
+  double a1d[kMaxN], m1d[kMaxN];
+  for (int i = 0; i < n; ++i)
+    {
+      double a = 0, m = 0;
+      for (int q = 0; q < n; ++q)
+        {
+          double g = 0;
+          for (int r = 0; r < n; ++r)
+            g += op->D[q * n + r] * op->S[r * n + i];
+          a += op->w[q] * g * g;
+          m += op->w[q] * op->S[q * n + i] * op->S[q * n + i];
+        }
+      a1d[i] = a;
+      m1d[i] = m;
+    }
+  MGX_HIP(hipMemsetAsync(op->d.inv_diag, 0, number_size(op->d.number) * op->d.n_dofs, s));
+  launch_cell_diagonal(s, op->d, op->d.inv_diag, a1d, m1d);
+  // set_constrained_entries_to_one + invert (laplace_operator.h:757-765)
+  launch_constrained_set(s, op->d.number, op->d.inv_diag, 1.0, op->d.constrained, op->d.n_constrained);
+  launch_invert(s, op->d.number, op->d.inv_diag, op->d.n_dofs);
+  MGX_HIP(hipGetLastError());
+  op->has_diag = true;
+  return MGX_OK;
+}
+
+int mgx_get_inverse_diagonal(mgx_operator_t op, const void **dptr)
+{
+  MGX_REQUIRE(op && dptr, "mgx_get_inverse_diagonal: null argument");
+  MGX_REQUIRE(op->has_diag, "mgx_get_inverse_diagonal: call mgx_compute_diagonal first");
+  *dptr = op->d.inv_diag;
+  return MGX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PreconditionChebyshev
+ * ------------------------------------------------------------------------------------------ */
+int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, int eig_cg_n_iterations,
+                        mgx_smoother_t *out)
+{
+  MGX_REQUIRE(op && out, "mgx_smoother_create: null argument");
+  MGX_REQUIRE(eig_cg_n_iterations > 2, "mgx_smoother_create: eig_cg_n_iterations must be > 2");
+  if (!op->has_diag)
+    MGX_TRY(mgx_compute_diagonal(op));
+  mgx_context_t ctx = op->ctx;
+  hipStream_t   s   = ctx->stream;
+  const int     num = op->d.number;
+  const size_t  n   = op->d.n_dofs, bytes = number_size(num) * n;
+  auto          sm  = std::make_unique<mgx_smoother_s>();
+  sm->op            = op;
+  MGX_HIP(hipMalloc(&sm->x_old, bytes));
+  MGX_HIP(hipMalloc(&sm->tmp, bytes));
+  // estimate_eigenvalues: PCG(D^-1) on v_i = (i mod 11) - mean; Lanczos tridiagonal
+  void *r = nullptr, *z = nullptr, *d = nullptr, *h = sm->tmp, *x = sm->x_old;
+  MGX_HIP(hipMalloc(&r, bytes));
+  MGX_HIP(hipMalloc(&z, bytes));
+  MGX_HIP(hipMalloc(&d, bytes));
+  {
+    std::vector<double> v(n);
+    double              mean = 0;
+    for (size_t i = 0; i < n; ++i)
+      mean += (double)(i % 11);
+    mean /= (double)n;
+    for (size_t i = 0; i < n; ++i)
+      v[i] = (double)(i % 11) - mean;
+    if (num == MGX_F64)
+      MGX_HIP(hipMemcpy(r, v.data(), bytes, hipMemcpyHostToDevice));
+    else
+      {
+        std::vector<float> vf(v.begin(), v.end());
+        MGX_HIP(hipMemcpy(r, vf.data(), bytes, hipMemcpyHostToDevice));
+      }
+  }
+  MGX_HIP(hipMemsetAsync(x, 0, bytes, s));
+  std::vector<double> diag, off;
+  double              res = 0, rz = 0, rz_old = 0, alpha = 0, alpha_old = 0, beta = 0;
+  MGX_TRY(dot(ctx, num, r, r, n, &res));
+  res    = std::sqrt(res);
+  int it = 0;
+  while (it < eig_cg_n_iterations && res > 1e-10) // IterationNumberControl(n_its, 1e-10)
+    {
+      ++it;
+      rz_old = rz;
+      launch_jacobi_dot(s, num, z, op->d.inv_diag, r, n, ctx->partial_dev, ctx->result_dev);
+      MGX_TRY(read_result(ctx, &rz));
+      if (it > 1)
+        {
+          beta = rz / rz_old;
+          launch_xpby(s, num, d, z, beta, n);
+        }
+      else
+        launch_copy_cast(s, d, num, z, num, n);
+      alpha_old = alpha;
+      MGX_TRY(mgx_vmult(op, h, d));
+      double dh = 0;
+      MGX_TRY(dot(ctx, num, d, h, n, &dh));
+      alpha = rz / dh;
+      launch_cg_update(s, num, x, r, d, h, alpha, n, ctx->partial_dev, ctx->result_dev);
+      MGX_TRY(read_result(ctx, &res));
+      res = std::sqrt(res);
+      if (it == 1)
+        diag.push_back(1. / alpha);
+      else
+        {
+          off.push_back(std::sqrt(beta) / alpha_old);
+          diag.push_back(1. / alpha + beta / alpha_old);
+        }
+    }
+  MGX_HIP(hipStreamSynchronize(s));
+  MGX_HIP(hipFree(r));
+  MGX_HIP(hipFree(z));
+  MGX_HIP(hipFree(d));
+  mgx_smoother_info &info = sm->info;
+  info.cg_iterations      = it;
+  if (diag.empty())
+    info.lambda_min = info.lambda_max = 1.;
+  else
+    {
+      double lo, hi;
+      off.push_back(0.);
+      tridiag_extreme((int)diag.size(), diag.data(), off.data(), lo, hi);
+      info.lambda_min = lo;
+      info.lambda_max = 1.2 * hi; // safety factor
+    }
+  const double a =
+    smoothing_range > 1. ? info.lambda_max / smoothing_range : std::min(0.9 * info.lambda_max, info.lambda_min);
+  if (degree < 0) // numbers::invalid_unsigned_int: Varga's estimate for eps = smoothing_range
+    {
+      const double actual_range = info.lambda_max / a;
+      const double sigma        = (1. - std::sqrt(1. / actual_range)) / (1. + std::sqrt(1. / actual_range));
+      const double eps          = smoothing_range;
+      degree = 1 + (int)(std::log(1. / eps + std::sqrt(1. / eps / eps - 1.)) / std::log(1. / sigma));
+    }
+  info.degree = degree;
+  info.delta  = (info.lambda_max - a) * 0.5;
+  info.theta  = (info.lambda_max + a) * 0.5;
+  *out        = sm.release();
+  return MGX_OK;
+}
+
+int mgx_smoother_destroy(mgx_smoother_t sm)
+{
+  if (!sm)
+    return MGX_OK;
+  (void)hipStreamSynchronize(sm->op->ctx->stream);
+  (void)hipFree(sm->x_old);
+  (void)hipFree(sm->tmp);
+  delete sm;
+  return MGX_OK;
+}
+
+int mgx_smoother_get_info(mgx_smoother_t sm, mgx_smoother_info *info)
+{
+  MGX_REQUIRE(sm && info, "mgx_smoother_get_info: null argument");
+  *info = sm->info;
+  return MGX_OK;
+}
+
+static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
+{
+  const mgx_smoother_info &I = sm->info;
+  mgx_operator_t           op = sm->op;
+  hipStream_t              s  = op->ctx->stream;
+  if (I.degree < 2 || std::fabs(I.delta) < 1e-40)
+    return MGX_OK;
+  double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+  for (int k = 0; k < I.degree - 1; ++k)
+    {
+      MGX_TRY(mgx_vmult(op, sm->tmp, x));
+      const double rhokp = 1. / (2. * sigma - rhok);
+      const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
+      rhok = rhokp;
+      launch_cheb_update(s, op->d.number, 2, x, sm->x_old, b, sm->tmp, op->d.inv_diag, f1, f2, op->d.n_dofs);
+    }
+  return MGX_OK;
+}
+
+int mgx_smoother_vmult(mgx_smoother_t sm, void *x, const void *b)
+{
+  MGX_REQUIRE(sm && x && b && x != b, "mgx_smoother_vmult: bad argument");
+  mgx_operator_t op = sm->op;
+  launch_cheb_update(op->ctx->stream, op->d.number, 0, x, sm->x_old, b, nullptr, op->d.inv_diag, 0.,
+                     1. / sm->info.theta, op->d.n_dofs);
+  return cheb_loop(sm, x, b);
+}
+
+int mgx_smoother_step(mgx_smoother_t sm, void *x, const void *b)
+{
+  MGX_REQUIRE(sm && x && b && x != b, "mgx_smoother_step: bad argument");
+  mgx_operator_t op = sm->op;
+  MGX_TRY(mgx_vmult(op, sm->tmp, x));
+  launch_cheb_update(op->ctx->stream, op->d.number, 1, x, sm->x_old, b, sm->tmp, op->d.inv_diag, 0.,
+                     1. / sm->info.theta, op->d.n_dofs);
+  return cheb_loop(sm, x, b);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * MGTransferMatrixFree (one level pair)
+ * ------------------------------------------------------------------------------------------ */
+int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_transfer_desc *desc,
+                        mgx_transfer_t *out)
+{
+  MGX_REQUIRE(coarse && fine && desc && out && desc->children && desc->prolong_1d,
+              "mgx_transfer_create: null argument");
+  MGX_REQUIRE(coarse->d.p == fine->d.p && coarse->d.number == fine->d.number,
+              "mgx_transfer_create: level operators differ in degree or number type");
+  MGX_REQUIRE(coarse->d.idx27_plain && fine->d.idx27_plain,
+              "mgx_transfer_create: operators were created without idx27_plain");
+  MGX_REQUIRE((uint64_t)coarse->d.n_cells * 8 == fine->d.n_cells,
+              "mgx_transfer_create: fine level must have 8 children per coarse cell (uniform refinement)");
+  const int      p = coarse->d.p, n = p + 1;
+  const uint32_t npar = coarse->d.n_cells;
+  for (size_t i = 0; i < 8 * (size_t)npar; ++i)
+    if (desc->children[i] >= fine->d.n_cells)
+      return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_transfer_create: child index out of range");
+  auto tr    = std::make_unique<mgx_transfer_s>();
+  tr->coarse = coarse;
+  tr->fine   = fine;
+  tr->d.coarse = &coarse->d;
+  tr->d.fine   = &fine->d;
+  MGX_HIP(hipMalloc((void **)&tr->d.children, sizeof(uint32_t) * 8 * (size_t)npar));
+  MGX_HIP(hipMemcpy(tr->d.children, desc->children, sizeof(uint32_t) * 8 * (size_t)npar, hipMemcpyHostToDevice));
+  // weights 1/multiplicity (multiplicity = number of parent patches sharing a fine DoF), stored
+  // compressed as 3^3 entries per parent like deal.II does on uniform meshes
+  {
+    std::vector<uint32_t> idxf(27 * (size_t)fine->d.n_cells);
+    MGX_HIP(hipMemcpy(idxf.data(), fine->d.idx27_plain, sizeof(uint32_t) * idxf.size(), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> cnt(fine->d.n_dofs, 0);
+    auto                 rep = [&](uint32_t pc, int e) {
+      const int      ca = e % 3, cb = (e / 3) % 3, cc = e / 9;
+      const int      ch = (ca == 2) | ((cb == 2) << 1) | ((cc == 2) << 2);
+      const uint32_t fc = desc->children[8 * (size_t)pc + ch];
+      return idxf[27 * (size_t)fc + 9 * cc + 3 * cb + ca];
+    };
+    for (uint32_t pc = 0; pc < npar; ++pc)
+      for (int e = 0; e < 27; ++e)
+        cnt[rep(pc, e)]++;
+    std::vector<uint8_t> shift(27 * (size_t)npar);
+    for (uint32_t pc = 0; pc < npar; ++pc)
+      for (int e = 0; e < 27; ++e)
+        {
+          const uint8_t c = cnt[rep(pc, e)];
+          if (c != 1 && c != 2 && c != 4 && c != 8)
+            return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: fine DoF multiplicity is not 1/2/4/8");
+          shift[27 * (size_t)pc + e] = c == 1 ? 0 : (c == 2 ? 1 : (c == 4 ? 2 : 3));
+        }
+    MGX_HIP(hipMalloc((void **)&tr->d.weight_shift, shift.size()));
+    MGX_HIP(hipMemcpy(tr->d.weight_shift, shift.data(), shift.size(), hipMemcpyHostToDevice));
+  }
+  // 1D prolongation matrix into the coarse operator's basis block
+  const size_t np1 = (size_t)(2 * p + 1) * n;
+  if (coarse->d.number == MGX_F64)
+    {
+      MGX_HIP(hipMemcpy((char *)coarse->d.basis + offsetof(Basis1D<double>, P1), desc->prolong_1d,
+                        sizeof(double) * np1, hipMemcpyHostToDevice));
+    }
+  else
+    {
+      std::vector<float> pf(desc->prolong_1d, desc->prolong_1d + np1);
+      MGX_HIP(hipMemcpy((char *)coarse->d.basis + offsetof(Basis1D<float>, P1), pf.data(), sizeof(float) * np1,
+                        hipMemcpyHostToDevice));
+    }
+  *out = tr.release();
+  return MGX_OK;
+}
+
+int mgx_transfer_destroy(mgx_transfer_t tr)
+{
+  if (!tr)
+    return MGX_OK;
+  (void)hipStreamSynchronize(tr->coarse->ctx->stream);
+  (void)hipFree(tr->d.children);
+  (void)hipFree(tr->d.weight_shift);
+  delete tr;
+  return MGX_OK;
+}
+
+int mgx_prolongate(mgx_transfer_t tr, void *fine, const void *coarse, int add, int with_constraints)
+{
+  MGX_REQUIRE(tr && fine && coarse, "mgx_prolongate: null argument");
+  launch_prolongate(tr->coarse->ctx->stream, tr->d, fine, coarse, add != 0, with_constraints != 0);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_restrict_and_add(mgx_transfer_t tr, void *coarse, const void *fine, int with_constraints)
+{
+  MGX_REQUIRE(tr && fine && coarse, "mgx_restrict_and_add: null argument");
+  launch_restrict_add(tr->coarse->ctx->stream, tr->d, coarse, fine, with_constraints != 0);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * MultigridSolver
+ * ------------------------------------------------------------------------------------------ */
+int mgx_solver_destroy(mgx_solver_t S)
+{
+  if (!S)
+    return MGX_OK;
+  (void)hipStreamSynchronize(S->ctx->stream);
+  for (auto sm : S->smooth)
+    mgx_smoother_destroy(sm);
+  for (auto p : S->solution)
+    (void)hipFree(p);
+  for (auto p : S->rhs)
+    (void)hipFree(p);
+  for (auto p : S->residual)
+    (void)hipFree(p);
+  for (auto p : S->defect)
+    (void)hipFree(p);
+  for (auto p : S->t)
+    (void)hipFree(p);
+  for (auto p : S->solution_update)
+    (void)hipFree(p);
+  for (auto p : S->bc_index_dev)
+    (void)hipFree(p);
+  for (auto p : S->bc_value_dev)
+    (void)hipFree(p);
+  for (auto p : S->bc_zero_dev)
+    (void)hipFree(p);
+  (void)hipFree(S->cg_r);
+  (void)hipFree(S->cg_z);
+  (void)hipFree(S->cg_d);
+  (void)hipFree(S->cg_h);
+  delete S;
+  return MGX_OK;
+}
+
+int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver_t *out)
+{
+  MGX_REQUIRE(ctx && desc && out, "mgx_solver_create: null argument");
+  MGX_REQUIRE(desc->n_levels >= 1 && desc->matrix && desc->matrix_dp && desc->rhs && desc->bc_count,
+              "mgx_solver_create: incomplete descriptor");
+  MGX_REQUIRE(desc->n_levels == 1 || (desc->transfer && desc->transfer_dp), "mgx_solver_create: missing transfers");
+  MGX_REQUIRE(desc->degree_pre >= 1 && desc->n_cycles >= 1, "mgx_solver_create: bad smoother degree / cycle count");
+  auto S      = std::unique_ptr<mgx_solver_s, int (*)(mgx_solver_t)>(new mgx_solver_s, mgx_solver_destroy);
+  S->ctx      = ctx;
+  S->n_levels = desc->n_levels;
+  S->degree   = desc->degree_pre;
+  S->n_cycles = desc->n_cycles;
+  S->vnumber  = desc->matrix[0]->d.number;
+  S->timings.assign(6 * (size_t)desc->n_levels, 0.);
+  const int nl = desc->n_levels;
+  S->transfer.assign(nl, nullptr);
+  S->transfer_dp.assign(nl, nullptr);
+  for (int l = 0; l < nl; ++l)
+    {
+      MGX_REQUIRE(desc->matrix[l] && desc->matrix_dp[l], "mgx_solver_create: null level operator");
+      MGX_REQUIRE(desc->matrix_dp[l]->d.number == MGX_F64, "mgx_solver_create: matrix_dp must be fp64");
+      MGX_REQUIRE(desc->matrix[l]->d.number == S->vnumber, "mgx_solver_create: mixed V-cycle number types");
+      MGX_REQUIRE(desc->matrix[l]->d.n_dofs == desc->matrix_dp[l]->d.n_dofs, "mgx_solver_create: level size mismatch");
+      S->matrix.push_back(desc->matrix[l]);
+      S->matrix_dp.push_back(desc->matrix_dp[l]);
+      if (l > 0)
+        {
+          MGX_REQUIRE(desc->transfer[l] && desc->transfer_dp[l], "mgx_solver_create: null transfer");
+          S->transfer[l]    = desc->transfer[l];
+          S->transfer_dp[l] = desc->transfer_dp[l];
+        }
+      const size_t n = desc->matrix[l]->d.n_dofs;
+      double      *p = nullptr;
+      void        *q = nullptr;
+      MGX_HIP(hipMalloc((void **)&p, 8 * n));
+      MGX_HIP(hipMemset(p, 0, 8 * n));
+      S->solution.push_back(p);
+      MGX_HIP(hipMalloc((void **)&p, 8 * n));
+      MGX_HIP(hipMemcpy(p, desc->rhs[l], 8 * n, hipMemcpyHostToDevice));
+      S->rhs.push_back(p);
+      MGX_HIP(hipMalloc((void **)&p, 8 * n));
+      MGX_HIP(hipMemset(p, 0, 8 * n));
+      S->residual.push_back(p);
+      const size_t vb = number_size(S->vnumber) * n;
+      MGX_HIP(hipMalloc(&q, vb));
+      MGX_HIP(hipMemset(q, 0, vb));
+      S->defect.push_back(q);
+      MGX_HIP(hipMalloc(&q, vb));
+      MGX_HIP(hipMemset(q, 0, vb));
+      S->t.push_back(q);
+      MGX_HIP(hipMalloc(&q, vb));
+      MGX_HIP(hipMemset(q, 0, vb));
+      S->solution_update.push_back(q);
+      // inhomogeneous boundary values (multigrid_solver.h:225-253)
+      const uint32_t nb = desc->bc_count[l];
+      S->bc_count.push_back(nb);
+      uint32_t *bi = nullptr;
+      double   *bv = nullptr, *bz = nullptr;
+      MGX_HIP(hipMalloc((void **)&bi, sizeof(uint32_t) * (nb + 1)));
+      MGX_HIP(hipMalloc((void **)&bv, sizeof(double) * (nb + 1)));
+      MGX_HIP(hipMalloc((void **)&bz, sizeof(double) * (nb + 1)));
+      MGX_HIP(hipMemset(bz, 0, sizeof(double) * (nb + 1)));
+      if (nb)
+        {
+          MGX_REQUIRE(desc->bc_index && desc->bc_value && desc->bc_index[l] && desc->bc_value[l],
+                      "mgx_solver_create: missing boundary lists");
+          for (uint32_t i = 0; i < nb; ++i)
+            if (desc->bc_index[l][i] >= n)
+              return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_solver_create: boundary index out of range");
+          MGX_HIP(hipMemcpy(bi, desc->bc_index[l], sizeof(uint32_t) * nb, hipMemcpyHostToDevice));
+          MGX_HIP(hipMemcpy(bv, desc->bc_value[l], sizeof(double) * nb, hipMemcpyHostToDevice));
+        }
+      S->bc_index_dev.push_back(bi);
+      S->bc_value_dev.push_back(bv);
+      S->bc_zero_dev.push_back(bz);
+    }
+  // smoothers (multigrid_solver.h:269-289)
+  for (int l = 0; l < nl; ++l)
+    {
+      mgx_smoother_t sm = nullptr;
+      MGX_TRY(mgx_compute_diagonal(S->matrix[l])); // :286
+      if (l > 0)
+        MGX_TRY(mgx_smoother_create(S->matrix[l], 20., S->degree, 15, &sm)); // :274-278
+      else
+        MGX_TRY(mgx_smoother_create(S->matrix[l], 1e-3, -1, (int)std::max<uint32_t>(3u, S->matrix[l]->d.n_dofs),
+                                    &sm)); // :282-284
+      S->smooth.push_back(sm);
+    }
+  const size_t nmax = S->matrix[nl - 1]->d.n_dofs;
+  MGX_HIP(hipMalloc((void **)&S->cg_r, 8 * nmax));
+  MGX_HIP(hipMalloc((void **)&S->cg_z, 8 * nmax));
+  MGX_HIP(hipMalloc((void **)&S->cg_d, 8 * nmax));
+  MGX_HIP(hipMalloc((void **)&S->cg_h, 8 * nmax));
+  *out = S.release();
+  return MGX_OK;
+}
+
+static void set_bc(mgx_solver_t S, int level, double *v, bool zero)
+{
+  launch_scatter_values(S->ctx->stream, MGX_F64, v, S->bc_index_dev[level],
+                        zero ? S->bc_zero_dev[level] : S->bc_value_dev[level], S->bc_count[level]);
+}
+
+// MultigridSolver::v_cycle (multigrid_solver.h:641-681)
+static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
+{
+  hipStream_t s = S->ctx->stream;
+  if (level == 0)
+    {
+      Stopwatch sw(S, 0, 0);
+      S->timings[1] += 1;
+      return mgx_smoother_vmult(S->smooth[0], S->solution_update[0], S->defect[0]); // :647 (MGCoarseFromSmoother :72-91)
+    }
+  const size_t nc = S->matrix[level - 1]->d.n_dofs;
+  for (int c = 0; c < my_n_cycles; ++c)
+    {
+      {
+        Stopwatch sw(S, level, 5);
+        if (c == 0) // :656-659
+          MGX_TRY(mgx_smoother_vmult(S->smooth[level], S->solution_update[level], S->defect[level]));
+        else
+          MGX_TRY(mgx_smoother_step(S->smooth[level], S->solution_update[level], S->defect[level]));
+      }
+      {
+        Stopwatch sw(S, level, 0);
+        MGX_TRY(mgx_vmult_residual(S->matrix[level], S->defect[level], S->solution_update[level], S->t[level])); // :663
+      }
+      {
+        Stopwatch sw(S, level, 1);
+        MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s));         // :667
+        MGX_TRY(mgx_restrict_and_add(S->transfer[level], S->defect[level - 1], S->t[level], 1)); // :668
+      }
+      MGX_TRY(v_cycle(S, level - 1, 1)); // :671
+      {
+        Stopwatch sw(S, level, 2);
+        MGX_TRY(mgx_prolongate(S->transfer[level], S->solution_update[level], S->solution_update[level - 1], 1,
+                               1)); // :674
+      }
+      {
+        Stopwatch sw(S, level, 5);
+        MGX_TRY(mgx_smoother_step(S->smooth[level], S->solution_update[level], S->defect[level])); // :678
+      }
+    }
+  return MGX_OK;
+}
+
+int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, double *trace)
+{
+  MGX_REQUIRE(S, "mgx_solver_solve: null solver");
+  hipStream_t s    = S->ctx->stream;
+  double      rate = 1.;
+  {
+    // coarse solver invoked twice (multigrid_solver.h:397-402)
+    Stopwatch    sw(S, 0, 0);
+    const size_t n0 = S->matrix[0]->d.n_dofs;
+    launch_copy_cast(s, S->defect[0], S->vnumber, S->rhs[0], MGX_F64, n0);
+    MGX_TRY(mgx_smoother_vmult(S->smooth[0], S->t[0], S->defect[0]));
+    MGX_TRY(mgx_smoother_step(S->smooth[0], S->t[0], S->defect[0]));
+    launch_copy_cast(s, S->solution[0], MGX_F64, S->t[0], S->vnumber, n0);
+    S->timings[1] += 2;
+  }
+  for (int level = 1; level < S->n_levels; ++level)
+    {
+      const size_t n = S->matrix[level]->d.n_dofs;
+      {
+        Stopwatch sw(S, level, 3);
+        set_bc(S, level - 1, S->solution[level - 1], false); // :408-409
+      }
+      {
+        Stopwatch sw(S, level, 2);
+        MGX_TRY(mgx_prolongate(S->transfer_dp[level], S->solution[level], S->solution[level - 1], 0, 0)); // :415
+      }
+      double init_residual = 1.;
+      set_bc(S, level, S->solution[level], true); // :427-428
+      {
+        Stopwatch sw(S, level, 0);
+        MGX_TRY(mgx_vmult_residual(S->matrix_dp[level], S->rhs[level], S->solution[level], S->residual[level])); // :432
+      }
+      {
+        Stopwatch sw(S, level, 4);
+        launch_copy_cast(s, S->defect[level], S->vnumber, S->residual[level], MGX_F64, n); // :437
+      }
+      if (do_analyze)
+        {
+          MGX_TRY(mgx_l2_norm(S->ctx, MGX_F64, S->residual[level], n, &init_residual)); // :444
+          if (trace)
+            trace[2 * level] = init_residual;
+        }
+      MGX_TRY(v_cycle(S, level, S->n_cycles)); // :451
+      {
+        Stopwatch sw(S, level, 4);
+        launch_add_cast(s, S->solution[level], MGX_F64, S->solution_update[level], S->vnumber, n); // :456
+      }
+      if (do_analyze)
+        {
+          set_bc(S, level, S->solution[level], true);                                         // :462-463
+          MGX_TRY(mgx_vmult(S->matrix_dp[level], S->residual[level], S->solution[level]));    // :464
+          launch_sadd(s, MGX_F64, S->residual[level], -1., 1., S->rhs[level], n);             // :465
+          double res_norm = 0;
+          MGX_TRY(mgx_l2_norm(S->ctx, MGX_F64, S->residual[level], n, &res_norm));            // :466
+          rate = std::pow(res_norm / init_residual, 1. / S->n_cycles);                        // :467
+          if (trace)
+            trace[2 * level + 1] = res_norm;
+        }
+    }
+  MGX_HIP(hipGetLastError());
+  if (reduction_rate)
+    *reduction_rate = rate;
+  return MGX_OK;
+}
+
+int mgx_solver_vmult(mgx_solver_t S, double *dst, const double *src)
+{
+  MGX_REQUIRE(S && dst && src, "mgx_solver_vmult: null argument");
+  const int    lmax = S->n_levels - 1;
+  const size_t n    = S->matrix[lmax]->d.n_dofs;
+  hipStream_t  s    = S->ctx->stream;
+  launch_copy_cast(s, S->defect[lmax], S->vnumber, src, MGX_F64, n); // :503
+  MGX_TRY(v_cycle(S, lmax, 1));                                       // :505
+  launch_copy_cast(s, dst, MGX_F64, S->solution_update[lmax], S->vnumber, n); // :507
+  return MGX_OK;
+}
+
+int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduction_rate)
+{
+  MGX_REQUIRE(S, "mgx_solver_solve_cg: null solver");
+  const int      lmax = S->n_levels - 1;
+  const size_t   n    = S->matrix[lmax]->d.n_dofs;
+  mgx_context_t  ctx  = S->ctx;
+  hipStream_t    s    = ctx->stream;
+  mgx_operator_t A    = S->matrix_dp[lmax];
+  double        *x = S->solution[lmax], *r = S->cg_r, *z = S->cg_z, *d = S->cg_d, *h = S->cg_h;
+  MGX_HIP(hipMemsetAsync(x, 0, 8 * n, s)); // :488
+  launch_copy_cast(s, r, MGX_F64, S->rhs[lmax], MGX_F64, n);
+  double res0 = 0;
+  MGX_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
+  double       res = res0, rz = 0, rz_old = 0;
+  unsigned int it  = 0;
+  // SolverCG with ReductionControl(1000, 1e-16, 1e-9) (:486)
+  while (res > 1e-16 && res > 1e-9 * res0 && it < 1000)
+    {
+      ++it;
+      MGX_TRY(mgx_solver_vmult(S, z, r));
+      rz_old = rz;
+      MGX_TRY(dot(ctx, MGX_F64, r, z, n, &rz));
+      if (it > 1)
+        launch_xpby(s, MGX_F64, d, z, rz / rz_old, n);
+      else
+        launch_copy_cast(s, d, MGX_F64, z, MGX_F64, n);
+      MGX_TRY(mgx_vmult(A, h, d));
+      double dh = 0;
+      MGX_TRY(dot(ctx, MGX_F64, d, h, n, &dh));
+      launch_cg_update(s, MGX_F64, x, r, d, h, rz / dh, n, ctx->partial_dev, ctx->result_dev);
+      MGX_TRY(read_result(ctx, &res));
+      res = std::sqrt(res);
+    }
+  if (iterations)
+    *iterations = it;
+  if (reduction_rate)
+    *reduction_rate = it > 0 ? std::pow(res / res0, 1. / it) : 1.; // :491-492
+  if (it >= 1000)
+    return fail(MGX_ERR_NOT_CONVERGED, "mgx_solver_solve_cg: no convergence in 1000 iterations");
+  return MGX_OK;
+}
+
+int mgx_solver_do_matvec(mgx_solver_t S)
+{
+  MGX_REQUIRE(S, "mgx_solver_do_matvec: null solver");
+  const int lmax = S->n_levels - 1;
+  return mgx_vmult(S->matrix_dp[lmax], S->residual[lmax], S->solution[lmax]); // :627
+}
+
+int mgx_solver_do_matvec_smoother(mgx_solver_t S)
+{
+  MGX_REQUIRE(S, "mgx_solver_do_matvec_smoother: null solver");
+  const int lmax = S->n_levels - 1;
+  return mgx_vmult(S->matrix[lmax], S->solution_update[lmax], S->defect[lmax]); // :636
+}
+
+int mgx_solver_get_solution(mgx_solver_t S, int level, int insert_bc, const double **dptr)
+{
+  MGX_REQUIRE(S && dptr && level >= 0 && level < S->n_levels, "mgx_solver_get_solution: bad argument");
+  if (insert_bc)
+    set_bc(S, level, S->solution[level], false); // :379-380
+  *dptr = S->solution[level];
+  return MGX_OK;
+}
+
+int mgx_solver_get_vector(mgx_solver_t S, int level, int which, void **dptr)
+{
+  MGX_REQUIRE(S && dptr && level >= 0 && level < S->n_levels, "mgx_solver_get_vector: bad argument");
+  switch (which)
+    {
+      case 0: *dptr = S->rhs[level]; break;
+      case 1: *dptr = S->residual[level]; break;
+      case 2: *dptr = S->defect[level]; break;
+      case 3: *dptr = S->t[level]; break;
+      case 4: *dptr = S->solution_update[level]; break;
+      default: return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_solver_get_vector: unknown vector id");
+    }
+  return MGX_OK;
+}
+
+int mgx_solver_get_smoother(mgx_solver_t S, int level, mgx_smoother_t *sm)
+{
+  MGX_REQUIRE(S && sm && level >= 0 && level < S->n_levels, "mgx_solver_get_smoother: bad argument");
+  *sm = S->smooth[level];
+  return MGX_OK;
+}
+
+int mgx_solver_get_timings(mgx_solver_t S, double *timings)
+{
+  MGX_REQUIRE(S && timings, "mgx_solver_get_timings: null argument");
+  std::copy(S->timings.begin(), S->timings.end(), timings);
+  std::fill(S->timings.begin(), S->timings.end(), 0.); // print_wall_times resets :368-370
+  return MGX_OK;
+}
+
+int mgx_solver_enable_timings(mgx_solver_t S, int enable)
+{
+  MGX_REQUIRE(S, "mgx_solver_enable_timings: null solver");
+  S->timing = enable != 0;
+  return MGX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,686 @@
+// mgx_cube.cpp -- host-side structured-cube discretisation (see include/mgx_cube.h): what deal.II's
+// Triangulation/DoFHandler/MatrixFree/FE_Q hand to the reference's LaplaceOperator and
+// MultigridSolver for poisson_cube.  Pure host code (C++17 + OpenMP); the device work is behind
+// mgx.h.
+#include "../../include/mgx_cube.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace
+{
+  constexpr int    kMaxN = 10;
+  constexpr double kPi   = 3.14159265358979323846264338327950288;
+
+  // ---- 1D element data: FE_Q(p) on Gauss-Lobatto nodes, QGauss(p+1) ----
+  struct Basis
+  {
+    int    p = 0, n = 0;
+    double gll[kMaxN], gq[kMaxN], gw[kMaxN];
+    double S[kMaxN * kMaxN], D[kMaxN * kMaxN], P1[2 * kMaxN * kMaxN];
+  };
+
+  using ld = long double;
+
+  void legendre(int n, ld x, ld &P, ld &dP)
+  {
+    if (n == 0)
+      {
+        P  = 1;
+        dP = 0;
+        return;
+      }
+    ld p0 = 1, p1 = x;
+    for (int k = 2; k <= n; ++k)
+      {
+        const ld pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+        p0          = p1;
+        p1          = pk;
+      }
+    P  = p1;
+    dP = n * (x * p1 - p0) / (x * x - 1);
+  }
+
+  ld lagrange_value(const std::vector<ld> &x, int i, ld t)
+  {
+    ld v = 1;
+    for (size_t j = 0; j < x.size(); ++j)
+      if ((int)j != i)
+        v *= (t - x[j]) / (x[i] - x[j]);
+    return v;
+  }
+
+  ld lagrange_derivative(const std::vector<ld> &x, int i, ld t)
+  {
+    ld s = 0;
+    for (size_t k = 0; k < x.size(); ++k)
+      if ((int)k != i)
+        {
+          ld term = 1 / (x[i] - x[k]);
+          for (size_t j = 0; j < x.size(); ++j)
+            if ((int)j != i && j != k)
+              term *= (t - x[j]) / (x[i] - x[j]);
+          s += term;
+        }
+    return s;
+  }
+
+  void make_basis(Basis &b, int p)
+  {
+    const int n = p + 1;
+    b.p         = p;
+    b.n         = n;
+    std::vector<ld> gll(n), gq(n), gw(n);
+    for (int i = 0; i < n; ++i) // Gauss-Legendre nodes: Newton on P_n
+      {
+        ld x = -std::cos((ld)kPi * (i + 0.75L) / (n + 0.5L)), P, dP;
+        for (int it = 0; it < 100; ++it)
+          {
+            legendre(n, x, P, dP);
+            const ld dx = P / dP;
+            x -= dx;
+            if (std::fabs(dx) < 1e-19L)
+              break;
+          }
+        legendre(n, x, P, dP);
+        gq[i] = (x + 1) / 2;
+        gw[i] = 1 / ((1 - x * x) * dP * dP);
+      }
+    gll[0] = 0;
+    gll[p] = 1;
+    for (int i = 1; i < p; ++i) // Gauss-Lobatto interior nodes: Newton on P_p'
+      {
+        ld x = -std::cos((ld)kPi * i / p), P, dP;
+        for (int it = 0; it < 100; ++it)
+          {
+            legendre(p, x, P, dP);
+            const ld d2P = (2 * x * dP - (ld)p * (p + 1) * P) / (1 - x * x);
+            const ld dx  = dP / d2P;
+            x -= dx;
+            if (std::fabs(dx) < 1e-19L)
+              break;
+          }
+        gll[i] = (x + 1) / 2;
+      }
+    for (int i = 0; i < n; ++i)
+      {
+        b.gll[i] = (double)gll[i];
+        b.gq[i]  = (double)gq[i];
+        b.gw[i]  = (double)gw[i];
+      }
+    for (int q = 0; q < n; ++q)
+      for (int i = 0; i < n; ++i)
+        {
+          b.S[q * n + i] = (double)lagrange_value(gll, i, gq[q]);
+          b.D[q * n + i] = (double)lagrange_derivative(gq, i, gq[q]);
+        }
+    for (int a = 0; a <= 2 * p; ++a)
+      {
+        const int child = a < p ? 0 : 1;
+        const ld  xi    = (child + gll[a - child * p]) / 2;
+        for (int i = 0; i < n; ++i)
+          {
+            ld v = lagrange_value(gll, i, xi);
+            if (std::fabs(v) < 1e-18L)
+              v = 0;
+            if (std::fabs(v - 1) < 1e-18L)
+              v = 1;
+            b.P1[a * n + i] = (double)v;
+          }
+      }
+  }
+
+  struct Level
+  {
+    int                   level = 0;
+    uint32_t              N = 0, n_cells = 0, n_dofs = 0, n_free = 0;
+    double                h = 0;
+    std::vector<uint32_t> idx27, idx27_plain, constrained, children, coords, dof_grid;
+    std::vector<double>   rhs, bc_value;
+    std::vector<uint32_t> bc_index;
+  };
+
+  inline uint32_t compact3(uint32_t m)
+  {
+    uint32_t r = 0;
+    for (int b = 0; b < 10; ++b)
+      r |= ((m >> (3 * b)) & 1u) << b;
+    return r;
+  }
+
+  double u_exact(double x, double y, double z) // poisson_cube/program.cc:98-104
+  {
+    return std::sin(kPi * x * 3.) * std::sin(kPi * y * 3.) * std::sin(kPi * z * 3.);
+  }
+  double f_rhs(double x, double y, double z) // :140-144
+  {
+    return 3. * kPi * 3. * kPi * 3. * u_exact(x, y, z);
+  }
+} // namespace
+
+struct mgx_cube_s
+{
+  int                p = 0, n_subdiv = 1;
+  Basis              basis;
+  std::vector<Level> levels;
+};
+
+namespace
+{
+  // offsets of a cell's DoFs: entity e = 9cz+3cy+cx; size of the entity and the position of the
+  // grid point of local DoF (ox,oy,oz)
+  void build_level(mgx_cube_s &C, Level &L, int level)
+  {
+    const int      p  = C.p;
+    const uint32_t N  = (uint32_t)C.n_subdiv << level;
+    L.level           = level;
+    L.N               = N;
+    L.n_cells         = N * N * N;
+    L.h               = 1.9 / N;
+    const uint32_t nc = L.n_cells, ns = (uint32_t)C.n_subdiv, per_root = 1u << (3 * level);
+    L.coords.resize(3 * (size_t)nc);
+    for (uint32_t c = 0; c < nc; ++c)
+      {
+        const uint32_t r = c / per_root, m = c % per_root;
+        L.coords[3 * (size_t)c + 0] = ((r % ns) << level) + compact3(m);
+        L.coords[3 * (size_t)c + 1] = (((r / ns) % ns) << level) + compact3(m >> 1);
+        L.coords[3 * (size_t)c + 2] = ((r / (ns * ns)) << level) + compact3(m >> 2);
+      }
+    const size_t          E = 2 * (size_t)N + 1;
+    std::vector<uint32_t> first(E * E * E, MGX_INVALID_INDEX);
+    auto                  esize = [p](int cx, int cy, int cz) {
+      return (uint32_t)((cx == 1 ? p - 1 : 1) * (cy == 1 ? p - 1 : 1) * (cz == 1 ? p - 1 : 1));
+    };
+    uint32_t next = 0;
+    for (int pass = 0; pass < 2; ++pass) // unconstrained entities first, Dirichlet boundary last
+      {
+        for (uint32_t c = 0; c < nc; ++c)
+          {
+            const size_t X = L.coords[3 * (size_t)c], Y = L.coords[3 * (size_t)c + 1],
+                         Z = L.coords[3 * (size_t)c + 2];
+            for (int cz = 0; cz < 3; ++cz)
+              for (int cy = 0; cy < 3; ++cy)
+                for (int cx = 0; cx < 3; ++cx)
+                  {
+                    const size_t ex = 2 * X + cx, ey = 2 * Y + cy, ez = 2 * Z + cz;
+                    const bool   on_boundary =
+                      ex == 0 || ex == E - 1 || ey == 0 || ey == E - 1 || ez == 0 || ez == E - 1;
+                    if ((int)on_boundary != pass)
+                      continue;
+                    uint32_t &f = first[(ez * E + ey) * E + ex];
+                    if (f == MGX_INVALID_INDEX)
+                      {
+                        f = next;
+                        next += esize(cx, cy, cz);
+                      }
+                  }
+          }
+        if (pass == 0)
+          L.n_free = next;
+      }
+    L.n_dofs = next;
+    L.constrained.resize(L.n_dofs - L.n_free);
+    for (uint32_t i = 0; i < L.constrained.size(); ++i)
+      L.constrained[i] = L.n_free + i;
+    L.idx27.resize(27 * (size_t)nc);
+    L.idx27_plain.resize(27 * (size_t)nc);
+#pragma omp parallel for schedule(static)
+    for (uint32_t c = 0; c < nc; ++c)
+      {
+        const size_t X = L.coords[3 * (size_t)c], Y = L.coords[3 * (size_t)c + 1], Z = L.coords[3 * (size_t)c + 2];
+        for (int e = 0; e < 27; ++e)
+          {
+            const int      cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+            const uint32_t base = first[((2 * Z + cz) * E + 2 * Y + cy) * E + 2 * X + cx];
+            L.idx27_plain[27 * (size_t)c + e] = base;
+            L.idx27[27 * (size_t)c + e]       = base >= L.n_free ? MGX_INVALID_INDEX : base;
+          }
+      }
+    if (level > 0)
+      {
+        L.children.resize(nc);
+        for (uint32_t i = 0; i < nc; ++i)
+          L.children[i] = i; // Morton order: children of parent c are 8c .. 8c+7
+      }
+  }
+
+  void build_dof_grid(const mgx_cube_s &C, Level &L)
+  {
+    const int    p = C.p;
+    const size_t G = (size_t)L.N * p + 1;
+    L.dof_grid.assign(L.n_dofs, 0);
+    for (uint32_t c = 0; c < L.n_cells; ++c)
+      {
+        const size_t X = L.coords[3 * (size_t)c], Y = L.coords[3 * (size_t)c + 1], Z = L.coords[3 * (size_t)c + 2];
+        for (int e = 0; e < 27; ++e)
+          {
+            const int      cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+            const int      nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
+            const uint32_t base = L.idx27_plain[27 * (size_t)c + e];
+            for (int oz = 0; oz < nz; ++oz)
+              for (int oy = 0; oy < ny; ++oy)
+                for (int ox = 0; ox < nx; ++ox)
+                  {
+                    const size_t gx = X * p + (cx == 0 ? 0 : (cx == 2 ? p : 1 + ox));
+                    const size_t gy = Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
+                    const size_t gz = Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
+                    L.dof_grid[base + (uint32_t)((oz * ny + oy) * nx + ox)] = (uint32_t)((gz * G + gy) * G + gx);
+                  }
+          }
+      }
+  }
+
+  // host cell kernels (setup only): lexicographic gather through a 27-entry table
+  void gather_cell(int p, const uint32_t *base, const double *src, double *v)
+  {
+    const int n = p + 1;
+    for (int k = 0; k < n; ++k)
+      {
+        const int cz = k == 0 ? 0 : (k == p ? 2 : 1), oz = cz == 1 ? k - 1 : 0;
+        for (int j = 0; j < n; ++j)
+          {
+            const int       cy = j == 0 ? 0 : (j == p ? 2 : 1), oy = cy == 1 ? j - 1 : 0;
+            const uint32_t  off = (uint32_t)((cy == 1 ? p - 1 : 1) * oz + oy);
+            const uint32_t *ind = base + 3 * (3 * cz + cy);
+            double         *row = v + (k * n + j) * n;
+            row[0]              = ind[0] == MGX_INVALID_INDEX ? 0. : src[ind[0] + off];
+            for (int i = 0; i < p - 1; ++i)
+              row[1 + i] = ind[1] == MGX_INVALID_INDEX ? 0. : src[ind[1] + off * (uint32_t)(p - 1) + (uint32_t)i];
+            row[p] = ind[2] == MGX_INVALID_INDEX ? 0. : src[ind[2] + off];
+          }
+      }
+  }
+
+  template <bool atomic>
+  void scatter_cell(int p, const uint32_t *base, double *dst, const double *v)
+  {
+    const int n   = p + 1;
+    auto      add = [&](uint32_t idx, double val) {
+      if (atomic)
+        {
+#pragma omp atomic
+          dst[idx] += val;
+        }
+      else
+        dst[idx] += val;
+    };
+    for (int k = 0; k < n; ++k)
+      {
+        const int cz = k == 0 ? 0 : (k == p ? 2 : 1), oz = cz == 1 ? k - 1 : 0;
+        for (int j = 0; j < n; ++j)
+          {
+            const int       cy = j == 0 ? 0 : (j == p ? 2 : 1), oy = cy == 1 ? j - 1 : 0;
+            const uint32_t  off = (uint32_t)((cy == 1 ? p - 1 : 1) * oz + oy);
+            const uint32_t *ind = base + 3 * (3 * cz + cy);
+            const double   *row = v + (k * n + j) * n;
+            if (ind[0] != MGX_INVALID_INDEX)
+              add(ind[0] + off, row[0]);
+            if (ind[1] != MGX_INVALID_INDEX)
+              for (int i = 0; i < p - 1; ++i)
+                add(ind[1] + off * (uint32_t)(p - 1) + (uint32_t)i, row[1 + i]);
+            if (ind[2] != MGX_INVALID_INDEX)
+              add(ind[2] + off, row[p]);
+          }
+      }
+  }
+
+  // tensor-product application of a 1D matrix (n x n, row-major, or its transpose) along dir
+  void apply_1d(int n, int dir, const double *M, bool transpose, const double *in, double *out, bool add)
+  {
+    const int stride = dir == 0 ? 1 : (dir == 1 ? n : n * n);
+    for (int o2 = 0; o2 < n; ++o2)
+      for (int o1 = 0; o1 < n; ++o1)
+        {
+          const int base = dir == 0 ? (o2 * n + o1) * n : (dir == 1 ? o2 * n * n + o1 : o2 * n + o1);
+          for (int a = 0; a < n; ++a)
+            {
+              double s = 0;
+              for (int b = 0; b < n; ++b)
+                s += (transpose ? M[b * n + a] : M[a * n + b]) * in[base + b * stride];
+              if (add)
+                out[base + a * stride] += s;
+              else
+                out[base + a * stride] = s;
+            }
+        }
+  }
+
+  // boundary values + rhs (multigrid_solver.h:225-261, laplace_operator.h:804-845)
+  void build_rhs(const mgx_cube_s &C, Level &L)
+  {
+    const int    p = C.p, n = p + 1, n3 = n * n * n;
+    const Basis &B = C.basis;
+    // inhomogeneous_bc: analytic solution at the support points of boundary DoFs, nonzero only
+    std::vector<double> bc_full(L.n_dofs, 0.);
+    {
+      const size_t G = (size_t)L.N * p + 1;
+      // support point coordinate of grid index g along one direction
+      std::vector<double> x1(G);
+      for (size_t g = 0; g < G; ++g)
+        {
+          size_t cell = g / p, loc = g % p;
+          if (cell == L.N)
+            {
+              cell = L.N - 1;
+              loc  = p;
+            }
+          x1[g] = -0.9 + L.h * ((double)cell + B.gll[loc]);
+        }
+      // walk boundary entities through the cells that touch the boundary
+      std::vector<uint8_t> done(L.n_dofs - L.n_free, 0);
+      for (uint32_t c = 0; c < L.n_cells; ++c)
+        {
+          const size_t X = L.coords[3 * (size_t)c], Y = L.coords[3 * (size_t)c + 1], Z = L.coords[3 * (size_t)c + 2];
+          if (X != 0 && X != L.N - 1 && Y != 0 && Y != L.N - 1 && Z != 0 && Z != L.N - 1)
+            continue;
+          for (int e = 0; e < 27; ++e)
+            {
+              const uint32_t base = L.idx27_plain[27 * (size_t)c + e];
+              const int      cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+              const int      nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
+              if (nx * ny * nz == 0) // p = 1: lines/quads/hexes carry no DoFs
+                continue;
+              if (base < L.n_free || done[base - L.n_free])
+                continue;
+              done[base - L.n_free] = 1;
+              for (int oz = 0; oz < nz; ++oz)
+                for (int oy = 0; oy < ny; ++oy)
+                  for (int ox = 0; ox < nx; ++ox)
+                    {
+                      const size_t gx = X * p + (cx == 0 ? 0 : (cx == 2 ? p : 1 + ox));
+                      const size_t gy = Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
+                      const size_t gz = Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
+                      bc_full[base + (uint32_t)((oz * ny + oy) * nx + ox)] = u_exact(x1[gx], x1[gy], x1[gz]);
+                    }
+            }
+        }
+    }
+    for (uint32_t i = L.n_free; i < L.n_dofs; ++i)
+      if (bc_full[i] != 0.0) // multigrid_solver.h:250
+        {
+          L.bc_index.push_back(i);
+          L.bc_value.push_back(bc_full[i]);
+        }
+    L.rhs.assign(L.n_dofs, 0.);
+    const double h = L.h, h3 = h * h * h;
+#pragma omp parallel
+    {
+      std::vector<double> buf(5 * (size_t)n3);
+      double             *u = buf.data(), *t0 = u + n3, *gx = t0 + n3, *gy = gx + n3, *gz = gy + n3;
+#pragma omp for schedule(static)
+      for (uint32_t c = 0; c < L.n_cells; ++c)
+        {
+          gather_cell(p, &L.idx27_plain[27 * (size_t)c], bc_full.data(), u);
+          for (int i = 0; i < n3; ++i)
+            u[i] = -u[i]; // laplace_operator.h:823-824
+          apply_1d(n, 0, B.S, false, u, t0, false);
+          apply_1d(n, 1, B.S, false, t0, u, false);
+          apply_1d(n, 2, B.S, false, u, t0, false);
+          apply_1d(n, 0, B.D, false, t0, gx, false);
+          apply_1d(n, 1, B.D, false, t0, gy, false);
+          apply_1d(n, 2, B.D, false, t0, gz, false);
+          const double x0 = -0.9 + h * L.coords[3 * (size_t)c], y0 = -0.9 + h * L.coords[3 * (size_t)c + 1],
+                       z0 = -0.9 + h * L.coords[3 * (size_t)c + 2];
+          for (int k = 0, q = 0; k < n; ++k)
+            for (int j = 0; j < n; ++j)
+              for (int i = 0; i < n; ++i, ++q)
+                {
+                  const double w = B.gw[i] * B.gw[j] * B.gw[k];
+                  gx[q] *= h * w; // merged coefficient diag(h,h,h) times w_q
+                  gy[q] *= h * w;
+                  gz[q] *= h * w;
+                  t0[q] = f_rhs(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]) * h3 * w; // :839
+                }
+          apply_1d(n, 0, B.D, true, gx, t0, true);
+          apply_1d(n, 1, B.D, true, gy, t0, true);
+          apply_1d(n, 2, B.D, true, gz, t0, true);
+          apply_1d(n, 0, B.S, true, t0, u, false);
+          apply_1d(n, 1, B.S, true, u, t0, false);
+          apply_1d(n, 2, B.S, true, t0, u, false);
+          scatter_cell<true>(p, &L.idx27[27 * (size_t)c], L.rhs.data(), u);
+        }
+    }
+  }
+
+  thread_local std::string g_cube_error;
+} // namespace
+
+extern "C" {
+
+int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *out)
+{
+  if (!out || degree < 1 || degree > MGX_MAX_DEGREE || n_subdiv < 1 || n_refine < 0 || n_refine > 9)
+    return MGX_ERR_INVALID_ARGUMENT;
+  const uint64_t N = (uint64_t)n_subdiv << n_refine;
+  if ((N * degree + 1) * (N * degree + 1) * (N * degree + 1) >= 0xFFFFFFFFull || N > 1023)
+    return MGX_ERR_UNSUPPORTED; // 32-bit DoF indices as in the reference's compressed table
+  auto C      = std::make_unique<mgx_cube_s>();
+  C->p        = degree;
+  C->n_subdiv = n_subdiv;
+  make_basis(C->basis, degree);
+  C->levels.resize(n_refine + 1);
+  for (int l = 0; l <= n_refine; ++l)
+    {
+      build_level(*C, C->levels[l], l);
+      build_rhs(*C, C->levels[l]);
+    }
+  *out = C.release();
+  return MGX_OK;
+}
+
+int mgx_cube_destroy(mgx_cube_t cube)
+{
+  delete cube;
+  return MGX_OK;
+}
+
+int      mgx_cube_n_levels(mgx_cube_t c) { return (int)c->levels.size(); }
+int      mgx_cube_degree(mgx_cube_t c) { return c->p; }
+uint32_t mgx_cube_n_cells(mgx_cube_t c, int l) { return c->levels[l].n_cells; }
+uint32_t mgx_cube_n_dofs(mgx_cube_t c, int l) { return c->levels[l].n_dofs; }
+uint32_t mgx_cube_n_constrained(mgx_cube_t c, int l) { return (uint32_t)c->levels[l].constrained.size(); }
+uint32_t mgx_cube_cells_per_dim(mgx_cube_t c, int l) { return c->levels[l].N; }
+double   mgx_cube_cell_size(mgx_cube_t c, int l) { return c->levels[l].h; }
+
+const uint32_t *mgx_cube_idx27(mgx_cube_t c, int l) { return c->levels[l].idx27.data(); }
+const uint32_t *mgx_cube_idx27_plain(mgx_cube_t c, int l) { return c->levels[l].idx27_plain.data(); }
+const uint32_t *mgx_cube_constrained(mgx_cube_t c, int l) { return c->levels[l].constrained.data(); }
+const uint32_t *mgx_cube_children(mgx_cube_t c, int l) { return l > 0 ? c->levels[l].children.data() : nullptr; }
+const uint32_t *mgx_cube_cell_coords(mgx_cube_t c, int l) { return c->levels[l].coords.data(); }
+const uint32_t *mgx_cube_dof_grid(mgx_cube_t c, int l)
+{
+  if (c->levels[l].dof_grid.empty())
+    build_dof_grid(*c, c->levels[l]);
+  return c->levels[l].dof_grid.data();
+}
+const double *mgx_cube_shape_values(mgx_cube_t c) { return c->basis.S; }
+const double *mgx_cube_colloc_grad(mgx_cube_t c) { return c->basis.D; }
+const double *mgx_cube_qweights(mgx_cube_t c) { return c->basis.gw; }
+const double *mgx_cube_qpoints(mgx_cube_t c) { return c->basis.gq; }
+const double *mgx_cube_gll(mgx_cube_t c) { return c->basis.gll; }
+const double *mgx_cube_prolong_1d(mgx_cube_t c) { return c->basis.P1; }
+
+const double   *mgx_cube_rhs(mgx_cube_t c, int l) { return c->levels[l].rhs.data(); }
+uint32_t        mgx_cube_bc_count(mgx_cube_t c, int l) { return (uint32_t)c->levels[l].bc_index.size(); }
+const uint32_t *mgx_cube_bc_index(mgx_cube_t c, int l) { return c->levels[l].bc_index.data(); }
+const double   *mgx_cube_bc_value(mgx_cube_t c, int l) { return c->levels[l].bc_value.data(); }
+
+int mgx_cube_operator_desc(mgx_cube_t c, int l, int number, mgx_operator_desc *d)
+{
+  if (!c || !d || l < 0 || l >= (int)c->levels.size())
+    return MGX_ERR_INVALID_ARGUMENT;
+  const Level &L   = c->levels[l];
+  d->degree        = c->p;
+  d->number        = number;
+  d->n_cells       = L.n_cells;
+  d->n_dofs        = L.n_dofs;
+  d->idx27         = L.idx27.data();
+  d->idx27_plain   = L.idx27_plain.data();
+  d->constrained   = L.constrained.data();
+  d->n_constrained = (uint32_t)L.constrained.size();
+  // merged_coefficient = a JxW J^-T J^-1 = h^3/h^2 on the Cartesian mesh (laplace_operator.h:374-387)
+  d->coef[0] = d->coef[1] = d->coef[2] = L.h;
+  d->coef[3] = d->coef[4] = d->coef[5] = 0.;
+  d->shape_values = c->basis.S;
+  d->colloc_grad  = c->basis.D;
+  d->qweights     = c->basis.gw;
+  return MGX_OK;
+}
+
+double mgx_cube_l2_error(mgx_cube_t c, int l, const double *sol)
+{
+  const Level &L = c->levels[l];
+  const Basis &B = c->basis;
+  const int    p = c->p, n = p + 1, n3 = n * n * n;
+  const double h = L.h, h3 = h * h * h;
+  double       err = 0, vol = 0;
+#pragma omp parallel reduction(+ : err, vol)
+  {
+    std::vector<double> buf(2 * (size_t)n3);
+    double             *u = buf.data(), *t0 = u + n3;
+#pragma omp for schedule(static)
+    for (uint32_t cell = 0; cell < L.n_cells; ++cell)
+      {
+        gather_cell(p, &L.idx27_plain[27 * (size_t)cell], sol, u); // read_dof_values_plain
+        apply_1d(n, 0, B.S, false, u, t0, false);
+        apply_1d(n, 1, B.S, false, t0, u, false);
+        apply_1d(n, 2, B.S, false, u, t0, false);
+        const double x0 = -0.9 + h * L.coords[3 * (size_t)cell], y0 = -0.9 + h * L.coords[3 * (size_t)cell + 1],
+                     z0 = -0.9 + h * L.coords[3 * (size_t)cell + 2];
+        for (int k = 0, q = 0; k < n; ++k)
+          for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i, ++q)
+              {
+                const double JxW = B.gw[i] * B.gw[j] * B.gw[k] * h3;
+                const double d   = t0[q] - u_exact(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]);
+                err += d * d * JxW;
+                vol += JxW;
+              }
+      }
+  }
+  return std::sqrt(err / vol);
+}
+
+int mgx_cube_seeded_vector(mgx_cube_t c, int l, uint64_t seed, double *out)
+{
+  if (!c || !out || l < 0 || l >= (int)c->levels.size())
+    return MGX_ERR_INVALID_ARGUMENT;
+  const uint32_t *g = mgx_cube_dof_grid(c, l);
+  const uint32_t  n = c->levels[l].n_dofs;
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < n; ++i)
+    {
+      uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)g[i] + 1);
+      z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      out[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+  return MGX_OK;
+}
+
+int mgx_cube_solver_destroy(mgx_cube_solver *s)
+{
+  if (!s)
+    return MGX_OK;
+  mgx_solver_destroy(s->solver);
+  for (int l = 0; l < s->n_levels; ++l)
+    {
+      if (s->transfer && s->transfer_dp && s->transfer_dp[l] != s->transfer[l])
+        mgx_transfer_destroy(s->transfer_dp[l]);
+      if (s->transfer)
+        mgx_transfer_destroy(s->transfer[l]);
+      if (s->matrix && s->matrix_dp && s->matrix_dp[l] != s->matrix[l])
+        mgx_operator_destroy(s->matrix_dp[l]);
+      if (s->matrix)
+        mgx_operator_destroy(s->matrix[l]);
+    }
+  delete[] s->matrix;
+  delete[] s->matrix_dp;
+  delete[] s->transfer;
+  delete[] s->transfer_dp;
+  std::memset(s, 0, sizeof(*s));
+  return MGX_OK;
+}
+
+int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int degree_pre, int n_cycles,
+                           mgx_cube_solver *out)
+{
+  if (!ctx || !cube || !out || (vnumber != MGX_F32 && vnumber != MGX_F64))
+    return MGX_ERR_INVALID_ARGUMENT;
+  const int nl = (int)cube->levels.size();
+  std::memset(out, 0, sizeof(*out));
+  out->n_levels    = nl;
+  out->matrix      = new mgx_operator_t[nl]();
+  out->matrix_dp   = new mgx_operator_t[nl]();
+  out->transfer    = new mgx_transfer_t[nl]();
+  out->transfer_dp = new mgx_transfer_t[nl]();
+  int status       = MGX_OK;
+  for (int l = 0; l < nl && status == MGX_OK; ++l)
+    {
+      mgx_operator_desc d;
+      mgx_cube_operator_desc(cube, l, MGX_F64, &d);
+      status = mgx_operator_create(ctx, &d, &out->matrix_dp[l]);
+      if (status != MGX_OK)
+        break;
+      if (vnumber == MGX_F64)
+        out->matrix[l] = out->matrix_dp[l];
+      else
+        {
+          d.number = MGX_F32;
+          status   = mgx_operator_create(ctx, &d, &out->matrix[l]);
+        }
+    }
+  for (int l = 1; l < nl && status == MGX_OK; ++l)
+    {
+      mgx_transfer_desc t;
+      t.children   = cube->levels[l].children.data();
+      t.prolong_1d = cube->basis.P1;
+      status       = mgx_transfer_create(out->matrix_dp[l - 1], out->matrix_dp[l], &t, &out->transfer_dp[l]);
+      if (status != MGX_OK)
+        break;
+      if (vnumber == MGX_F64)
+        out->transfer[l] = out->transfer_dp[l];
+      else
+        status = mgx_transfer_create(out->matrix[l - 1], out->matrix[l], &t, &out->transfer[l]);
+    }
+  if (status == MGX_OK)
+    {
+      std::vector<const double *>   rhs(nl), bcv(nl);
+      std::vector<const uint32_t *> bci(nl);
+      std::vector<uint32_t>         bcn(nl);
+      for (int l = 0; l < nl; ++l)
+        {
+          rhs[l] = cube->levels[l].rhs.data();
+          bci[l] = cube->levels[l].bc_index.data();
+          bcv[l] = cube->levels[l].bc_value.data();
+          bcn[l] = (uint32_t)cube->levels[l].bc_index.size();
+        }
+      mgx_solver_desc sd;
+      sd.n_levels    = nl;
+      sd.degree_pre  = degree_pre;
+      sd.n_cycles    = n_cycles;
+      sd.matrix      = out->matrix;
+      sd.matrix_dp   = out->matrix_dp;
+      sd.transfer    = out->transfer;
+      sd.transfer_dp = out->transfer_dp;
+      sd.rhs         = rhs.data();
+      sd.bc_index    = bci.data();
+      sd.bc_value    = bcv.data();
+      sd.bc_count    = bcn.data();
+      status         = mgx_solver_create(ctx, &sd, &out->solver);
+    }
+  if (status != MGX_OK)
+    {
+      std::string keep = mgx_last_error();
+      mgx_cube_solver_destroy(out);
+      (void)keep;
+    }
+  return status;
+}
+
+} // extern "C"

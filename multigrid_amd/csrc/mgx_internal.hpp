@@ -1,0 +1,97 @@
+// mgx_internal.hpp -- internal C++ interface between the C ABI (mgx_api.cpp) and the HIP kernels
+// (mgx_kernels.hip).  Not installed; the public boundary is include/mgx.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace mgx
+{
+  constexpr int      kMaxN    = 10; // p <= 9
+  constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+  // 1D data of the element in the operator's number type, resident in device memory and read
+  // through wave-uniform (scalar) loads.
+  template <typename T>
+  struct Basis1D
+  {
+    T S[kMaxN * kMaxN];       // S[q*n+i]   nodal -> quadrature
+    T D[kMaxN * kMaxN];       // D[q*n+r]   collocation derivative
+    T w[kMaxN];               // quadrature weights
+    T P1[2 * kMaxN * kMaxN];  // P1[a*n+i]  prolongation, a in [0,2p]
+  };
+
+  // Device-side view of a LaplaceOperator level (laplace_operator.h:126-163)
+  struct OperatorData
+  {
+    int       p        = 0;
+    int       number   = 1; // MGX_F64
+    uint32_t  n_cells  = 0;
+    uint32_t  n_dofs   = 0;
+    uint32_t  n_constrained = 0;
+    uint32_t *idx27         = nullptr; // device
+    uint32_t *idx27_plain   = nullptr; // device (may be null)
+    uint32_t *constrained   = nullptr; // device
+    void     *basis         = nullptr; // device Basis1D<T>
+    void     *inv_diag      = nullptr; // device, number type
+    double    coef[6]       = {0, 0, 0, 0, 0, 0};
+  };
+
+  struct TransferData
+  {
+    const OperatorData *coarse = nullptr, *fine = nullptr;
+    uint32_t           *children = nullptr;    // device [n_coarse_cells*8]
+    uint8_t            *weight_shift = nullptr; // device [n_coarse_cells*27]: weight = 2^-shift
+  };
+
+  // ---- cell loops (mgx_kernels.hip) ----
+  // dst += A_cells * src  (MatrixFree::cell_loop(local_apply), laplace_operator.h:527-558)
+  void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src);
+  // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)
+  // a1d[i] = sum_q w_q (dphi_i(x_q))^2, m1d[i] = sum_q w_q phi_i(x_q)^2 (host arrays, n entries)
+  void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a1d,
+                            const double *m1d);
+  // transfers
+  void launch_prolongate(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
+                         bool with_constraints);
+  void launch_restrict_add(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
+                           bool with_constraints);
+
+  // ---- vector kernels (mgx_vector.hip) ----
+  void launch_copy_cast(hipStream_t s, void *dst, int dn, const void *src, int sn, size_t n);
+  void launch_add_cast(hipStream_t s, void *dst, int dn, const void *src, int sn, size_t n);
+  void launch_sadd(hipStream_t s, int number, void *x, double sx, double a, const void *v, size_t n);
+  // res = rhs - res over [0,n)
+  void launch_rhs_minus(hipStream_t s, int number, void *res, const void *rhs, size_t n);
+  // dst[c] = src[c] for constrained c  /  res[c] = rhs[c] - lhs[c]
+  void launch_constrained_copy(hipStream_t s, int number, void *dst, const void *src, const uint32_t *list,
+                               uint32_t count);
+  void launch_constrained_residual(hipStream_t s, int number, void *res, const void *rhs, const void *lhs,
+                                   const uint32_t *list, uint32_t count);
+  void launch_constrained_set(hipStream_t s, int number, void *v, double value, const uint32_t *list,
+                              uint32_t count);
+  void launch_invert(hipStream_t s, int number, void *v, size_t n);
+  void launch_scatter_values(hipStream_t s, int number, void *v, const uint32_t *idx_dev, const double *val_dev,
+                             uint32_t count);
+  // Chebyshev updates (PreconditionChebyshev internal::vector_updates):
+  //   mode 0: x = f2 * dinv * b, x_old = 0
+  //   mode 1: x_new = x + f2 * dinv * (b - t)                       (x_old <- x)
+  //   mode 2: x_new = x + f1 * (x - x_old) + f2 * dinv * (b - t)     (x_old <- x)
+  void launch_cheb_update(hipStream_t s, int number, int mode, void *x, void *x_old, const void *b,
+                          const void *t, const void *dinv, double f1, double f2, size_t n);
+  // partial[0..n_blocks) block sums of x.y, then reduced into *result_dev (double)
+  void launch_dot(hipStream_t s, int number, const void *x, const void *y, size_t n, double *partial_dev,
+                  double *result_dev);
+  constexpr int kDotBlocks = 1024;
+  // CG vector updates with fused reductions
+  //   x += alpha d ; r -= alpha h ; result = r.r
+  void launch_cg_update(hipStream_t s, int number, void *x, void *r, const void *d, const void *h, double alpha,
+                        size_t n, double *partial_dev, double *result_dev);
+  //   d = z + beta d
+  void launch_xpby(hipStream_t s, int number, void *d, const void *z, double beta, size_t n);
+  // z = dinv .* r ; result = r.z
+  void launch_jacobi_dot(hipStream_t s, int number, void *z, const void *dinv, const void *r, size_t n,
+                         double *partial_dev, double *result_dev);
+} // namespace mgx

@@ -1,0 +1,628 @@
+// mgx_kernels.hip -- hand-written gfx950 kernels of the matrix-free Laplace cell loop and the
+// multigrid transfers.
+//
+// Mapping (CDNA4, 64-wide waves): a cell of FE_Q(p) has n^3 = (p+1)^3 points.  A tile of
+// n x n threads owns one cell; each thread holds ONE 1D line of n values in registers, so every
+// sum-factorisation sweep is an in-register (n x n)(n) product whose matrix
+// entries arrive through wave-uniform scalar loads.  Between sweeps the cell is transposed
+// through LDS (x-lines -> y-lines -> z-lines), one write + one read of n values per thread,
+// instead of the n^2 LDS reads per sweep of a "column in registers, rows in LDS" scheme.
+// Several cells are packed per 256-thread workgroup so the waves are full
+// (p=4: 10 cells = 250 threads).
+//
+// The DoF gather/scatter uses the reference's 27-entry compressed index table
+// (common/vector_access_reduced.h:11-505, restated in SURVEY.md Appendix A): thread (j,k) loads
+// the x-line {left vertex/edge/face entry, p-1 contiguous interior entries, right entry}.
+#include "mgx_internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace mgx
+{
+  template <int P>
+  struct Cfg
+  {
+    static constexpr int N        = P + 1;
+    static constexpr int LN       = N | 1; // x-line pitch, odd => conflict-free ds_read_b64
+    static constexpr int TPC      = N * N; // threads per cell
+    static constexpr int CPB      = (256 / TPC) < 1 ? 1 : (256 / TPC);
+    static constexpr int THREADS  = ((CPB * TPC + 63) / 64) * 64;
+    static constexpr int CELL_LDS = N * N * LN;
+  };
+
+  // out[a] = sum_b M[a*N+b] in[b]
+  template <int N, typename T>
+  __device__ __forceinline__ void mv(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      {
+        T s = M[a * N] * in[0];
+#pragma unroll
+        for (int b = 1; b < N; ++b)
+          s = fma(M[a * N + b], in[b], s);
+        out[a] = s;
+      }
+  }
+
+  // out[a] = sum_b M[b*N+a] in[b]
+  template <int N, typename T>
+  __device__ __forceinline__ void mvT(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      {
+        T s = M[a] * in[0];
+#pragma unroll
+        for (int b = 1; b < N; ++b)
+          s = fma(M[b * N + a], in[b], s);
+        out[a] = s;
+      }
+  }
+
+  // entity code (0 = low vertex plane, 1 = interior, 2 = high) and offset inside the entity of
+  // the 1D node index j (vector_access_reduced.h:232-247)
+  template <int P>
+  __device__ __forceinline__ void node_code(int j, int &code, int &offs)
+  {
+    code = (j == 0) ? 0 : (j == P ? 2 : 1);
+    offs = (code == 1) ? j - 1 : 0;
+  }
+
+  template <int P>
+  struct LineIndex
+  {
+    uint32_t b0, b1, b2; // first DoF of the left / interior / right entity of this x-line
+    uint32_t off;        // offset of the line inside those entities
+  };
+
+  // address computation of read_dof_values_compressed for the x-line (j,k) of `cell`
+  // (vector_access_reduced.h:153-229)
+  template <int P>
+  __device__ __forceinline__ LineIndex<P> line_index(const uint32_t *__restrict__ idx27, uint32_t cell, int j,
+                                                     int k)
+  {
+    int cy, oy, cz, oz;
+    node_code<P>(j, cy, oy);
+    node_code<P>(k, cz, oz);
+    LineIndex<P>    L;
+    const uint32_t *ind = idx27 + 27u * (size_t)cell + 3 * (3 * cz + cy);
+    L.b0                = ind[0];
+    L.b1                = ind[1];
+    L.b2                = ind[2];
+    L.off               = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
+    return L;
+  }
+
+  template <int P, typename T>
+  __device__ __forceinline__ void gather_line(const T *__restrict__ src, const LineIndex<P> &L, T (&r)[P + 1])
+  {
+    r[0] = L.b0 != kInvalid ? src[L.b0 + L.off] : T(0);
+#pragma unroll
+    for (int i = 0; i < P - 1; ++i)
+      r[1 + i] = L.b1 != kInvalid ? src[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i] : T(0);
+    r[P] = L.b2 != kInvalid ? src[L.b2 + L.off] : T(0);
+  }
+
+  template <int P, typename T>
+  __device__ __forceinline__ void scatter_add_line(T *__restrict__ dst, const LineIndex<P> &L,
+                                                   const T (&r)[P + 1])
+  {
+    if (L.b0 != kInvalid)
+      unsafeAtomicAdd(&dst[L.b0 + L.off], r[0]);
+    if (L.b1 != kInvalid)
+      {
+#pragma unroll
+        for (int i = 0; i < P - 1; ++i)
+          unsafeAtomicAdd(&dst[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i], r[1 + i]);
+      }
+    if (L.b2 != kInvalid)
+      unsafeAtomicAdd(&dst[L.b2 + L.off], r[P]);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Cell loop: dst += sum_cells  S^T [ sum_d D_d^T (c_d w) D_d ] S  src   (diagonal coefficient)
+  // = local_apply of laplace_operator.h:527-558 with the quadrature-point operation :471-487.
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T>
+  __global__ void __launch_bounds__(Cfg<P>::THREADS)
+    cell_loop_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
+                     uint32_t n_cells, const Basis1D<T> *__restrict__ B, T c0, T c1, T c2)
+  {
+    using C           = Cfg<P>;
+    constexpr int N   = C::N;
+    constexpr int LN  = C::LN;
+    constexpr int PL  = N * LN; // plane pitch
+    __shared__ T U[C::CPB * C::CELL_LDS];
+    __shared__ T V[C::CPB * C::CELL_LDS];
+
+    const int      tid    = threadIdx.x;
+    const int      lc     = tid / C::TPC;
+    const int      t      = tid - lc * C::TPC;
+    const int      a      = t % N;
+    const int      b      = t / N;
+    const uint32_t cell   = blockIdx.x * C::CPB + lc;
+    const bool     active = (lc < C::CPB) && (cell < n_cells);
+    T             *Uc     = U + (lc < C::CPB ? lc : 0) * C::CELL_LDS;
+    T             *Vc     = V + (lc < C::CPB ? lc : 0) * C::CELL_LDS;
+
+    const int xl = (b * N + a) * LN; // x-line (j=a,k=b): + i
+    const int yl = b * PL + a;       // y-line (i=a,k=b): + j*LN
+    const int zl = b * LN + a;       // z-line (i=a,j=b): + k*PL
+
+    const T wa = B->w[a], wb = B->w[b];
+    T       r[N], q[N], vz[N];
+    LineIndex<P> L;
+
+    // 1. gather x-lines, interpolate to quadrature points along x
+    if (active)
+      {
+        L = line_index<P>(idx27, cell, a, b);
+        gather_line<P, T>(src, L, r);
+        mv<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[xl + i] = q[i];
+      }
+    __syncthreads();
+    // 2. along y
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[yl + i * LN];
+        mv<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[yl + i * LN] = q[i];
+      }
+    __syncthreads();
+    // 3. along z -> values at quadrature points; z-derivative pair in registers
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[zl + i * PL];
+        mv<N, T>(B->S, r, q); // q = u at quadrature points of this z-line
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[zl + i * PL] = q[i];
+        mv<N, T>(B->D, q, r);
+        const T f = c2 * wa * wb;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] *= f * B->w[i];
+        mvT<N, T>(B->D, r, vz);
+      }
+    __syncthreads();
+    // 4. x-derivative pair
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          q[i] = Uc[xl + i];
+        mv<N, T>(B->D, q, r);
+        const T f = c0 * wa * wb;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] *= f * B->w[i];
+        mvT<N, T>(B->D, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Vc[xl + i] = q[i];
+      }
+    __syncthreads();
+    // 5. y-derivative pair, accumulated
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          q[i] = Uc[yl + i * LN];
+        mv<N, T>(B->D, q, r);
+        const T f = c1 * wa * wb;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] *= f * B->w[i];
+        mvT<N, T>(B->D, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Vc[yl + i * LN] += q[i];
+      }
+    __syncthreads();
+    // 6. add the z part, integrate along z
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Vc[zl + i * PL] + vz[i];
+        mvT<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Vc[zl + i * PL] = q[i];
+      }
+    __syncthreads();
+    // 7. along y
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Vc[yl + i * LN];
+        mvT<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Vc[yl + i * LN] = q[i];
+      }
+    __syncthreads();
+    // 8. along x, scatter-add (distribute_local_to_global_compressed,
+    //    vector_access_reduced.h:255-505)
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Vc[xl + i];
+        mvT<N, T>(B->S, r, q);
+        scatter_add_line<P, T>(dst, L, q);
+      }
+  }
+
+  // diagonal of the cell matrix (local_compute_diagonal, laplace_operator.h:770-800).  For the
+  // affine constant-coefficient tensor the unit-vector applications collapse to
+  //   d_i = c0 a[ix] m[iy] m[iz] + c1 m[ix] a[iy] m[iz] + c2 m[ix] m[iy] a[iz]
+  // with a[i] = sum_q w_q (dphi_i(x_q))^2, m[i] = sum_q w_q phi_i(x_q)^2.
+  template <typename T>
+  struct Diag1D
+  {
+    T a[kMaxN], m[kMaxN];
+  };
+
+  template <int P, typename T>
+  __global__ void __launch_bounds__(256)
+    cell_diagonal_kernel(T *__restrict__ diag, const uint32_t *__restrict__ idx27, uint32_t n_cells,
+                         Diag1D<T> d1, T c0, T c1, T c2)
+  {
+    constexpr int  N    = P + 1;
+    const uint32_t gid  = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cell = gid / (N * N);
+    if (cell >= n_cells)
+      return;
+    const int t = gid % (N * N), j = t % N, k = t / N;
+    T         r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      r[i] = c0 * d1.a[i] * d1.m[j] * d1.m[k] + c1 * d1.m[i] * d1.a[j] * d1.m[k] +
+             c2 * d1.m[i] * d1.m[j] * d1.a[k];
+    const LineIndex<P> L = line_index<P>(idx27, cell, j, k);
+    scatter_add_line<P, T>(diag, L, r);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Transfers (MGTransferMatrixFree restated): one workgroup per parent
+  // cell; the (p+1)^3 coarse values are interpolated to the (2p+1)^3 points of the children
+  // patch by three LDS-staged sweeps with P1.
+  // ------------------------------------------------------------------------------------------
+  template <int P>
+  struct TCfg
+  {
+    static constexpr int N       = P + 1;
+    static constexpr int M       = 2 * P + 1;
+    static constexpr int THREADS = ((M * M + 63) / 64) * 64 > 1024 ? 1024 : ((M * M + 63) / 64) * 64;
+  };
+
+  template <int P>
+  __device__ __forceinline__ int patch_code(int a)
+  {
+    return a == 0 ? 0 : (a == 2 * P ? 2 : 1);
+  }
+
+  template <int P, typename T>
+  __global__ void __launch_bounds__(TCfg<P>::THREADS)
+    prolongate_kernel(T *__restrict__ fine, const T *__restrict__ coarse, const uint32_t *__restrict__ idx_c,
+                      const uint32_t *__restrict__ idx_f, const uint32_t *__restrict__ children,
+                      const uint8_t *__restrict__ wshift, uint32_t n_parents, const Basis1D<T> *__restrict__ B,
+                      int add)
+  {
+    constexpr int N = P + 1, M = 2 * P + 1;
+    __shared__ T  p1[M * N];
+    __shared__ T  in[N * N * N];
+    __shared__ T  t1[N * N * M];
+    __shared__ T  t2[N * M * M];
+    __shared__ T  out[M * M * M];
+    const uint32_t pc = blockIdx.x;
+    if (pc >= n_parents)
+      return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < M * N; i += nt)
+      p1[i] = B->P1[i];
+    for (int t = tid; t < N * N; t += nt)
+      {
+        const int    j = t % N, k = t / N;
+        T            r[N];
+        LineIndex<P> L = line_index<P>(idx_c, pc, j, k);
+        gather_line<P, T>(coarse, L, r);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          in[(k * N + j) * N + i] = r[i];
+      }
+    __syncthreads();
+    for (int o = tid; o < N * N * M; o += nt) // x: [k][j][a]
+      {
+        const int a = o % M, kj = o / M;
+        T         s = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          s = fma(p1[a * N + i], in[kj * N + i], s);
+        t1[o] = s;
+      }
+    __syncthreads();
+    for (int o = tid; o < N * M * M; o += nt) // y: [k][b][a]
+      {
+        const int a = o % M, b = (o / M) % M, k = o / (M * M);
+        T         s = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          s = fma(p1[b * N + j], t1[(k * N + j) * M + a], s);
+        t2[o] = s;
+      }
+    __syncthreads();
+    for (int o = tid; o < M * M * M; o += nt) // z: [c][b][a]
+      {
+        const int ba = o % (M * M), c = o / (M * M);
+        T         s = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          s = fma(p1[c * N + k], t2[k * M * M + ba], s);
+        out[o] = s;
+      }
+    __syncthreads();
+    // distribute to the 8 children
+    for (int w = tid; w < 8 * N * N; w += nt)
+      {
+        const int      ch = w / (N * N), t = w % (N * N), j = t % N, k = t / N;
+        const uint32_t fc = children[8u * (size_t)pc + ch];
+        const int      ox = (ch & 1) * P, oy = ((ch >> 1) & 1) * P, oz = (ch >> 2) * P;
+        const int      b = oy + j, c = oz + k;
+        LineIndex<P>   L = line_index<P>(idx_f, fc, j, k);
+        T              r[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = out[(c * M + b) * M + ox + i];
+        if (!add)
+          {
+            // overwrite: every child stores all its values; DoFs shared between children or
+            // parents receive bitwise identical values from each of them
+            if (L.b0 != kInvalid)
+              fine[L.b0 + L.off] = r[0];
+            if (L.b1 != kInvalid)
+              {
+#pragma unroll
+                for (int i = 0; i < P - 1; ++i)
+                  fine[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i] = r[1 + i];
+              }
+            if (L.b2 != kInvalid)
+              fine[L.b2 + L.off] = r[P];
+          }
+        else
+          {
+            // add: a patch point is distributed once per parent (by the first child holding
+            // it), weighted with 1/(number of parent patches sharing it)
+            const bool line_dup = (((ch >> 1) & 1) && j == 0) || ((ch >> 2) && k == 0);
+            if (line_dup)
+              continue;
+            const uint8_t *ws = wshift + 27u * (size_t)pc + 9 * patch_code<P>(c) + 3 * patch_code<P>(b);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              {
+                const int sh = ws[patch_code<P>(ox + i)];
+                r[i] *= T(1) / T(1 << sh);
+              }
+            // i == 0 of an x-upper child duplicates i == p of its sibling
+            if (L.b0 != kInvalid && !(ch & 1))
+              unsafeAtomicAdd(&fine[L.b0 + L.off], r[0]);
+            if (L.b1 != kInvalid)
+              {
+#pragma unroll
+                for (int i = 0; i < P - 1; ++i)
+                  unsafeAtomicAdd(&fine[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i], r[1 + i]);
+              }
+            if (L.b2 != kInvalid)
+              unsafeAtomicAdd(&fine[L.b2 + L.off], r[P]);
+          }
+      }
+  }
+
+  template <int P, typename T>
+  __global__ void __launch_bounds__(TCfg<P>::THREADS)
+    restrict_kernel(T *__restrict__ coarse, const T *__restrict__ fine, const uint32_t *__restrict__ idx_c,
+                    const uint32_t *__restrict__ idx_f, const uint32_t *__restrict__ children,
+                    const uint8_t *__restrict__ wshift, uint32_t n_parents, const Basis1D<T> *__restrict__ B)
+  {
+    constexpr int N = P + 1, M = 2 * P + 1;
+    __shared__ T  p1[M * N];
+    __shared__ T  in[N * N * N];
+    __shared__ T  t1[N * N * M];
+    __shared__ T  t2[N * M * M];
+    __shared__ T  out[M * M * M];
+    const uint32_t pc = blockIdx.x;
+    if (pc >= n_parents)
+      return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < M * N; i += nt)
+      p1[i] = B->P1[i];
+    // gather the weighted fine patch (shared points are written with identical values by the
+    // children that hold them)
+    for (int w = tid; w < 8 * N * N; w += nt)
+      {
+        const int      ch = w / (N * N), t = w % (N * N), j = t % N, k = t / N;
+        const uint32_t fc = children[8u * (size_t)pc + ch];
+        const int      ox = (ch & 1) * P, oy = ((ch >> 1) & 1) * P, oz = (ch >> 2) * P;
+        const int      b = oy + j, c = oz + k;
+        LineIndex<P>   L = line_index<P>(idx_f, fc, j, k);
+        T              r[N];
+        gather_line<P, T>(fine, L, r);
+        const uint8_t *ws = wshift + 27u * (size_t)pc + 9 * patch_code<P>(c) + 3 * patch_code<P>(b);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          {
+            const int sh               = ws[patch_code<P>(ox + i)];
+            out[(c * M + b) * M + ox + i] = r[i] * (T(1) / T(1 << sh));
+          }
+      }
+    __syncthreads();
+    for (int o = tid; o < N * M * M; o += nt) // z^T: [k][b][a]
+      {
+        const int ba = o % (M * M), k = o / (M * M);
+        T         s = 0;
+#pragma unroll
+        for (int c = 0; c < M; ++c)
+          s = fma(p1[c * N + k], out[c * M * M + ba], s);
+        t2[o] = s;
+      }
+    __syncthreads();
+    for (int o = tid; o < N * N * M; o += nt) // y^T: [k][j][a]
+      {
+        const int a = o % M, j = (o / M) % N, k = o / (M * N);
+        T         s = 0;
+#pragma unroll
+        for (int b = 0; b < M; ++b)
+          s = fma(p1[b * N + j], t2[(k * M + b) * M + a], s);
+        t1[o] = s;
+      }
+    __syncthreads();
+    for (int o = tid; o < N * N * N; o += nt) // x^T: [k][j][i]
+      {
+        const int i = o % N, kj = o / N;
+        T         s = 0;
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+          s = fma(p1[a * N + i], t1[kj * M + a], s);
+        in[o] = s;
+      }
+    __syncthreads();
+    for (int t = tid; t < N * N; t += nt)
+      {
+        const int    j = t % N, k = t / N;
+        LineIndex<P> L = line_index<P>(idx_c, pc, j, k);
+        T            r[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = in[(k * N + j) * N + i];
+        scatter_add_line<P, T>(coarse, L, r);
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // launchers
+  // ------------------------------------------------------------------------------------------
+#define MGX_DISPATCH_P(p, ...)                 \
+  switch (p)                                   \
+    {                                          \
+      case 1: { constexpr int P = 1; __VA_ARGS__; } break; \
+      case 2: { constexpr int P = 2; __VA_ARGS__; } break; \
+      case 3: { constexpr int P = 3; __VA_ARGS__; } break; \
+      case 4: { constexpr int P = 4; __VA_ARGS__; } break; \
+      case 5: { constexpr int P = 5; __VA_ARGS__; } break; \
+      case 6: { constexpr int P = 6; __VA_ARGS__; } break; \
+      case 7: { constexpr int P = 7; __VA_ARGS__; } break; \
+      case 8: { constexpr int P = 8; __VA_ARGS__; } break; \
+      case 9: { constexpr int P = 9; __VA_ARGS__; } break; \
+      default: break;                          \
+    }
+
+  template <int P, typename T>
+  static void cell_loop_t(hipStream_t s, const OperatorData &op, void *dst, const void *src)
+  {
+    using C            = Cfg<P>;
+    const uint32_t nb  = (op.n_cells + C::CPB - 1) / C::CPB;
+    hipLaunchKernelGGL((cell_loop_kernel<P, T>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                       op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
+                       (T)op.coef[2]);
+  }
+
+  void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src)
+  {
+    if (op.number == 1)
+      {
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, dst, src));
+      }
+    else
+      {
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src));
+      }
+  }
+
+  template <int P, typename T>
+  static void cell_diag_t(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m)
+  {
+    constexpr int N = P + 1;
+    Diag1D<T>     d1;
+    for (int i = 0; i < N; ++i)
+      {
+        d1.a[i] = (T)a[i];
+        d1.m[i] = (T)m[i];
+      }
+    const uint64_t nthreads = (uint64_t)op.n_cells * N * N;
+    const uint32_t nb       = (uint32_t)((nthreads + 255) / 256);
+    hipLaunchKernelGGL((cell_diagonal_kernel<P, T>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, op.n_cells,
+                       d1, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2]);
+  }
+
+  void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m)
+  {
+    if (op.number == 1)
+      {
+        MGX_DISPATCH_P(op.p, cell_diag_t<P, double>(s, op, diag, a, m));
+      }
+    else
+      {
+        MGX_DISPATCH_P(op.p, cell_diag_t<P, float>(s, op, diag, a, m));
+      }
+  }
+
+  template <int P, typename T>
+  static void prolongate_t(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
+                           bool with_constraints)
+  {
+    const OperatorData &c = *t.coarse, &f = *t.fine;
+    const uint32_t     *idx_c = with_constraints ? c.idx27 : c.idx27_plain;
+    hipLaunchKernelGGL((prolongate_kernel<P, T>), dim3(c.n_cells), dim3(TCfg<P>::THREADS), 0, s, (T *)fine,
+                       (const T *)coarse, idx_c, f.idx27_plain, t.children, t.weight_shift, c.n_cells,
+                       (const Basis1D<T> *)c.basis, add ? 1 : 0);
+  }
+
+  void launch_prolongate(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
+                         bool with_constraints)
+  {
+    if (t.coarse->number == 1)
+      {
+        MGX_DISPATCH_P(t.coarse->p, prolongate_t<P, double>(s, t, fine, coarse, add, with_constraints));
+      }
+    else
+      {
+        MGX_DISPATCH_P(t.coarse->p, prolongate_t<P, float>(s, t, fine, coarse, add, with_constraints));
+      }
+  }
+
+  template <int P, typename T>
+  static void restrict_t(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
+                         bool with_constraints)
+  {
+    const OperatorData &c = *t.coarse, &f = *t.fine;
+    const uint32_t     *idx_c = with_constraints ? c.idx27 : c.idx27_plain;
+    hipLaunchKernelGGL((restrict_kernel<P, T>), dim3(c.n_cells), dim3(TCfg<P>::THREADS), 0, s, (T *)coarse,
+                       (const T *)fine, idx_c, f.idx27_plain, t.children, t.weight_shift, c.n_cells,
+                       (const Basis1D<T> *)c.basis);
+  }
+
+  void launch_restrict_add(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
+                           bool with_constraints)
+  {
+    if (t.coarse->number == 1)
+      {
+        MGX_DISPATCH_P(t.coarse->p, restrict_t<P, double>(s, t, coarse, fine, with_constraints));
+      }
+    else
+      {
+        MGX_DISPATCH_P(t.coarse->p, restrict_t<P, float>(s, t, coarse, fine, with_constraints));
+      }
+  }
+} // namespace mgx

@@ -1,0 +1,363 @@
+// mgx_vector.hip -- vector kernels of the multigrid driver (SURVEY.md 8a row U and the
+// PreconditionChebyshev / SolverCG vector updates).  All are streaming, HBM-bound kernels:
+// grid-stride loops over a grid capped at 256 CUs x 8 workgroups, one element per lane and
+// iteration (fp64: 512 B per wave instruction).
+#include "mgx_internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace mgx
+{
+  static inline dim3 stream_grid(size_t n)
+  {
+    size_t nb = (n + 255) / 256;
+    if (nb > 2048)
+      nb = 2048;
+    if (nb < 1)
+      nb = 1;
+    return dim3((unsigned)nb);
+  }
+
+#define GRID_STRIDE(i, n) \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+  template <typename TD, typename TS>
+  __global__ void __launch_bounds__(256) k_copy_cast(TD *__restrict__ dst, const TS *__restrict__ src, size_t n)
+  {
+    GRID_STRIDE(i, n) dst[i] = (TD)src[i];
+  }
+
+  template <typename TD, typename TS>
+  __global__ void __launch_bounds__(256) k_add_cast(TD *__restrict__ dst, const TS *__restrict__ src, size_t n)
+  {
+    GRID_STRIDE(i, n) dst[i] += (TD)src[i];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256) k_sadd(T *__restrict__ x, T sx, T a, const T *__restrict__ v, size_t n)
+  {
+    GRID_STRIDE(i, n) x[i] = sx * x[i] + a * v[i];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256) k_rhs_minus(T *__restrict__ res, const T *__restrict__ rhs, size_t n)
+  {
+    GRID_STRIDE(i, n) res[i] = rhs[i] - res[i];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_constrained_copy(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ list,
+                       uint32_t count)
+  {
+    GRID_STRIDE(i, count)
+    {
+      const uint32_t c = list[i];
+      dst[c]           = src[c];
+    }
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_constrained_residual(T *__restrict__ res, const T *__restrict__ rhs, const T *__restrict__ lhs,
+                           const uint32_t *__restrict__ list, uint32_t count)
+  {
+    GRID_STRIDE(i, count)
+    {
+      const uint32_t c = list[i];
+      res[c]           = rhs[c] - lhs[c];
+    }
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_constrained_set(T *__restrict__ v, T value, const uint32_t *__restrict__ list, uint32_t count)
+  {
+    GRID_STRIDE(i, count) v[list[i]] = value;
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256) k_invert(T *__restrict__ v, size_t n)
+  {
+    GRID_STRIDE(i, n) v[i] = T(1) / v[i];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_scatter_values(T *__restrict__ v, const uint32_t *__restrict__ idx, const double *__restrict__ val,
+                     uint32_t count)
+  {
+    GRID_STRIDE(i, count) v[idx[i]] = (T)val[i];
+  }
+
+  template <typename T, int MODE>
+  __global__ void __launch_bounds__(256)
+    k_cheb_update(T *__restrict__ x, T *__restrict__ x_old, const T *__restrict__ b, const T *__restrict__ t,
+                  const T *__restrict__ dinv, T f1, T f2, size_t n)
+  {
+    GRID_STRIDE(i, n)
+    {
+      if (MODE == 0)
+        {
+          x_old[i] = T(0);
+          x[i]     = f2 * dinv[i] * b[i];
+        }
+      else
+        {
+          const T xi = x[i];
+          T       xn = xi + f2 * dinv[i] * (b[i] - t[i]);
+          if (MODE == 2)
+            xn += f1 * (xi - x_old[i]);
+          x_old[i] = xi;
+          x[i]     = xn;
+        }
+    }
+  }
+
+  // ---- reductions: deterministic two-stage sum (block partials, then one block) ----
+  __device__ __forceinline__ double wave_sum(double v)
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      v += __shfl_down(v, o, 64);
+    return v;
+  }
+
+  __device__ __forceinline__ double block_sum(double v)
+  {
+    __shared__ double ws[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0)
+      ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0)
+      r = ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+    return r;
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_dot_partial(const T *__restrict__ x, const T *__restrict__ y, size_t n, double *__restrict__ partial)
+  {
+    double s = 0;
+    GRID_STRIDE(i, n) s += (double)x[i] * (double)y[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = s;
+  }
+
+  __global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__ partial, int count,
+                                                        double *__restrict__ result)
+  {
+    double s = 0;
+    for (int i = threadIdx.x; i < count; i += 256)
+      s += partial[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      *result = s;
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_cg_update(T *__restrict__ x, T *__restrict__ r, const T *__restrict__ d, const T *__restrict__ h, T alpha,
+                size_t n, double *__restrict__ partial)
+  {
+    double s = 0;
+    GRID_STRIDE(i, n)
+    {
+      x[i] += alpha * d[i];
+      const T ri = r[i] - alpha * h[i];
+      r[i]       = ri;
+      s += (double)ri * (double)ri;
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = s;
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256) k_xpby(T *__restrict__ d, const T *__restrict__ z, T beta, size_t n)
+  {
+    GRID_STRIDE(i, n) d[i] = z[i] + beta * d[i];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_jacobi_dot(T *__restrict__ z, const T *__restrict__ dinv, const T *__restrict__ r, size_t n,
+                 double *__restrict__ partial)
+  {
+    double s = 0;
+    GRID_STRIDE(i, n)
+    {
+      const T zi = dinv[i] * r[i];
+      z[i]       = zi;
+      s += (double)r[i] * (double)zi;
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = s;
+  }
+
+  static inline dim3 reduce_grid(size_t n)
+  {
+    size_t nb = (n + 255) / 256;
+    if (nb > (size_t)kDotBlocks)
+      nb = kDotBlocks;
+    if (nb < 1)
+      nb = 1;
+    return dim3((unsigned)nb);
+  }
+
+#define BY_NUMBER(number, ...)    \
+  if ((number) == 1)              \
+    {                             \
+      using T = double;           \
+      __VA_ARGS__;                \
+    }                             \
+  else                            \
+    {                             \
+      using T = float;            \
+      __VA_ARGS__;                \
+    }
+
+  void launch_copy_cast(hipStream_t s, void *dst, int dn, const void *src, int sn, size_t n)
+  {
+    if (n == 0)
+      return;
+    const dim3 g = stream_grid(n);
+    if (dn == 1 && sn == 1)
+      hipLaunchKernelGGL((k_copy_cast<double, double>), g, dim3(256), 0, s, (double *)dst, (const double *)src, n);
+    else if (dn == 1 && sn == 0)
+      hipLaunchKernelGGL((k_copy_cast<double, float>), g, dim3(256), 0, s, (double *)dst, (const float *)src, n);
+    else if (dn == 0 && sn == 1)
+      hipLaunchKernelGGL((k_copy_cast<float, double>), g, dim3(256), 0, s, (float *)dst, (const double *)src, n);
+    else
+      hipLaunchKernelGGL((k_copy_cast<float, float>), g, dim3(256), 0, s, (float *)dst, (const float *)src, n);
+  }
+
+  void launch_add_cast(hipStream_t s, void *dst, int dn, const void *src, int sn, size_t n)
+  {
+    if (n == 0)
+      return;
+    const dim3 g = stream_grid(n);
+    if (dn == 1 && sn == 1)
+      hipLaunchKernelGGL((k_add_cast<double, double>), g, dim3(256), 0, s, (double *)dst, (const double *)src, n);
+    else if (dn == 1 && sn == 0)
+      hipLaunchKernelGGL((k_add_cast<double, float>), g, dim3(256), 0, s, (double *)dst, (const float *)src, n);
+    else if (dn == 0 && sn == 1)
+      hipLaunchKernelGGL((k_add_cast<float, double>), g, dim3(256), 0, s, (float *)dst, (const double *)src, n);
+    else
+      hipLaunchKernelGGL((k_add_cast<float, float>), g, dim3(256), 0, s, (float *)dst, (const float *)src, n);
+  }
+
+  void launch_sadd(hipStream_t s, int number, void *x, double sx, double a, const void *v, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_sadd<T>), stream_grid(n), dim3(256), 0, s, (T *)x, (T)sx, (T)a,
+                                         (const T *)v, n));
+  }
+
+  void launch_rhs_minus(hipStream_t s, int number, void *res, const void *rhs, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number,
+              hipLaunchKernelGGL((k_rhs_minus<T>), stream_grid(n), dim3(256), 0, s, (T *)res, (const T *)rhs, n));
+  }
+
+  void launch_constrained_copy(hipStream_t s, int number, void *dst, const void *src, const uint32_t *list,
+                               uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_constrained_copy<T>), stream_grid(count), dim3(256), 0, s, (T *)dst,
+                                         (const T *)src, list, count));
+  }
+
+  void launch_constrained_residual(hipStream_t s, int number, void *res, const void *rhs, const void *lhs,
+                                   const uint32_t *list, uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_constrained_residual<T>), stream_grid(count), dim3(256), 0, s,
+                                         (T *)res, (const T *)rhs, (const T *)lhs, list, count));
+  }
+
+  void launch_constrained_set(hipStream_t s, int number, void *v, double value, const uint32_t *list,
+                              uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_constrained_set<T>), stream_grid(count), dim3(256), 0, s, (T *)v,
+                                         (T)value, list, count));
+  }
+
+  void launch_invert(hipStream_t s, int number, void *v, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_invert<T>), stream_grid(n), dim3(256), 0, s, (T *)v, n));
+  }
+
+  void launch_scatter_values(hipStream_t s, int number, void *v, const uint32_t *idx_dev, const double *val_dev,
+                             uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_scatter_values<T>), stream_grid(count), dim3(256), 0, s, (T *)v,
+                                         idx_dev, val_dev, count));
+  }
+
+  void launch_cheb_update(hipStream_t s, int number, int mode, void *x, void *x_old, const void *b,
+                          const void *t, const void *dinv, double f1, double f2, size_t n)
+  {
+    if (n == 0)
+      return;
+    const dim3 g = stream_grid(n);
+    BY_NUMBER(
+      number, if (mode == 0) hipLaunchKernelGGL((k_cheb_update<T, 0>), g, dim3(256), 0, s, (T *)x, (T *)x_old,
+                                                (const T *)b, (const T *)t, (const T *)dinv, (T)f1, (T)f2, n);
+      else if (mode == 1) hipLaunchKernelGGL((k_cheb_update<T, 1>), g, dim3(256), 0, s, (T *)x, (T *)x_old,
+                                             (const T *)b, (const T *)t, (const T *)dinv, (T)f1, (T)f2, n);
+      else hipLaunchKernelGGL((k_cheb_update<T, 2>), g, dim3(256), 0, s, (T *)x, (T *)x_old, (const T *)b,
+                              (const T *)t, (const T *)dinv, (T)f1, (T)f2, n));
+  }
+
+  void launch_dot(hipStream_t s, int number, const void *x, const void *y, size_t n, double *partial_dev,
+                  double *result_dev)
+  {
+    const dim3 g = reduce_grid(n);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_dot_partial<T>), g, dim3(256), 0, s, (const T *)x, (const T *)y, n,
+                                         partial_dev));
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+
+  void launch_cg_update(hipStream_t s, int number, void *x, void *r, const void *d, const void *h, double alpha,
+                        size_t n, double *partial_dev, double *result_dev)
+  {
+    const dim3 g = reduce_grid(n);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_cg_update<T>), g, dim3(256), 0, s, (T *)x, (T *)r, (const T *)d,
+                                         (const T *)h, (T)alpha, n, partial_dev));
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+
+  void launch_xpby(hipStream_t s, int number, void *d, const void *z, double beta, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number,
+              hipLaunchKernelGGL((k_xpby<T>), stream_grid(n), dim3(256), 0, s, (T *)d, (const T *)z, (T)beta, n));
+  }
+
+  void launch_jacobi_dot(hipStream_t s, int number, void *z, const void *dinv, const void *r, size_t n,
+                         double *partial_dev, double *result_dev)
+  {
+    const dim3 g = reduce_grid(n);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_jacobi_dot<T>), g, dim3(256), 0, s, (T *)z, (const T *)dinv,
+                                         (const T *)r, n, partial_dev));
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+} // namespace mgx

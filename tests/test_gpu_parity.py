@@ -1,0 +1,231 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/mgx.h) against the CPU oracle on the
+same inputs.  Tolerances (fp64): the arithmetic is the same sum-factorisation in a different
+summation order (thread-tile sweeps, atomic scatter-add order), so agreement is at round-off
+level: 1e-12 relative to the max-norm for one operator application, 1e-9 for composite cycles
+(SURVEY.md 8a/BASELINE.md 3).  fp32 V-cycle: 2e-4."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+mg = pytest.importorskip("multigrid_amd")
+from oracle import Oracle  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mg.Context(0)
+    yield c
+    c.close()
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+CASES = [(1, 2, 1), (2, 1, 2), (3, 1, 2), (4, 1, 2), (4, 3, 1), (5, 1, 1), (6, 1, 1), (7, 1, 1), (8, 1, 1),
+         (9, 1, 1)]
+
+
+@pytest.mark.parametrize("p,ns,nr", CASES)
+def test_vmult_and_residual(ctx, p, ns, nr):
+    cube = mg.Cube(p, ns, nr)
+    orc = Oracle(p, ns, nr)
+    for l in range(cube.n_levels):
+        op = mg.LaplaceOperator.from_cube(ctx, cube, l)
+        x = cube.seeded_vector(l, 1)
+        b = cube.seeded_vector(l, 2)
+        src, rhs, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=b), ctx.vector(x.size)
+        op.vmult(dst, src)
+        assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+        op.vmult_residual(rhs, src, dst)
+        assert rel(dst.download(), orc.vmult_residual(l, b, x)) < 1e-12
+        op.compute_diagonal()
+        assert rel(op.get_matrix_diagonal_inverse().download(), orc.inv_diag(l)) < 1e-13
+        op.clear()
+    cube.close()
+    orc.close()
+
+
+def test_operator_from_foreign_tables(ctx):
+    """Drop-in scenario: tables come from the caller (here: the oracle's own arrays), not from
+    mgx_cube."""
+    p = 4
+    orc = Oracle(p, 1, 2)
+    l = 2
+    idx = np.ascontiguousarray(orc.idx27(l)).ravel()
+    plain = np.ascontiguousarray(orc.idx27_plain(l)).ravel()
+    cons = orc.constrained(l)
+    S, D, w = orc.shape_values().ravel(), orc.colloc_grad().ravel(), orc.qweights()
+    d = mg._lib.OperatorDesc()
+    d.degree, d.number, d.n_cells, d.n_dofs = p, mg.F64, orc.n_cells(l), orc.n_dofs(l)
+    d.idx27 = idx.ctypes.data_as(mg._lib.u32p)
+    d.idx27_plain = plain.ctypes.data_as(mg._lib.u32p)
+    d.constrained = cons.ctypes.data_as(mg._lib.u32p)
+    d.n_constrained = cons.size
+    h = orc.cell_size(l)
+    for i, v in enumerate([h, h, h, 0, 0, 0]):
+        d.coef[i] = v
+    d.shape_values = S.ctypes.data_as(mg._lib.f64p)
+    d.colloc_grad = D.ctypes.data_as(mg._lib.f64p)
+    d.qweights = w.ctypes.data_as(mg._lib.f64p)
+    op = mg.LaplaceOperator(ctx, d)
+    x = np.random.default_rng(3).uniform(-1, 1, orc.n_dofs(l))
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    op.vmult(dst, src)
+    assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+    op.clear()
+
+
+def test_error_paths(ctx):
+    cube = mg.Cube(3, 1, 1)
+    d = cube.operator_desc(1)
+    bad = cube.idx27(1).copy().ravel()
+    bad[5] = cube.n_dofs(1) + 7  # out of range compressed index must be refused on the host
+    d.idx27 = bad.ctypes.data_as(mg._lib.u32p)
+    with pytest.raises(mg.MgxError):
+        mg.LaplaceOperator(ctx, d)
+    op = mg.LaplaceOperator.from_cube(ctx, cube, 1)
+    v = op.initialize_dof_vector()
+    with pytest.raises(mg.MgxError):
+        op.vmult(v, v)  # aliasing refused (laplace_operator.h:573-601 needs distinct vectors)
+    d2 = cube.operator_desc(1)
+    d2.coef[3] = 0.1
+    with pytest.raises(mg.MgxError):
+        mg.LaplaceOperator(ctx, d2)
+    op.clear()
+    cube.close()
+
+
+@pytest.mark.parametrize("p,ns,nr", [(2, 1, 2), (4, 1, 2), (4, 3, 1), (7, 1, 1)])
+def test_chebyshev(ctx, p, ns, nr):
+    cube = mg.Cube(p, ns, nr)
+    orc = Oracle(p, ns, nr, degree=3)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    for l in range(cube.n_levels):
+        sm = solver.smoother(l)
+        gi, oi = sm.info(), orc.cheb_info(l)
+        assert gi["degree"] == oi["degree"] and gi["cg_its"] == oi["cg_its"]
+        for k in ("lambda_max", "theta", "delta"):
+            assert gi[k] == pytest.approx(oi[k], rel=1e-8)
+        b = cube.seeded_vector(l, 7)
+        bd, xd = ctx.vector(b.size, data=b), ctx.vector(b.size)
+        sm.vmult(xd, bd)
+        x_ref = orc.cheb_vmult(l, b)
+        assert rel(xd.download(), x_ref) < 1e-10
+        sm.step(xd, bd)
+        assert rel(xd.download(), orc.cheb_step(l, x_ref, b)) < 1e-10
+    solver.close()
+    cube.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("p,ns,nr", [(1, 2, 1), (2, 1, 2), (4, 1, 2), (4, 3, 1), (8, 1, 1)])
+def test_transfers(ctx, p, ns, nr):
+    cube = mg.Cube(p, ns, nr)
+    orc = Oracle(p, ns, nr)
+    ops = [mg.LaplaceOperator.from_cube(ctx, cube, l) for l in range(cube.n_levels)]
+    for l in range(1, cube.n_levels):
+        tr = mg.Transfer(ops[l - 1], ops[l], cube.children(l), cube.prolong_1d())
+        xc = cube.seeded_vector(l - 1, 11)
+        xf = cube.seeded_vector(l, 12)
+        dc, df = ctx.vector(xc.size, data=xc), ctx.vector(xf.size, data=xf)
+        out = ctx.vector(xf.size, data=np.full(xf.size, 7.0))
+        tr.prolongate(out, dc, with_constraints=False)  # overwrite
+        assert rel(out.download(), orc.prolongate(l, xc, with_bc=False)) < 1e-13
+        out.upload(xf)
+        tr.prolongate_and_add(out, dc, with_constraints=True)
+        assert rel(out.download(), orc.prolongate(l, xc, fine=xf, with_bc=True)) < 1e-13
+        outc = ctx.vector(xc.size, data=xc)
+        tr.restrict_and_add(outc, df, with_constraints=True)
+        assert rel(outc.download(), orc.restrict_and_add(l, xc, xf, with_bc=True)) < 1e-13
+        outc.upload(xc)
+        tr.restrict_and_add(outc, df, with_constraints=False)
+        assert rel(outc.download(), orc.restrict_and_add(l, xc, xf, with_bc=False)) < 1e-13
+        tr.clear()
+    for o in ops:
+        o.clear()
+    cube.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("p,ns,nr,degree,ncyc", [(4, 1, 3, 3, 1), (4, 1, 3, 3, 2), (4, 3, 1, 2, 1), (2, 1, 3, 3, 1),
+                                                  (8, 1, 2, 3, 1), (4, 1, 0, 3, 1)])
+def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
+    cube = mg.Cube(p, ns, nr)
+    orc = Oracle(p, ns, nr, degree=degree, n_cycles=ncyc)
+    solver = mg.MultigridSolver(ctx, cube, degree, degree, ncyc, mg.F64)
+    lmax = cube.max_level
+    x = cube.seeded_vector(lmax, 5)
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    solver.vmult(dst, src)  # MultigridSolver::vmult = one V-cycle
+    assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    rate, trace = solver.solve(True)
+    orate, otrace = orc.solve(True)
+    if nr > 0:
+        assert rate == pytest.approx(orate, rel=1e-6)
+        np.testing.assert_allclose(trace[1:, 0], otrace[1:, 1], rtol=1e-9)  # residual start
+        np.testing.assert_allclose(trace[1:, 1], otrace[1:, 2], rtol=1e-6)  # residual end
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-8)
+    assert rel(solver.get_solution().download(), orc.solution(lmax)) < 1e-9
+    its, red = solver.solve_cg()
+    oits, ored = orc.solve_cg()
+    assert its == oits
+    assert red == pytest.approx(ored, rel=1e-5)
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-8)
+    solver.close()
+    cube.close()
+    orc.close()
+
+
+def test_readme_known_answers_on_gpu(ctx):
+    """README.md:143 (512 cells): the GPU path itself reproduces the reference's printed numbers."""
+    cube = mg.Cube(4, 1, 3)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 2, mg.F32)  # README run: fp32 V-cycle, 2 cycles
+    rate, _ = solver.solve(True)
+    assert rate == pytest.approx(1.319e-01, rel=0.10)
+    assert solver.compute_l2_error() == pytest.approx(4.037e-04, rel=0.05)
+    its, red = solver.solve_cg()
+    assert its == 8
+    assert red == pytest.approx(6.689e-02, rel=0.05)
+    assert solver.compute_l2_error() == pytest.approx(3.822e-04, rel=0.01)
+    solver.close()
+    cube.close()
+
+
+def test_mixed_precision_vcycle(ctx):
+    cube = mg.Cube(4, 1, 3)
+    orc = Oracle(4, 1, 3, degree=3, n_cycles=1, vfloat=True)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32)
+    lmax = cube.max_level
+    x = cube.seeded_vector(lmax, 5)
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    solver.vmult(dst, src)
+    assert rel(dst.download(), orc.vcycle(x)) < 2e-4
+    solver.solve(False)
+    orc.solve(False)
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-4)
+    solver.close()
+    cube.close()
+    orc.close()
+
+
+def test_vector_kernels(ctx):
+    rng = np.random.default_rng(9)
+    n = 100003
+    a, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    da, db = ctx.vector(n, data=a), ctx.vector(n, data=b)
+    assert ctx.dot(da, db) == pytest.approx(np.dot(a, b), rel=1e-12)
+    assert ctx.l2_norm(da) == pytest.approx(np.linalg.norm(a), rel=1e-13)
+    lib = ctx.lib
+    mg.check(lib.mgx_sadd(ctx.h, mg.F64, da.ptr, -1.0, 1.0, db.ptr, n))
+    np.testing.assert_array_equal(da.download(), -a + b)
+    f = ctx.vector(n, mg.F32)
+    mg.check(lib.mgx_copy_cast(ctx.h, f.ptr, mg.F32, db.ptr, mg.F64, n))
+    np.testing.assert_array_equal(f.download(), b.astype(np.float32))
+    mg.check(lib.mgx_add_cast(ctx.h, db.ptr, mg.F64, f.ptr, mg.F32, n))
+    np.testing.assert_array_equal(db.download(), b + b.astype(np.float32).astype(np.float64))
+    z = ctx.vector(0)
+    assert ctx.dot(z, z) == 0.0  # empty input

@@ -1,0 +1,119 @@
+"""CPU-side checks of the product's host logic and of the C-ABI library (no compute calls, no GPU):
+libmgx.so loads, exports every symbol include/*.h declares, fails loudly without a device, and the
+host-side cube provider (mgx_cube) agrees with the oracle's independently written tables."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "multigrid_amd", "libmgx.so")):
+        g.build()
+    from multigrid_amd import _lib
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    from multigrid_amd import _lib
+    declared = set()
+    for hdr in ("mgx.h", "mgx_cube.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(mgx_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) > 60
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libmgx.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "python binding lacks %s" % name
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device the product refuses to run (this container has none); on the GPU box
+    the context is created."""
+    import multigrid_amd as mg
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mg.MgxError) as e:
+        mg.Context(0)
+    assert e.value.status == -2  # MGX_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing in the product tree may reference it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "multigrid_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(base, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()
+
+
+@pytest.mark.parametrize("p,ns,nr", [(1, 2, 2), (2, 1, 2), (4, 1, 3), (4, 3, 1), (5, 3, 1), (8, 1, 1), (9, 1, 1)])
+def test_cube_provider_matches_oracle(lib, p, ns, nr):
+    import multigrid_amd as mg
+    c = mg.Cube(p, ns, nr)
+    o = Oracle(p, ns, nr)
+    assert c.n_levels == o.n_levels
+    for l in range(c.n_levels):
+        assert c.n_dofs(l) == (c.cells_per_dim(l) * p + 1) ** 3
+        assert np.array_equal(c.idx27(l), o.idx27(l))
+        assert np.array_equal(c.idx27_plain(l), o.idx27_plain(l))
+        assert np.array_equal(c.dof_grid(l), o.dof_grid(l))
+        assert np.array_equal(c.constrained(l), o.constrained(l))
+        assert np.array_equal(c.cell_coords(l), o.cell_coords(l))
+        np.testing.assert_allclose(c.rhs(l), o.rhs(l), rtol=1e-12, atol=1e-14)
+        bi, bv = c.bc(l)
+        oi, ov = o.bc(l)
+        order = np.argsort(oi)
+        assert np.array_equal(bi, oi[order])
+        np.testing.assert_allclose(bv, ov[order], rtol=1e-14)
+        if l > 0:
+            ch = c.children(l)
+            cc, cf = c.cell_coords(l - 1), c.cell_coords(l)
+            for k in range(8):  # child k = x + 2y + 4z of its parent
+                off = np.array([k & 1, (k >> 1) & 1, k >> 2])
+                assert np.array_equal(cf[ch[:, k]], 2 * cc + off)
+    np.testing.assert_allclose(c.shape_values(), o.shape_values(), atol=1e-15)
+    np.testing.assert_allclose(c.colloc_grad(), o.colloc_grad(), atol=1e-13)
+    np.testing.assert_allclose(c.qweights(), o.qweights(), atol=1e-16)
+    np.testing.assert_allclose(c.prolong_1d(), o.prolong_1d(), atol=1e-15)
+    # L2 error functional agrees on an arbitrary vector
+    l = c.max_level
+    v = c.seeded_vector(l, 3)
+    assert c.l2_error(l, v) > 0
+    c.close()
+    o.close()
+
+
+def test_seeded_vector_is_numbering_independent(lib):
+    import multigrid_amd as mg
+    c = mg.Cube(3, 1, 2)
+    v = c.seeded_vector(2, 42)
+    g = c.dof_grid(2)
+    assert v.min() >= -1 and v.max() < 1 and abs(v.mean()) < 0.05
+    lex = np.empty_like(v)
+    lex[g] = v
+    c2 = mg.Cube(3, 1, 2)
+    lex2 = np.empty_like(v)
+    lex2[c2.dof_grid(2)] = c2.seeded_vector(2, 42)
+    assert np.array_equal(lex, lex2)
+    c.close()
+    c2.close()
+
+
+def test_invalid_arguments(lib):
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.mgx_cube_create(0, 1, 1, C.byref(h)) == -1
+    assert lib.mgx_cube_create(4, 1, 12, C.byref(h)) != 0
+    assert lib.mgx_cube_create(9, 3, 8, C.byref(h)) == -4  # 32-bit DoF index overflow refused
