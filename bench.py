@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the matrix-free multigrid Laplace path on MI355X.
+
+Metric (BASELINE.json): DoFs/s for the fp64 Laplace matvec + V-cycle of poisson_cube, FE_Q(4).
+One *step* = the two operator applications one PCG iteration of the reference performs on the
+finest level (multigrid_solver.h:483-510): one fp64 `LaplaceOperator::vmult` (matrix_dp) followed
+by one fp64 V-cycle (`MultigridSolver::vmult`: Chebyshev(3) pre/post smoothing, residual,
+restriction, coarse solve, prolongation).  `value` = global DoFs / time per step; the matvec-only
+and V-cycle-only rates are reported next to it (`matvec_dofs_per_s`, `vcycle_dofs_per_s`).
+
+N = 1: BASELINE config 1 -- 128^3 cells, 135 005 697 DoFs, one MI355X, inputs resident in HBM.
+N > 1: see DESIGN.md "multi-GPU": one process per GPU.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--cells 128] [--degree 4]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cells", type=int, default=128, help="cells per direction of the finest level")
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--smoother-degree", type=int, default=3)
+    ap.add_argument("--vcycle-number", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=32, help="finest level of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def split_size(cells):
+    """poisson_cube/program.cc:532-539: strip factors of two -> (n_subdiv, n_refine)"""
+    n_subdiv, n_refine = cells, 0
+    if n_subdiv > 1:
+        while n_subdiv % 2 == 0:
+            n_refine += 1
+            n_subdiv //= 2
+    return n_subdiv, n_refine
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample of
+    the same workload: same element/algorithm on a smaller finest level (DoFs/s of a matrix-free
+    operator is size independent once out of cache)."""
+    from oracle import Oracle
+    ns, nr = split_size(args.cpu_cells)
+    t0 = time.time()
+    orc = Oracle(args.degree, ns, nr, degree=args.smoother_degree, n_cycles=1, vfloat=False)
+    n = orc.n_dofs(orc.max_level)
+    orc.time_vmult(orc.max_level, 1)  # warm-up
+    n_mv = 10
+    t_mv = orc.time_vmult(orc.max_level, n_mv) / n_mv
+    orc.time_vcycle(1)
+    n_vc = 3
+    t_vc = orc.time_vcycle(n_vc) / n_vc
+    threads = orc.num_threads()
+    orc.close()
+    return {
+        "value": n / (t_mv + t_vc), "unit": "DoFs/s", "cores": threads, "kind": "port",
+        "sample": "FE_Q(%d) %d^3 cells (%d DoFs): %d fp64 matvecs + %d fp64 V-cycles of the oracle "
+                  "(oracle/mg_oracle.c, OpenMP), %.1f s incl. setup" % (args.degree, args.cpu_cells, n, n_mv, n_vc,
+                                                                        time.time() - t0),
+        "matvec_dofs_per_s": n / t_mv, "vcycle_dofs_per_s": n / t_vc,
+        "reference_readme_12c_broadwell": {"matvec_dofs_per_s": 8.74e8, "vcycle_mixed_precision_dofs_per_s": 9.7e7},
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+
+    import multigrid_amd as mg
+
+    ctx = mg.Context(local_rank)
+    ns, nr = split_size(args.cells)
+    t_setup = time.time()
+    cube = mg.Cube(args.degree, ns, nr)
+    vnum = mg.F64 if args.vcycle_number == "f64" else mg.F32
+    solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum)
+    lmax = cube.max_level
+    n_dofs = cube.n_dofs(lmax)
+    # inputs resident in HBM: seeded vector for the matvec, rhs as V-cycle defect
+    x = ctx.vector(n_dofs, data=cube.seeded_vector(lmax, 42))
+    y = ctx.vector(n_dofs)
+    rhs = solver.get_vector(lmax, "rhs")
+    z = ctx.vector(n_dofs)
+    A = solver.matrix_dp(lmax)
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def step():
+        A.vmult(y, x)          # LaplaceOperator::vmult, fp64
+        solver.vmult(z, rhs)   # MultigridSolver::vmult = one V-cycle
+
+    for _ in range(args.warmup):
+        step()
+    # ---- the timed region: exactly K steps, bracketed by barrier + synchronize ----
+    A.set_profiled(True)
+    if vnum == mg.F64:
+        solver.matrix(lmax).set_profiled(True)
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.profile_read()
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # secondary figures (outside the timed region): matvec-only and V-cycle-only
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps
+
+    t_mv = timed(lambda: A.vmult(y, x), 20)
+    t_vc = timed(lambda: solver.vmult(z, rhs), 5)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    total_dofs = n_dofs * world
+    # dominant kernel: the finest-level fp64 cell loop; algorithmic bytes = 16 B/DoF (read src once,
+    # write dst once) x DoFs of one launch
+    avg_kernel_ms = kernel_ms / max(launches, 1)
+    achieved = 16.0 * n_dofs / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+    out = {
+        "metric": "DoFs/s for Laplace matvec + V-cycle, poisson_cube p=%d fp64" % args.degree,
+        "value": total_dofs / (elapsed / args.steps),
+        "unit": "DoFs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if vnum == mg.F64 else "f64 outer / f32 V-cycle", "data": "synthetic",
+        "config": {"workload": "poisson_cube FE_Q(%d) %d^3 cells, %d DoFs per GPU, %d levels, "
+                               "step = 1 fp64 vmult + 1 V-cycle (Chebyshev degree %d)" %
+                               (args.degree, args.cells, n_dofs, cube.n_levels, args.smoother_degree),
+                   "cells_per_dim": args.cells, "degree": args.degree, "n_dofs_per_gpu": n_dofs,
+                   "parallelism": "1 GPU" if world == 1 else "%d independent replicas (no halo exchange yet)" % world},
+        "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
+        "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
+        "roofline": {"bound": "hbm", "kernel": "mgx::cell_loop_kernel<%d,double> (finest level)" % args.degree,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "launches": launches, "avg_launch_ms": avg_kernel_ms,
+                     "algorithmic_bytes_per_launch": 16.0 * n_dofs},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    solver.close()
+    cube.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

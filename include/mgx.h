@@ -62,6 +62,13 @@ int mgx_sync(mgx_context_t ctx);
 /* raw HIP stream (hipStream_t) the context enqueues on, for callers that time with HIP events */
 void *mgx_context_stream(mgx_context_t ctx);
 
+/* ---- instrumentation (the reference brackets its phases with LIKWID markers,
+ * poisson_cube/program.cc:281-296,347-354; here: HIP events on the context's stream around every
+ * launch of the cell-loop kernel of the operators flagged with mgx_operator_set_profiled) ---- */
+int mgx_profile_enable(mgx_context_t ctx, int enable);
+/* synchronises, returns the number of bracketed launches and their summed duration, resets */
+int mgx_profile_read(mgx_context_t ctx, uint64_t *launches, double *total_ms);
+
 /* ---- device vectors (LinearAlgebra::distributed::Vector<number> storage) ---- */
 int mgx_malloc(mgx_context_t ctx, void **dptr, size_t bytes);
 int mgx_free(mgx_context_t ctx, void *dptr);
@@ -118,6 +125,7 @@ typedef struct
 int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_operator_t *op);
 int mgx_operator_destroy(mgx_operator_t op);
 uint32_t mgx_operator_n_dofs(mgx_operator_t op); /* Base::m() */
+int mgx_operator_set_profiled(mgx_operator_t op, int profiled);
 int mgx_operator_number(mgx_operator_t op);
 /* LaplaceOperator::vmult(dst, src) laplace_operator.h:573-601 */
 int mgx_vmult(mgx_operator_t op, void *dst, const void *src);

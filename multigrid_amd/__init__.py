@@ -38,6 +38,15 @@ class Context:
     def stream(self):
         return self.lib.mgx_context_stream(self.h)
 
+    def profile_enable(self, on=True):
+        check(self.lib.mgx_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        """(number of bracketed cell-loop launches, their summed duration in ms); resets"""
+        n, ms = C.c_uint64(), C.c_double()
+        check(self.lib.mgx_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mgx_context_destroy(self.h)
@@ -224,6 +233,9 @@ class LaplaceOperator:
 
     def m(self):
         return self.lib.mgx_operator_n_dofs(self.h)
+
+    def set_profiled(self, on=True):
+        check(self.lib.mgx_operator_set_profiled(self.h, int(on)))
 
     def initialize_dof_vector(self):
         return DeviceVector(self.ctx, self.m(), self.number)

@@ -11,9 +11,11 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace mgx;
@@ -56,6 +58,24 @@ namespace
   while (0)
 
   inline size_t number_size(int number) { return number == MGX_F64 ? 8 : 4; }
+
+  // MGX_TRACE=1 prints the host-side control flow to stderr (debugging aid)
+  bool trace_on()
+  {
+    static const bool on = std::getenv("MGX_TRACE") != nullptr;
+    return on;
+  }
+#define MGX_TRACE(...)                  \
+  do                                    \
+    {                                   \
+      if (trace_on())                   \
+        {                               \
+          std::fprintf(stderr, "[mgx] " __VA_ARGS__); \
+          std::fputc('\n', stderr);     \
+          std::fflush(stderr);          \
+        }                               \
+    }                                   \
+  while (0)
 } // namespace
 
 struct mgx_context_s
@@ -65,6 +85,9 @@ struct mgx_context_s
   double     *partial_dev = nullptr; // kDotBlocks block partials
   double     *result_dev  = nullptr; // 4 scalars
   double     *result_host = nullptr; // pinned
+  // cell-loop launch profiling (mgx_profile_*)
+  bool                                        profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_used;
 };
 
 struct mgx_operator_s
@@ -73,6 +96,7 @@ struct mgx_operator_s
   OperatorData  d;
   double        S[kMaxN * kMaxN], D[kMaxN * kMaxN], w[kMaxN];
   bool          has_diag = false;
+  bool          profiled = false;
 };
 
 struct mgx_smoother_s
@@ -119,6 +143,33 @@ namespace
   {
     launch_dot(ctx->stream, number, x, y, n, ctx->partial_dev, ctx->result_dev);
     return read_result(ctx, out);
+  }
+
+  // cell loop with optional HIP-event bracket
+  int run_cell_loop(mgx_operator_t op, void *dst, const void *src)
+  {
+    mgx_context_t ctx = op->ctx;
+    if (ctx->profile && op->profiled)
+      {
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (ctx->ev_pool.empty())
+          {
+            MGX_HIP(hipEventCreate(&ev.first));
+            MGX_HIP(hipEventCreate(&ev.second));
+          }
+        else
+          {
+            ev = ctx->ev_pool.back();
+            ctx->ev_pool.pop_back();
+          }
+        MGX_HIP(hipEventRecord(ev.first, ctx->stream));
+        launch_cell_loop(ctx->stream, op->d, dst, src);
+        MGX_HIP(hipEventRecord(ev.second, ctx->stream));
+        ctx->ev_used.push_back(ev);
+      }
+    else
+      launch_cell_loop(ctx->stream, op->d, dst, src);
+    return MGX_OK;
   }
 
   struct Stopwatch
@@ -226,6 +277,12 @@ int mgx_context_destroy(mgx_context_t ctx)
   (void)hipFree(ctx->partial_dev);
   (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
+  for (auto *pool : {&ctx->ev_pool, &ctx->ev_used})
+    for (auto &ev : *pool)
+      {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+      }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MGX_OK;
@@ -239,6 +296,31 @@ int mgx_sync(mgx_context_t ctx)
 }
 
 void *mgx_context_stream(mgx_context_t ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int mgx_profile_enable(mgx_context_t ctx, int enable)
+{
+  MGX_REQUIRE(ctx, "mgx_profile_enable: null context");
+  ctx->profile = enable != 0;
+  return MGX_OK;
+}
+
+int mgx_profile_read(mgx_context_t ctx, uint64_t *launches, double *total_ms)
+{
+  MGX_REQUIRE(ctx && launches && total_ms, "mgx_profile_read: null argument");
+  MGX_HIP(hipStreamSynchronize(ctx->stream));
+  double sum = 0;
+  for (auto &ev : ctx->ev_used)
+    {
+      float ms = 0;
+      MGX_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+      sum += ms;
+      ctx->ev_pool.push_back(ev);
+    }
+  *launches = ctx->ev_used.size();
+  *total_ms = sum;
+  ctx->ev_used.clear();
+  return MGX_OK;
+}
 
 int mgx_malloc(mgx_context_t ctx, void **dptr, size_t bytes)
 {
@@ -457,6 +539,13 @@ int mgx_operator_destroy(mgx_operator_t op)
 }
 
 uint32_t mgx_operator_n_dofs(mgx_operator_t op) { return op ? op->d.n_dofs : 0; }
+
+int mgx_operator_set_profiled(mgx_operator_t op, int profiled)
+{
+  MGX_REQUIRE(op, "mgx_operator_set_profiled: null operator");
+  op->profiled = profiled != 0;
+  return MGX_OK;
+}
 int      mgx_operator_number(mgx_operator_t op) { return op ? op->d.number : -1; }
 
 int mgx_vmult(mgx_operator_t op, void *dst, const void *src)
@@ -466,7 +555,7 @@ int mgx_vmult(mgx_operator_t op, void *dst, const void *src)
   hipStream_t s = op->ctx->stream;
   // "zero dst within the loop" (laplace_operator.h:590)
   MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
-  launch_cell_loop(s, op->d, dst, src);
+  MGX_TRY(run_cell_loop(op, dst, src));
   // dst[c] = src[c] on constrained rows (:592-593)
   launch_constrained_copy(s, op->d.number, dst, src, op->d.constrained, op->d.n_constrained);
   MGX_HIP(hipGetLastError());
@@ -479,7 +568,7 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
   MGX_REQUIRE(res != lhs && res != rhs, "mgx_vmult_residual: residual must not alias rhs/lhs");
   hipStream_t s = op->ctx->stream;
   MGX_HIP(hipMemsetAsync(res, 0, number_size(op->d.number) * op->d.n_dofs, s)); // :617-623
-  launch_cell_loop(s, op->d, res, lhs);
+  MGX_TRY(run_cell_loop(op, res, lhs));
   launch_rhs_minus(s, op->d.number, res, rhs, op->d.n_dofs); // :624-631
   // res[c] -= lhs[c] on constrained rows (:632-633); the loop never touches them
   launch_constrained_residual(s, op->d.number, res, rhs, lhs, op->d.constrained, op->d.n_constrained);
@@ -571,6 +660,7 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
   MGX_TRY(dot(ctx, num, r, r, n, &res));
   res    = std::sqrt(res);
   int it = 0;
+  MGX_TRACE("smoother_create: n=%zu eig_its=%d res0=%g", n, eig_cg_n_iterations, res);
   while (it < eig_cg_n_iterations && res > 1e-10) // IterationNumberControl(n_its, 1e-10)
     {
       ++it;
@@ -625,6 +715,7 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
       const double eps          = smoothing_range;
       degree = 1 + (int)(std::log(1. / eps + std::sqrt(1. / eps / eps - 1.)) / std::log(1. / sigma));
     }
+  MGX_TRACE("smoother_create: its=%d lambda=[%g,%g] degree=%d", it, info.lambda_min, info.lambda_max, degree);
   info.degree = degree;
   info.delta  = (info.lambda_max - a) * 0.5;
   info.theta  = (info.lambda_max + a) * 0.5;
@@ -707,6 +798,7 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   for (size_t i = 0; i < 8 * (size_t)npar; ++i)
     if (desc->children[i] >= fine->d.n_cells)
       return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_transfer_create: child index out of range");
+  MGX_TRACE("transfer_create: parents=%u", npar);
   auto tr    = std::make_unique<mgx_transfer_s>();
   tr->coarse = coarse;
   tr->fine   = fine;
@@ -828,6 +920,7 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
               "mgx_solver_create: incomplete descriptor");
   MGX_REQUIRE(desc->n_levels == 1 || (desc->transfer && desc->transfer_dp), "mgx_solver_create: missing transfers");
   MGX_REQUIRE(desc->degree_pre >= 1 && desc->n_cycles >= 1, "mgx_solver_create: bad smoother degree / cycle count");
+  MGX_TRACE("solver_create: n_levels=%d", desc->n_levels);
   auto S      = std::unique_ptr<mgx_solver_s, int (*)(mgx_solver_t)>(new mgx_solver_s, mgx_solver_destroy);
   S->ctx      = ctx;
   S->n_levels = desc->n_levels;
@@ -856,23 +949,23 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
       double      *p = nullptr;
       void        *q = nullptr;
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
-      MGX_HIP(hipMemset(p, 0, 8 * n));
+      MGX_HIP(hipMemsetAsync(p, 0, 8 * n, ctx->stream));
       S->solution.push_back(p);
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
       MGX_HIP(hipMemcpy(p, desc->rhs[l], 8 * n, hipMemcpyHostToDevice));
       S->rhs.push_back(p);
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
-      MGX_HIP(hipMemset(p, 0, 8 * n));
+      MGX_HIP(hipMemsetAsync(p, 0, 8 * n, ctx->stream));
       S->residual.push_back(p);
       const size_t vb = number_size(S->vnumber) * n;
       MGX_HIP(hipMalloc(&q, vb));
-      MGX_HIP(hipMemset(q, 0, vb));
+      MGX_HIP(hipMemsetAsync(q, 0, vb, ctx->stream));
       S->defect.push_back(q);
       MGX_HIP(hipMalloc(&q, vb));
-      MGX_HIP(hipMemset(q, 0, vb));
+      MGX_HIP(hipMemsetAsync(q, 0, vb, ctx->stream));
       S->t.push_back(q);
       MGX_HIP(hipMalloc(&q, vb));
-      MGX_HIP(hipMemset(q, 0, vb));
+      MGX_HIP(hipMemsetAsync(q, 0, vb, ctx->stream));
       S->solution_update.push_back(q);
       // inhomogeneous boundary values (multigrid_solver.h:225-253)
       const uint32_t nb = desc->bc_count[l];
@@ -882,7 +975,7 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
       MGX_HIP(hipMalloc((void **)&bi, sizeof(uint32_t) * (nb + 1)));
       MGX_HIP(hipMalloc((void **)&bv, sizeof(double) * (nb + 1)));
       MGX_HIP(hipMalloc((void **)&bz, sizeof(double) * (nb + 1)));
-      MGX_HIP(hipMemset(bz, 0, sizeof(double) * (nb + 1)));
+      MGX_HIP(hipMemsetAsync(bz, 0, sizeof(double) * (nb + 1), ctx->stream));
       if (nb)
         {
           MGX_REQUIRE(desc->bc_index && desc->bc_value && desc->bc_index[l] && desc->bc_value[l],

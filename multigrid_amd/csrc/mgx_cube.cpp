@@ -4,8 +4,13 @@
 // mgx.h.
 #include "../../include/mgx_cube.h"
 
+#include <omp.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -446,7 +451,31 @@ namespace
     }
   }
 
-  thread_local std::string g_cube_error;
+  // threads the host really grants: min(affinity mask, cgroup CPU quota) unless OMP_NUM_THREADS
+  // is set (a GPU box hands a small CPU share of a large machine to each job)
+  int effective_threads()
+  {
+    const char *env = std::getenv("OMP_NUM_THREADS");
+    if (env && std::atoi(env) > 0)
+      return std::atoi(env);
+    int       n = omp_get_num_procs();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+      n = CPU_COUNT(&set);
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))
+      {
+        char   quota[64];
+        double period = 0;
+        if (std::fscanf(f, "%63s %lf", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+          {
+            const int q = (int)(std::atof(quota) / period + 0.5);
+            if (q >= 1 && q < n)
+              n = q;
+          }
+        std::fclose(f);
+      }
+    return std::max(1, n);
+  }
 } // namespace
 
 extern "C" {
@@ -458,6 +487,7 @@ int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *out)
   const uint64_t N = (uint64_t)n_subdiv << n_refine;
   if ((N * degree + 1) * (N * degree + 1) * (N * degree + 1) >= 0xFFFFFFFFull || N > 1023)
     return MGX_ERR_UNSUPPORTED; // 32-bit DoF indices as in the reference's compressed table
+  omp_set_num_threads(effective_threads());
   auto C      = std::make_unique<mgx_cube_s>();
   C->p        = degree;
   C->n_subdiv = n_subdiv;

@@ -35,6 +35,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # many small parallel regions: sleeping waiters behave far better than spinning ones when the
+    # host grants fewer CPUs than it shows (GPU boxes hand out a cgroup share)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     build()
     L = C.CDLL(_LIB_PATH)
     vp = C.c_void_p

@@ -12,6 +12,9 @@
  * deal.II parts (FEEvaluation, PreconditionChebyshev, MGTransferMatrixFree, SolverCG) are not
  * vendored; they are restated from SURVEY.md 8a rows E, R, S, T / Appendix D.
  */
+#ifndef _GNU_SOURCE
+#  define _GNU_SOURCE /* sched_getaffinity / CPU_COUNT */
+#endif
 #include "mg_oracle.h"
 
 #include <math.h>
@@ -22,6 +25,7 @@
 #ifdef _OPENMP
 #  include <omp.h>
 #endif
+#include <sched.h>
 
 #ifndef M_PI
 #  define M_PI 3.14159265358979323846
@@ -498,8 +502,45 @@ static void set_bc(const orc_problem *P, int level, double *v, int zero)
     v[P->bc_idx[level][i]] = zero ? 0. : P->bc_val[level][i];
 }
 
+/* Number of threads the host actually grants this process: the smaller of the affinity mask and
+ * the cgroup CPU quota (a GPU box hands a 16-CPU share of a much larger machine to one job; one
+ * OpenMP thread per *visible* core would oversubscribe it by an order of magnitude). */
+static int effective_threads(void)
+{
+  int n = 1;
+#ifdef _OPENMP
+  const char *env = getenv("OMP_NUM_THREADS");
+  if (env && atoi(env) > 0)
+    return atoi(env);
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0)
+    n = CPU_COUNT(&set);
+  else
+    n = omp_get_num_procs();
+  FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f)
+    {
+      char   quota[64];
+      double period = 0;
+      if (fscanf(f, "%63s %lf", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+        {
+          const int q = (int)(atof(quota) / period + 0.5);
+          if (q >= 1 && q < n)
+            n = q;
+        }
+      fclose(f);
+    }
+  if (n < 1)
+    n = 1;
+#endif
+  return n;
+}
+
 orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cycles, int vfloat)
 {
+#ifdef _OPENMP
+  omp_set_num_threads(effective_threads());
+#endif
   if (p < 1 || p > 9 || n_subdiv < 1 || n_refine < 0)
     return NULL;
   /* the 27-entry compressed path is what the reference uses for fe_degree > 2
