@@ -812,16 +812,19 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
     std::vector<uint32_t> idxf(27 * (size_t)fine->d.n_cells);
     MGX_HIP(hipMemcpy(idxf.data(), fine->d.idx27_plain, sizeof(uint32_t) * idxf.size(), hipMemcpyDeviceToHost));
     std::vector<uint8_t> cnt(fine->d.n_dofs, 0);
-    auto                 rep = [&](uint32_t pc, int e) {
+    // representative fine DoF of patch entity e = (ca,cb,cc): a child vertex lying in it (low
+    // patch face: child 0's low vertex; patch interior: the mid plane = child 0's high vertex;
+    // high patch face: child 1's high vertex) -- vertices carry exactly one DoF for every p
+    auto rep = [&](uint32_t pc, int e) {
       const int      ca = e % 3, cb = (e / 3) % 3, cc = e / 9;
       const int      ch = (ca == 2) | ((cb == 2) << 1) | ((cc == 2) << 2);
       const uint32_t fc = desc->children[8 * (size_t)pc + ch];
-      return idxf[27 * (size_t)fc + 9 * cc + 3 * cb + ca];
+      return idxf[27 * (size_t)fc + 9 * (cc ? 2 : 0) + 3 * (cb ? 2 : 0) + (ca ? 2 : 0)];
     };
     for (uint32_t pc = 0; pc < npar; ++pc)
       for (int e = 0; e < 27; ++e)
         cnt[rep(pc, e)]++;
-    std::vector<uint8_t> shift(27 * (size_t)npar);
+    std::vector<uint8_t> shift(27 * (size_t)npar, 0);
     for (uint32_t pc = 0; pc < npar; ++pc)
       for (int e = 0; e < 27; ++e)
         {

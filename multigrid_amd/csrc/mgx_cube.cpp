@@ -618,12 +618,16 @@ int mgx_cube_solver_destroy(mgx_cube_solver *s)
   if (!s)
     return MGX_OK;
   mgx_solver_destroy(s->solver);
+  // transfers reference their level operators: release them first
   for (int l = 0; l < s->n_levels; ++l)
     {
       if (s->transfer && s->transfer_dp && s->transfer_dp[l] != s->transfer[l])
         mgx_transfer_destroy(s->transfer_dp[l]);
       if (s->transfer)
         mgx_transfer_destroy(s->transfer[l]);
+    }
+  for (int l = 0; l < s->n_levels; ++l)
+    {
       if (s->matrix && s->matrix_dp && s->matrix_dp[l] != s->matrix[l])
         mgx_operator_destroy(s->matrix_dp[l]);
       if (s->matrix)
