@@ -119,6 +119,12 @@ typedef struct
   const double *shape_values;
   const double *colloc_grad;
   const double *qweights;
+  /* Optional scheduling hint, may be NULL.  If cells [64k, 64k+64) form 4x4x4 bricks in Morton
+   * order (two uniform refinements of a common ancestor -- what p4est/deal.II produce), the
+   * library runs its atomic-free brick cell loop; brick_colour[k] (n_cells/64 entries, < 32) is
+   * a colouring in which bricks that share DoFs differ.  Without the hint a greedy colouring is
+   * computed; the brick structure itself is always verified against idx27. */
+  const uint8_t *brick_colour;
 } mgx_operator_desc;
 
 /* LaplaceOperator::initialize + evaluate_coefficient (laplace_operator.h:184-220, 357-432) */

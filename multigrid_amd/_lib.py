@@ -21,7 +21,8 @@ f64p = C.POINTER(C.c_double)
 class OperatorDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("number", C.c_int), ("n_cells", C.c_uint32), ("n_dofs", C.c_uint32),
                 ("idx27", u32p), ("idx27_plain", u32p), ("constrained", u32p), ("n_constrained", C.c_uint32),
-                ("coef", C.c_double * 6), ("shape_values", f64p), ("colloc_grad", f64p), ("qweights", f64p)]
+                ("coef", C.c_double * 6), ("shape_values", f64p), ("colloc_grad", f64p), ("qweights", f64p),
+                ("brick_colour", C.POINTER(C.c_uint8))]
 
 
 class SmootherInfo(C.Structure):

@@ -3,6 +3,7 @@
 // HIP kernels.  Reference citations (file:line) are relative to the reference root; deal.II
 // semantics follow SURVEY.md 8a rows R, S, T and Appendix D.
 #include "../../include/mgx.h"
+#include "mgx_bricks.hpp"
 #include "mgx_internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -145,30 +146,56 @@ namespace
     return read_result(ctx, out);
   }
 
-  // cell loop with optional HIP-event bracket
-  int run_cell_loop(mgx_operator_t op, void *dst, const void *src)
+  // HIP-event bracket around the cell loop of a profiled operator
+  struct ProfileBracket
   {
-    mgx_context_t ctx = op->ctx;
-    if (ctx->profile && op->profiled)
-      {
-        std::pair<hipEvent_t, hipEvent_t> ev;
-        if (ctx->ev_pool.empty())
-          {
-            MGX_HIP(hipEventCreate(&ev.first));
-            MGX_HIP(hipEventCreate(&ev.second));
-          }
-        else
-          {
-            ev = ctx->ev_pool.back();
-            ctx->ev_pool.pop_back();
-          }
-        MGX_HIP(hipEventRecord(ev.first, ctx->stream));
-        launch_cell_loop(ctx->stream, op->d, dst, src);
-        MGX_HIP(hipEventRecord(ev.second, ctx->stream));
-        ctx->ev_used.push_back(ev);
-      }
+    mgx_context_t ctx;
+    bool          on;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    ProfileBracket(mgx_operator_t op)
+      : ctx(op->ctx)
+      , on(op->ctx->profile && op->profiled)
+    {
+      if (!on)
+        return;
+      if (ctx->ev_pool.empty())
+        {
+          if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+            {
+              on = false;
+              return;
+            }
+        }
+      else
+        {
+          ev = ctx->ev_pool.back();
+          ctx->ev_pool.pop_back();
+        }
+      (void)hipEventRecord(ev.first, ctx->stream);
+    }
+    ~ProfileBracket()
+    {
+      if (on)
+        {
+          (void)hipEventRecord(ev.second, ctx->stream);
+          ctx->ev_used.push_back(ev);
+        }
+    }
+  };
+
+  // dst = A src on the unconstrained rows (constrained rows untouched)
+  int apply_plain(mgx_operator_t op, void *dst, const void *src)
+  {
+    hipStream_t    s = op->ctx->stream;
+    ProfileBracket pb(op);
+    if (op->d.bricks.available())
+      launch_brick_loop(s, op->d, 0, src, nullptr, nullptr, dst, dst, 0., 0.);
     else
-      launch_cell_loop(ctx->stream, op->d, dst, src);
+      {
+        // "zero dst within the loop" (laplace_operator.h:590)
+        MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
+        launch_cell_loop(s, op->d, dst, src);
+      }
     return MGX_OK;
   }
 
@@ -520,6 +547,29 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       MGX_HIP(hipMemcpy(d.basis, &b, sizeof(b), hipMemcpyHostToDevice));
     }
   MGX_HIP(hipMalloc(&d.inv_diag, number_size(d.number) * d.n_dofs));
+  // brick schedule for the atomic-free cell loop (mgx_brick.hip); MGX_NO_BRICKS=1 keeps the
+  // per-cell kernel (A/B measurements)
+  if (!std::getenv("MGX_NO_BRICKS"))
+    {
+      BrickHost   bh;
+      std::string why;
+      if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour, bh, why))
+        {
+          BrickData &b = d.bricks;
+          b.n_bricks   = bh.n_bricks;
+          b.n_colours  = bh.n_colours;
+          for (int c = 0; c <= bh.n_colours; ++c)
+            b.colour_start[c] = bh.colour_start[c];
+          MGX_HIP(hipMalloc((void **)&b.ent_base, sizeof(uint32_t) * bh.ent_base.size()));
+          MGX_HIP(hipMemcpy(b.ent_base, bh.ent_base.data(), sizeof(uint32_t) * bh.ent_base.size(),
+                            hipMemcpyHostToDevice));
+          MGX_HIP(hipMalloc((void **)&b.ent_flags, bh.ent_flags.size()));
+          MGX_HIP(hipMemcpy(b.ent_flags, bh.ent_flags.data(), bh.ent_flags.size(), hipMemcpyHostToDevice));
+          MGX_TRACE("operator_create: %u bricks, %d colours", b.n_bricks, b.n_colours);
+        }
+      else
+        MGX_TRACE("operator_create: per-cell kernel (%s)", why.c_str());
+    }
   *out = op.release();
   return MGX_OK;
 }
@@ -534,6 +584,8 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.constrained);
   (void)hipFree(op->d.basis);
   (void)hipFree(op->d.inv_diag);
+  (void)hipFree(op->d.bricks.ent_base);
+  (void)hipFree(op->d.bricks.ent_flags);
   delete op;
   return MGX_OK;
 }
@@ -553,9 +605,7 @@ int mgx_vmult(mgx_operator_t op, void *dst, const void *src)
   MGX_REQUIRE(op && dst && src, "mgx_vmult: null argument");
   MGX_REQUIRE(dst != src, "mgx_vmult: dst and src must not alias (laplace_operator.h:573-601)");
   hipStream_t s = op->ctx->stream;
-  // "zero dst within the loop" (laplace_operator.h:590)
-  MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
-  MGX_TRY(run_cell_loop(op, dst, src));
+  MGX_TRY(apply_plain(op, dst, src));
   // dst[c] = src[c] on constrained rows (:592-593)
   launch_constrained_copy(s, op->d.number, dst, src, op->d.constrained, op->d.n_constrained);
   MGX_HIP(hipGetLastError());
@@ -567,9 +617,17 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
   MGX_REQUIRE(op && rhs && lhs && res, "mgx_vmult_residual: null argument");
   MGX_REQUIRE(res != lhs && res != rhs, "mgx_vmult_residual: residual must not alias rhs/lhs");
   hipStream_t s = op->ctx->stream;
-  MGX_HIP(hipMemsetAsync(res, 0, number_size(op->d.number) * op->d.n_dofs, s)); // :617-623
-  MGX_TRY(run_cell_loop(op, res, lhs));
-  launch_rhs_minus(s, op->d.number, res, rhs, op->d.n_dofs); // :624-631
+  if (op->d.bricks.available())
+    {
+      // zeroing (:617-623) and rhs - A lhs (:624-631) are fused into the brick loop
+      ProfileBracket pb(op);
+      launch_brick_loop(s, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0.);
+    }
+  else
+    {
+      MGX_TRY(apply_plain(op, res, lhs));
+      launch_rhs_minus(s, op->d.number, res, rhs, op->d.n_dofs); // :624-631
+    }
   // res[c] -= lhs[c] on constrained rows (:632-633); the loop never touches them
   launch_constrained_residual(s, op->d.number, res, rhs, lhs, op->d.constrained, op->d.n_constrained);
   MGX_HIP(hipGetLastError());
@@ -741,6 +799,7 @@ int mgx_smoother_get_info(mgx_smoother_t sm, mgx_smoother_info *info)
   return MGX_OK;
 }
 
+// legacy path (levels without a brick schedule): matvec into tmp, then an elementwise update
 static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 {
   const mgx_smoother_info &I = sm->info;
@@ -760,23 +819,96 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
   return MGX_OK;
 }
 
+// One fused Chebyshev iteration on a brick-scheduled level (the counterpart of
+// LaplaceOperator::vmult(dst, src, before, after), laplace_operator.h:723-741, with
+// PreconditionChebyshev's update as the after-operation):
+//   out <- cur + f1 (cur - out) + f2 D^-1 (b - A cur);  mode 2 general, 3 without the f1 term,
+//   4 with out == 0 on entry.  sm->tmp carries the partial sums of brick-surface DoFs.
+static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, void *out, const void *b, double f1,
+                                double f2)
+{
+  mgx_operator_t op = sm->op;
+  hipStream_t    s  = op->ctx->stream;
+  {
+    ProfileBracket pb(op);
+    launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2);
+  }
+  launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
+                          op->d.n_constrained);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+// vmult (zero start) / step (nonzero start).  *px is the iterate; with allow_swap the result may
+// be handed back in the smoother's second buffer (pointer swap instead of a copy, as deal.II
+// swaps solution and solution_old).
+static int smoother_apply(mgx_smoother_t sm, void **px, const void *b, bool is_step, bool allow_swap)
+{
+  const mgx_smoother_info &I  = sm->info;
+  mgx_operator_t           op = sm->op;
+  hipStream_t              s  = op->ctx->stream;
+  const int                num = op->d.number;
+  const size_t             n   = op->d.n_dofs;
+  void                    *x   = *px;
+  if (!op->d.bricks.available())
+    {
+      if (is_step)
+        {
+          MGX_TRY(mgx_vmult(op, sm->tmp, x));
+          launch_cheb_update(s, num, 1, x, sm->x_old, b, sm->tmp, op->d.inv_diag, 0., 1. / I.theta, n);
+        }
+      else
+        launch_cheb_update(s, num, 0, x, sm->x_old, b, nullptr, op->d.inv_diag, 0., 1. / I.theta, n);
+      return cheb_loop(sm, x, b);
+    }
+  void *cur = x, *other = sm->x_old;
+  bool  other_is_zero = false;
+  if (is_step)
+    {
+      MGX_TRY(cheb_fused_iteration(sm, 3, cur, other, b, 0., 1. / I.theta));
+      std::swap(cur, other);
+    }
+  else
+    {
+      launch_cheb_init(s, num, cur, b, op->d.inv_diag, 1. / I.theta, n);
+      other_is_zero = true; // x_0 = 0
+    }
+  if (I.degree >= 2 && std::fabs(I.delta) >= 1e-40)
+    {
+      double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+      for (int k = 0; k < I.degree - 1; ++k)
+        {
+          const double rhokp = 1. / (2. * sigma - rhok);
+          const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
+          rhok = rhokp;
+          MGX_TRY(cheb_fused_iteration(sm, other_is_zero ? 4 : 2, cur, other, b, f1, f2));
+          other_is_zero = false;
+          std::swap(cur, other);
+        }
+    }
+  if (cur != x)
+    {
+      if (allow_swap)
+        {
+          sm->x_old = x;
+          *px       = cur;
+        }
+      else
+        launch_copy_cast(s, x, num, cur, num, n);
+    }
+  return MGX_OK;
+}
+
 int mgx_smoother_vmult(mgx_smoother_t sm, void *x, const void *b)
 {
   MGX_REQUIRE(sm && x && b && x != b, "mgx_smoother_vmult: bad argument");
-  mgx_operator_t op = sm->op;
-  launch_cheb_update(op->ctx->stream, op->d.number, 0, x, sm->x_old, b, nullptr, op->d.inv_diag, 0.,
-                     1. / sm->info.theta, op->d.n_dofs);
-  return cheb_loop(sm, x, b);
+  return smoother_apply(sm, &x, b, false, false);
 }
 
 int mgx_smoother_step(mgx_smoother_t sm, void *x, const void *b)
 {
   MGX_REQUIRE(sm && x && b && x != b, "mgx_smoother_step: bad argument");
-  mgx_operator_t op = sm->op;
-  MGX_TRY(mgx_vmult(op, sm->tmp, x));
-  launch_cheb_update(op->ctx->stream, op->d.number, 1, x, sm->x_old, b, sm->tmp, op->d.inv_diag, 0.,
-                     1. / sm->info.theta, op->d.n_dofs);
-  return cheb_loop(sm, x, b);
+  return smoother_apply(sm, &x, b, true, false);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1028,7 +1160,7 @@ static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
     {
       Stopwatch sw(S, 0, 0);
       S->timings[1] += 1;
-      return mgx_smoother_vmult(S->smooth[0], S->solution_update[0], S->defect[0]); // :647 (MGCoarseFromSmoother :72-91)
+      return smoother_apply(S->smooth[0], &S->solution_update[0], S->defect[0], false, true); // :647 (MGCoarseFromSmoother :72-91)
     }
   const size_t nc = S->matrix[level - 1]->d.n_dofs;
   for (int c = 0; c < my_n_cycles; ++c)
@@ -1036,9 +1168,9 @@ static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
       {
         Stopwatch sw(S, level, 5);
         if (c == 0) // :656-659
-          MGX_TRY(mgx_smoother_vmult(S->smooth[level], S->solution_update[level], S->defect[level]));
+          MGX_TRY(smoother_apply(S->smooth[level], &S->solution_update[level], S->defect[level], false, true));
         else
-          MGX_TRY(mgx_smoother_step(S->smooth[level], S->solution_update[level], S->defect[level]));
+          MGX_TRY(smoother_apply(S->smooth[level], &S->solution_update[level], S->defect[level], true, true));
       }
       {
         Stopwatch sw(S, level, 0);
@@ -1057,7 +1189,7 @@ static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
       }
       {
         Stopwatch sw(S, level, 5);
-        MGX_TRY(mgx_smoother_step(S->smooth[level], S->solution_update[level], S->defect[level])); // :678
+        MGX_TRY(smoother_apply(S->smooth[level], &S->solution_update[level], S->defect[level], true, true)); // :678
       }
     }
   return MGX_OK;
@@ -1073,8 +1205,8 @@ int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, dou
     Stopwatch    sw(S, 0, 0);
     const size_t n0 = S->matrix[0]->d.n_dofs;
     launch_copy_cast(s, S->defect[0], S->vnumber, S->rhs[0], MGX_F64, n0);
-    MGX_TRY(mgx_smoother_vmult(S->smooth[0], S->t[0], S->defect[0]));
-    MGX_TRY(mgx_smoother_step(S->smooth[0], S->t[0], S->defect[0]));
+    MGX_TRY(smoother_apply(S->smooth[0], &S->t[0], S->defect[0], false, true));
+    MGX_TRY(smoother_apply(S->smooth[0], &S->t[0], S->defect[0], true, true));
     launch_copy_cast(s, S->solution[0], MGX_F64, S->t[0], S->vnumber, n0);
     S->timings[1] += 2;
   }

@@ -1,0 +1,233 @@
+// mgx_bricks.cpp -- host-side construction of the brick schedule consumed by mgx_brick.hip from
+// the caller's 27-entry compressed index tables (laplace_operator.h:224-353).  Nothing here
+// assumes the cube: the 4x4x4 structure of every group of 64 consecutive cells is *verified*
+// through the entity indices the cells share, the brick adjacency is derived from shared surface
+// entities, and a level that does not pass falls back to the per-cell kernel.
+#include "mgx_bricks.hpp"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <parallel/algorithm>
+
+namespace mgx
+{
+  namespace
+  {
+    constexpr uint32_t kInvalid    = 0xFFFFFFFFu;
+    constexpr int      kMaxColours = 32;
+    constexpr uint32_t kUnset      = 0xFFFFFFFEu;
+    constexpr int      E1 = 9, NE = 729;
+
+    inline int compact3(int m)
+    {
+      return (m & 1) | ((m >> 2) & 2);
+    }
+
+    struct SurfaceRef
+    {
+      uint32_t key;   // first DoF of the entity (identifies it globally)
+      uint32_t brick; // brick index (cell order)
+      uint16_t slot;  // entity slot inside the brick
+    };
+  } // namespace
+
+  bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
+                    const uint8_t *colour_hint, BrickHost &out, std::string &why)
+  {
+    out = BrickHost();
+    if (p < 1 || p > 4)
+      {
+        why = "degree > 4: (4p+1)^3 accumulator does not fit the LDS budget";
+        return false;
+      }
+    if (n_cells < 64 || n_cells % 64 != 0)
+      {
+        why = "fewer than 64 cells or cell count not a multiple of 64";
+        return false;
+      }
+    const uint32_t nb = n_cells / 64;
+    out.n_bricks      = nb;
+    out.ent_base.assign((size_t)nb * NE, kInvalid);
+    out.ent_flags.assign((size_t)nb * NE, 0);
+    bool structured = true;
+    // 1. entity table of every brick; consistency of the shared entities proves the 4x4x4 layout
+#pragma omp parallel for schedule(static)
+    for (uint32_t b = 0; b < nb; ++b)
+      {
+        uint32_t key[NE];
+        for (int i = 0; i < NE; ++i)
+          key[i] = kUnset;
+        uint32_t *ent = &out.ent_base[(size_t)b * NE];
+        for (int m = 0; m < 64; ++m)
+          {
+            const int      bx = compact3(m), by = compact3(m >> 1), bz = compact3(m >> 2);
+            const uint32_t c  = 64 * b + m;
+            for (int e = 0; e < 27; ++e)
+              {
+                const int cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+                const int size = (cx == 1 ? p - 1 : 1) * (cy == 1 ? p - 1 : 1) * (cz == 1 ? p - 1 : 1);
+                const int slot = ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx + cx;
+                if (size == 0)
+                  {
+                    key[slot] = kInvalid; // p = 1: lines/quads/hexes carry no DoFs
+                    continue;
+                  }
+                const uint32_t v = idx27[27 * (size_t)c + e];
+                const uint32_t k = idx27_plain ? idx27_plain[27 * (size_t)c + e] : v;
+                if (key[slot] == kUnset)
+                  {
+                    key[slot] = k;
+                    ent[slot] = v;
+                  }
+                else if (key[slot] != k || ent[slot] != v)
+                  {
+#pragma omp atomic write
+                    structured = false;
+                  }
+              }
+          }
+      }
+    if (!structured)
+      {
+        why = "cells [64k,64k+64) do not form 4x4x4 bricks in Morton order";
+        out = BrickHost();
+        return false;
+      }
+    // 2. references to the (unconstrained) surface entities; interior entities are complete
+    //    after their own brick: FIRST|LAST
+    std::vector<SurfaceRef> refs;
+    {
+      std::vector<std::vector<SurfaceRef>> local(omp_get_max_threads());
+#pragma omp parallel for schedule(static)
+      for (uint32_t b = 0; b < nb; ++b)
+        {
+          auto &mine = local[omp_get_thread_num()];
+          for (int slot = 0; slot < NE; ++slot)
+            {
+              const uint32_t v = out.ent_base[(size_t)b * NE + slot];
+              if (v == kInvalid)
+                continue;
+              const int ex = slot % E1, ey = (slot / E1) % E1, ez = slot / (E1 * E1);
+              const bool surface = ex == 0 || ex == E1 - 1 || ey == 0 || ey == E1 - 1 || ez == 0 || ez == E1 - 1;
+              if (surface)
+                mine.push_back({v, b, (uint16_t)slot});
+              else
+                out.ent_flags[(size_t)b * NE + slot] = 3;
+            }
+        }
+      size_t total = 0;
+      for (auto &l : local)
+        total += l.size();
+      refs.reserve(total);
+      for (auto &l : local)
+        refs.insert(refs.end(), l.begin(), l.end());
+    }
+    __gnu_parallel::sort(refs.begin(), refs.end(), [](const SurfaceRef &a, const SurfaceRef &b) {
+      return a.key != b.key ? a.key < b.key : a.brick < b.brick;
+    });
+    // 3. colours: bricks sharing an entity must differ
+    std::vector<uint8_t> colour(nb, 255);
+    if (colour_hint)
+      {
+        for (uint32_t b = 0; b < nb; ++b)
+          colour[b] = colour_hint[b];
+      }
+    else
+      {
+        // adjacency from the groups, greedy colouring in brick order
+        std::vector<std::vector<uint32_t>> adj(nb);
+        for (size_t i = 0; i < refs.size();)
+          {
+            size_t j = i;
+            while (j < refs.size() && refs[j].key == refs[i].key)
+              ++j;
+            for (size_t a = i; a < j; ++a)
+              for (size_t c = i; c < j; ++c)
+                if (a != c)
+                  adj[refs[a].brick].push_back(refs[c].brick);
+            i = j;
+          }
+        for (uint32_t b = 0; b < nb; ++b)
+          {
+            uint64_t used = 0;
+            for (uint32_t o : adj[b])
+              if (colour[o] != 255)
+                used |= 1ull << colour[o];
+            int c = 0;
+            while (used & (1ull << c))
+              ++c;
+            if (c >= kMaxColours)
+              {
+                why = "more than 32 brick colours needed";
+                out = BrickHost();
+                return false;
+              }
+            colour[b] = (uint8_t)c;
+          }
+      }
+    int n_colours = 0;
+    for (uint32_t b = 0; b < nb; ++b)
+      {
+        if (colour[b] >= kMaxColours)
+          {
+            why = "brick colour out of range";
+            out = BrickHost();
+            return false;
+          }
+        n_colours = std::max(n_colours, colour[b] + 1);
+      }
+    // 4. FIRST / LAST flags of the surface entities from the launch order (= colour order)
+    for (size_t i = 0; i < refs.size();)
+      {
+        size_t j = i;
+        while (j < refs.size() && refs[j].key == refs[i].key)
+          ++j;
+        size_t lo = i, hi = i;
+        for (size_t a = i; a < j; ++a)
+          {
+            for (size_t c = a + 1; c < j; ++c)
+              if (colour[refs[a].brick] == colour[refs[c].brick])
+                {
+                  why = "two bricks that share DoFs have the same colour";
+                  out = BrickHost();
+                  return false;
+                }
+            if (colour[refs[a].brick] < colour[refs[lo].brick])
+              lo = a;
+            if (colour[refs[a].brick] > colour[refs[hi].brick])
+              hi = a;
+          }
+        out.ent_flags[(size_t)refs[lo].brick * NE + refs[lo].slot] |= 1;
+        out.ent_flags[(size_t)refs[hi].brick * NE + refs[hi].slot] |= 2;
+        i = j;
+      }
+    // 5. sort the bricks by colour (stable in cell order) and permute the tables
+    std::vector<uint32_t> order(nb);
+    out.colour_start.assign(n_colours + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b)
+      out.colour_start[colour[b] + 1]++;
+    for (int c = 0; c < n_colours; ++c)
+      out.colour_start[c + 1] += out.colour_start[c];
+    {
+      std::vector<uint32_t> pos(out.colour_start.begin(), out.colour_start.end() - 1);
+      for (uint32_t b = 0; b < nb; ++b)
+        order[pos[colour[b]]++] = b;
+    }
+    std::vector<uint32_t> base2((size_t)nb * NE);
+    std::vector<uint8_t>  flags2((size_t)nb * NE);
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < nb; ++i)
+      {
+        std::memcpy(&base2[(size_t)i * NE], &out.ent_base[(size_t)order[i] * NE], sizeof(uint32_t) * NE);
+        std::memcpy(&flags2[(size_t)i * NE], &out.ent_flags[(size_t)order[i] * NE], NE);
+      }
+    out.ent_base.swap(base2);
+    out.ent_flags.swap(flags2);
+    out.n_colours = n_colours;
+    (void)n_dofs;
+    return true;
+  }
+} // namespace mgx

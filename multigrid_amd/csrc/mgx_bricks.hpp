@@ -1,0 +1,22 @@
+// mgx_bricks.hpp -- host-side brick schedule builder (see mgx_bricks.cpp)
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mgx
+{
+  struct BrickHost
+  {
+    uint32_t              n_bricks  = 0;
+    int                   n_colours = 0;
+    std::vector<uint32_t> colour_start; // [n_colours+1] into the colour-sorted brick order
+    std::vector<uint32_t> ent_base;     // [n_bricks*729] first DoF per brick entity (constrained: invalid)
+    std::vector<uint8_t>  ent_flags;    // [n_bricks*729] bit0 FIRST, bit1 LAST
+  };
+
+  // false (with a reason) if the level cannot be scheduled as 4x4x4 bricks
+  bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
+                    const uint8_t *colour_hint, BrickHost &out, std::string &why);
+} // namespace mgx

@@ -145,6 +145,7 @@ namespace
     uint32_t              N = 0, n_cells = 0, n_dofs = 0, n_free = 0;
     double                h = 0;
     std::vector<uint32_t> idx27, idx27_plain, constrained, children, coords, dof_grid;
+    std::vector<uint8_t>  brick_colour; // parity colouring of the 4x4x4 Morton bricks (level >= 2)
     std::vector<double>   rhs, bc_value;
     std::vector<uint32_t> bc_index;
   };
@@ -243,6 +244,16 @@ namespace
             const uint32_t base = first[((2 * Z + cz) * E + 2 * Y + cy) * E + 2 * X + cx];
             L.idx27_plain[27 * (size_t)c + e] = base;
             L.idx27[27 * (size_t)c + e]       = base >= L.n_free ? MGX_INVALID_INDEX : base;
+          }
+      }
+    if (level >= 2) // 64 consecutive Morton cells = one 4x4x4 brick; 8 colours by brick parity
+      {
+        L.brick_colour.resize(nc / 64);
+        for (uint32_t b = 0; b < nc / 64; ++b)
+          {
+            const uint32_t X = L.coords[3 * (size_t)(64 * b)] / 4, Y = L.coords[3 * (size_t)(64 * b) + 1] / 4,
+                           Z = L.coords[3 * (size_t)(64 * b) + 2] / 4;
+            L.brick_colour[b] = (uint8_t)((X & 1) | ((Y & 1) << 1) | ((Z & 1) << 2));
           }
       }
     if (level > 0)
@@ -558,6 +569,7 @@ int mgx_cube_operator_desc(mgx_cube_t c, int l, int number, mgx_operator_desc *d
   d->shape_values = c->basis.S;
   d->colloc_grad  = c->basis.D;
   d->qweights     = c->basis.gw;
+  d->brick_colour = L.brick_colour.empty() ? nullptr : L.brick_colour.data();
   return MGX_OK;
 }
 

@@ -23,6 +23,20 @@ namespace mgx
     T P1[2 * kMaxN * kMaxN];  // P1[a*n+i]  prolongation, a in [0,2p]
   };
 
+  // Brick schedule of a level (mgx_brick.hip): 64-cell bricks sorted by colour, one launch per
+  // colour; per brick the first DoF of each of its 9^3 mesh entities and the FIRST/LAST flags.
+  struct BrickData
+  {
+    uint32_t  n_bricks  = 0;
+    int       n_colours = 0;
+    uint32_t  colour_start[33] = {0};
+    uint32_t *ent_base  = nullptr; // device [n_bricks * 729]
+    uint8_t  *ent_flags = nullptr; // device [n_bricks * 729]  bit0 FIRST, bit1 LAST
+    bool      available() const { return n_bricks > 0; }
+  };
+  constexpr int kBrickEntities = 729;
+  constexpr int kMaxColours    = 32;
+
   // Device-side view of a LaplaceOperator level (laplace_operator.h:126-163)
   struct OperatorData
   {
@@ -37,6 +51,7 @@ namespace mgx
     void     *basis         = nullptr; // device Basis1D<T>
     void     *inv_diag      = nullptr; // device, number type
     double    coef[6]       = {0, 0, 0, 0, 0, 0};
+    BrickData bricks;
   };
 
   struct TransferData
@@ -49,6 +64,12 @@ namespace mgx
   // ---- cell loops (mgx_kernels.hip) ----
   // dst += A_cells * src  (MatrixFree::cell_loop(local_apply), laplace_operator.h:527-558)
   void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src);
+  // brick cell loop with fused post-operation (mgx_brick.hip); mode = BrickMode
+  //   0: out = A src          1: out = a - A src
+  //   2: out = src + f1 (src - out) + f2 b (a - A src)      3: same without the f1 term
+  // `partial` carries partial sums of brick-surface DoFs between the colour launches
+  void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
+                         const void *b, void *out, void *partial, double f1, double f2);
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)
   // a1d[i] = sum_q w_q (dphi_i(x_q))^2, m1d[i] = sum_q w_q phi_i(x_q)^2 (host arrays, n entries)
   void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a1d,
@@ -81,6 +102,9 @@ namespace mgx
   //   mode 2: x_new = x + f1 * (x - x_old) + f2 * dinv * (b - t)     (x_old <- x)
   void launch_cheb_update(hipStream_t s, int number, int mode, void *x, void *x_old, const void *b,
                           const void *t, const void *dinv, double f1, double f2, size_t n);
+  void launch_cheb_init(hipStream_t s, int number, void *x, const void *b, const void *dinv, double f2, size_t n);
+  void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
+                               const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count);
   // partial[0..n_blocks) block sums of x.y, then reduced into *result_dev (double)
   void launch_dot(hipStream_t s, int number, const void *x, const void *y, size_t n, double *partial_dev,
                   double *result_dev);

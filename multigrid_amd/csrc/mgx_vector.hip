@@ -114,6 +114,34 @@ namespace mgx
     }
   }
 
+  // x = f2 * dinv * b (first Chebyshev iterate from a zero start, x_old implied zero)
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_cheb_init(T *__restrict__ x, const T *__restrict__ b, const T *__restrict__ dinv, T f2, size_t n)
+  {
+    GRID_STRIDE(i, n) x[i] = f2 * dinv[i] * b[i];
+  }
+
+  // Chebyshev update on the constrained rows, where (A x)_c = x_c (laplace_operator.h:736-737);
+  // mode as in mgx_brick.hip: 2 general, 3 first step, 4 x_old == 0
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_cheb_constrained(int mode, const T *__restrict__ x, T *__restrict__ out, const T *__restrict__ b,
+                       const T *__restrict__ dinv, T f1, T f2, const uint32_t *__restrict__ list, uint32_t count)
+  {
+    GRID_STRIDE(i, count)
+    {
+      const uint32_t c  = list[i];
+      const T        xi = x[c];
+      T              xn = xi + f2 * dinv[c] * (b[c] - xi);
+      if (mode == 2)
+        xn += f1 * (xi - out[c]);
+      else if (mode == 4)
+        xn += f1 * xi;
+      out[c] = xn;
+    }
+  }
+
   // ---- reductions: deterministic two-stage sum (block partials, then one block) ----
   __device__ __forceinline__ double wave_sum(double v)
   {
@@ -324,6 +352,24 @@ namespace mgx
                                              (const T *)b, (const T *)t, (const T *)dinv, (T)f1, (T)f2, n);
       else hipLaunchKernelGGL((k_cheb_update<T, 2>), g, dim3(256), 0, s, (T *)x, (T *)x_old, (const T *)b,
                               (const T *)t, (const T *)dinv, (T)f1, (T)f2, n));
+  }
+
+  void launch_cheb_init(hipStream_t s, int number, void *x, const void *b, const void *dinv, double f2, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_init<T>), stream_grid(n), dim3(256), 0, s, (T *)x, (const T *)b,
+                                         (const T *)dinv, (T)f2, n));
+  }
+
+  void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
+                               const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_constrained<T>), stream_grid(count), dim3(256), 0, s, mode,
+                                         (const T *)x, (T *)out, (const T *)b, (const T *)dinv, (T)f1, (T)f2, list,
+                                         count));
   }
 
   void launch_dot(hipStream_t s, int number, const void *x, const void *y, size_t n, double *partial_dev,

@@ -25,8 +25,10 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-CASES = [(1, 2, 1), (2, 1, 2), (3, 1, 2), (4, 1, 2), (4, 3, 1), (5, 1, 1), (6, 1, 1), (7, 1, 1), (8, 1, 1),
-         (9, 1, 1)]
+# levels with >= 64 cells in Morton bricks and p <= 4 run the brick cell loop (mgx_brick.hip), the
+# others the per-cell kernel (mgx_kernels.hip): both are covered
+CASES = [(1, 2, 1), (1, 1, 3), (2, 1, 2), (2, 1, 3), (3, 1, 2), (3, 3, 2), (4, 1, 2), (4, 1, 3), (4, 3, 1),
+         (4, 3, 2), (5, 1, 1), (5, 1, 2), (6, 1, 1), (7, 1, 1), (8, 1, 1), (8, 1, 2), (9, 1, 1)]
 
 
 @pytest.mark.parametrize("p,ns,nr", CASES)
@@ -49,12 +51,12 @@ def test_vmult_and_residual(ctx, p, ns, nr):
     orc.close()
 
 
-def test_operator_from_foreign_tables(ctx):
+@pytest.mark.parametrize("p,nr", [(4, 2), (4, 3), (2, 4)])
+def test_operator_from_foreign_tables(ctx, p, nr):
     """Drop-in scenario: tables come from the caller (here: the oracle's own arrays), not from
-    mgx_cube."""
-    p = 4
-    orc = Oracle(p, 1, 2)
-    l = 2
+    mgx_cube, and without the brick colour hint (the library colours the bricks itself)."""
+    orc = Oracle(p, 1, nr)
+    l = nr
     idx = np.ascontiguousarray(orc.idx27(l)).ravel()
     plain = np.ascontiguousarray(orc.idx27_plain(l)).ravel()
     cons = orc.constrained(l)
@@ -71,11 +73,20 @@ def test_operator_from_foreign_tables(ctx):
     d.shape_values = S.ctypes.data_as(mg._lib.f64p)
     d.colloc_grad = D.ctypes.data_as(mg._lib.f64p)
     d.qweights = w.ctypes.data_as(mg._lib.f64p)
+    d.brick_colour = None
     op = mg.LaplaceOperator(ctx, d)
     x = np.random.default_rng(3).uniform(-1, 1, orc.n_dofs(l))
-    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    b = np.random.default_rng(4).uniform(-1, 1, orc.n_dofs(l))
+    src, rhs, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=b), ctx.vector(x.size)
+    dst.upload(np.full(x.size, np.nan))  # the loop must overwrite, never read, the old dst
     op.vmult(dst, src)
     assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+    first = dst.download()
+    op.vmult(dst, src)
+    assert np.array_equal(first, dst.download())  # atomic-free => bitwise reproducible
+    dst.upload(np.full(x.size, np.nan))
+    op.vmult_residual(rhs, src, dst)
+    assert rel(dst.download(), orc.vmult_residual(l, b, x)) < 1e-12
     op.clear()
 
 
@@ -99,7 +110,7 @@ def test_error_paths(ctx):
     cube.close()
 
 
-@pytest.mark.parametrize("p,ns,nr", [(2, 1, 2), (4, 1, 2), (4, 3, 1), (7, 1, 1)])
+@pytest.mark.parametrize("p,ns,nr", [(2, 1, 2), (4, 1, 2), (4, 1, 3), (3, 3, 2), (4, 3, 1), (7, 1, 1)])
 def test_chebyshev(ctx, p, ns, nr):
     cube = mg.Cube(p, ns, nr)
     orc = Oracle(p, ns, nr, degree=3)
@@ -152,7 +163,8 @@ def test_transfers(ctx, p, ns, nr):
 
 
 @pytest.mark.parametrize("p,ns,nr,degree,ncyc", [(4, 1, 3, 3, 1), (4, 1, 3, 3, 2), (4, 3, 1, 2, 1), (2, 1, 3, 3, 1),
-                                                  (8, 1, 2, 3, 1), (4, 1, 0, 3, 1)])
+                                                  (8, 1, 2, 3, 1), (4, 1, 0, 3, 1), (4, 3, 2, 4, 1),
+                                                  (3, 1, 3, 2, 2), (1, 1, 4, 3, 1)])
 def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
     cube = mg.Cube(p, ns, nr)
     orc = Oracle(p, ns, nr, degree=degree, n_cycles=ncyc)
