@@ -35,8 +35,7 @@ namespace mgx
     static constexpr int NE1      = 2 * NB + 1;  // mesh entities per direction
     static constexpr int NE       = NE1 * NE1 * NE1;
     static constexpr int TPC      = N * N;
-    static constexpr int CTHREADS = 8 * TPC;     // compute threads per round
-    static constexpr int THREADS  = CTHREADS > 256 ? ((CTHREADS + 63) / 64) * 64 : 256;
+    static constexpr int THREADS  = 256;         // 4 waves x 2 cells per round
     static constexpr int CELL_LDS = N * N * LN;
   };
 
@@ -88,6 +87,23 @@ namespace mgx
     T        f1, f2;
   };
 
+  // wave-local ordering of LDS traffic: the two cells of a wave exchange data only among the
+  // lanes of that wave, which execute in lockstep; the LDS services one wave's operations in
+  // order, so a compiler-level barrier is all that is needed between the transposes
+  __device__ __forceinline__ void wave_sync()
+  {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // workgroup barrier that orders LDS traffic only: global loads issued earlier (the prefetch of
+  // the next round's source values) stay in flight across it, which __syncthreads() would drain
+  __device__ __forceinline__ void lds_barrier()
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
   template <int P, typename T, int MODE>
   __global__ void __launch_bounds__(BCfg<P>::THREADS)
     brick_loop_kernel(const T *__restrict__ src, uint32_t brick_first, const uint32_t *__restrict__ ent_base,
@@ -100,9 +116,9 @@ namespace mgx
     constexpr int PL = N * LN;
     constexpr int G  = C::G;
     constexpr int E1 = C::NE1;
+    static_assert(C::TPC <= 32 && C::THREADS == 256, "two cells per wave, four waves");
     __shared__ T        acc[G * G * G];
     __shared__ T        U[8 * C::CELL_LDS];
-    __shared__ T        V[8 * C::CELL_LDS];
     __shared__ uint32_t ebase[C::NE];
     __shared__ uint8_t  eflags[C::NE];
 
@@ -116,48 +132,70 @@ namespace mgx
     for (int i = tid; i < G * G * G; i += C::THREADS)
       acc[i] = T(0);
 
-    const bool compute = tid < C::CTHREADS;
-    const int  lc      = compute ? tid / C::TPC : 0;
-    const int  t       = tid - lc * C::TPC;
-    const int  a       = t % N;
-    const int  b       = t / N;
+    // a wave owns two cells of every round: lanes [0,TPC) and [32,32+TPC)
+    const int  lane    = tid & 63;
+    const int  t       = lane & 31;
+    const bool compute = t < C::TPC;
+    const int  lc      = 2 * (tid >> 6) + (lane >> 5); // 0..7
+    const int  a       = compute ? t % N : 0;
+    const int  b       = compute ? t / N : 0;
     T         *Uc      = U + lc * C::CELL_LDS;
-    T         *Vc      = V + lc * C::CELL_LDS;
     const int  xl      = (b * N + a) * LN;
     const int  yl      = b * PL + a;
     const int  zl      = b * LN + a;
-    const T    wa = B->w[compute ? a : 0], wb = B->w[compute ? b : 0];
+    const T    wa = B->w[a], wb = B->w[b];
     // entity codes of this thread's x-line (j = a, k = b): vector_access_reduced.h:232-247
     const int cy = (a == 0) ? 0 : (a == P ? 2 : 1), oy = (cy == 1) ? a - 1 : 0;
     const int cz = (b == 0) ? 0 : (b == P ? 2 : 1), oz = (cz == 1) ? b - 1 : 0;
     const uint32_t loff = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
+    // position of the cell inside its 2x2x2 octant (lc bits); the round adds the parity
+    const int hx = 2 * (lc & 1), hy = 2 * ((lc >> 1) & 1), hz = 2 * (lc >> 2);
     __syncthreads();
+
+    // read_dof_values_compressed through the brick's entity table for the cell of `round`.
+    // The loads are unconditional (constrained entities read element 0 and are masked when
+    // consumed) so that no branch forces a wait: they stay in flight as a prefetch.
+    uint32_t nvalid = 0; // bit i: entity i of the prefetched line is unconstrained
+    auto gather = [&](int round, T(&r)[N]) {
+      const int       bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
+      const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
+      const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
+      nvalid = (b0 != kInvalid ? 1u : 0u) | (b1 != kInvalid ? 2u : 0u) | (b2 != kInvalid ? 4u : 0u);
+      r[0] = src[b0 != kInvalid ? b0 + loff : 0u];
+      const uint32_t m1 = b1 != kInvalid ? b1 + loff * (uint32_t)(P - 1) : 0u;
+#pragma unroll
+      for (int i = 0; i < P - 1; ++i)
+        r[1 + i] = src[m1 + (uint32_t)i];
+      r[P] = src[b2 != kInvalid ? b2 + loff : 0u];
+    };
+
+    // Source values of the next round (prefetched).  The gather runs in uniform control flow
+    // (idle lanes duplicate line (0,0)): defined inside the lane-masked region the compiler
+    // would have to wait for the loads at the end of that region instead of at the next use.
+    T rn[N];
+    gather(0, rn);
 
 #pragma unroll 1
     for (int round = 0; round < 8; ++round)
       {
-        // cell of this thread in the round: same parity (round bits), position (lc bits)
-        const int bx = 2 * (lc & 1) + (round & 1);
-        const int by = 2 * ((lc >> 1) & 1) + ((round >> 1) & 1);
-        const int bz = 2 * (lc >> 2) + (round >> 2);
-        T         r[N], q[N], vz[N];
+        T r[N], q[N], vx[N], vy[N], vz[N];
+        r[0] = (nvalid & 1u) ? rn[0] : T(0);
+#pragma unroll
+        for (int i = 1; i < P; ++i)
+          r[i] = (nvalid & 2u) ? rn[i] : T(0);
+        r[P] = (nvalid & 4u) ? rn[P] : T(0);
+        if (round < 7)
+          gather(round + 1, rn); // in flight during the whole round
         if (compute)
           {
-            // read_dof_values_compressed through the brick's entity table
-            const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
-            const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
-            r[0] = b0 != kInvalid ? src[b0 + loff] : T(0);
-#pragma unroll
-            for (int i = 0; i < P - 1; ++i)
-              r[1 + i] = b1 != kInvalid ? src[b1 + loff * (uint32_t)(P - 1) + (uint32_t)i] : T(0);
-            r[P] = b2 != kInvalid ? src[b2 + loff] : T(0);
+            // 1. nodal -> quadrature along x
             bmv<N, T>(B->S, r, q);
 #pragma unroll
             for (int i = 0; i < N; ++i)
               Uc[xl + i] = q[i];
           }
-        __syncthreads();
-        if (compute)
+        wave_sync();
+        if (compute) // 2. along y
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
@@ -167,8 +205,8 @@ namespace mgx
             for (int i = 0; i < N; ++i)
               Uc[yl + i * LN] = q[i];
           }
-        __syncthreads();
-        if (compute)
+        wave_sync();
+        if (compute) // 3. along z; z-derivative pair stays in registers
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
@@ -184,76 +222,85 @@ namespace mgx
               r[i] *= f * B->w[i];
             bmvT<N, T>(B->D, r, vz);
           }
-        __syncthreads();
-        if (compute)
+        wave_sync();
+        if (compute) // 4./5. x- and y-derivative pairs from the quadrature values (read only)
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
               q[i] = Uc[xl + i];
             bmv<N, T>(B->D, q, r);
-            const T f = c0 * wa * wb;
+            const T fx = c0 * wa * wb;
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              r[i] *= f * B->w[i];
-            bmvT<N, T>(B->D, r, q);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              Vc[xl + i] = q[i];
-          }
-        __syncthreads();
-        if (compute)
-          {
+              r[i] *= fx * B->w[i];
+            bmvT<N, T>(B->D, r, vx);
 #pragma unroll
             for (int i = 0; i < N; ++i)
               q[i] = Uc[yl + i * LN];
             bmv<N, T>(B->D, q, r);
-            const T f = c1 * wa * wb;
+            const T fy = c1 * wa * wb;
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              r[i] *= f * B->w[i];
-            bmvT<N, T>(B->D, r, q);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              Vc[yl + i * LN] += q[i];
+              r[i] *= fy * B->w[i];
+            bmvT<N, T>(B->D, r, vy);
           }
-        __syncthreads();
-        if (compute)
+        wave_sync();
+        if (compute) // 6. the buffer is free: deposit the x part
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              r[i] = Vc[zl + i * PL] + vz[i];
-            bmvT<N, T>(B->S, r, q);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              Vc[zl + i * PL] = q[i];
+              Uc[xl + i] = vx[i];
           }
-        __syncthreads();
-        if (compute)
+        wave_sync();
+        if (compute) // 7. add the y part
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              r[i] = Vc[yl + i * LN];
-            bmvT<N, T>(B->S, r, q);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              Vc[yl + i * LN] = q[i];
+              Uc[yl + i * LN] += vy[i];
           }
-        __syncthreads();
-        if (compute)
+        wave_sync();
+        if (compute) // 8. add the z part, integrate along z
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              r[i] = Vc[xl + i];
+              r[i] = Uc[zl + i * PL] + vz[i];
             bmvT<N, T>(B->S, r, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[zl + i * PL] = q[i];
+          }
+        wave_sync();
+        if (compute) // 9. along y
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r[i] = Uc[yl + i * LN];
+            bmvT<N, T>(B->S, r, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[yl + i * LN] = q[i];
+          }
+        wave_sync();
+        if (compute) // 10. along x
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r[i] = Uc[xl + i];
+            bmvT<N, T>(B->S, r, q);
+          }
+        // cells of consecutive rounds are neighbours: all accumulator updates of the previous
+        // round must have landed before this round's begin
+        lds_barrier();
+        if (compute)
+          {
             // distribute_local_to_global into the brick accumulator: no other cell of this
             // round touches these points
-            T *row = acc + ((bz * P + b) * G + (by * P + a)) * G + bx * P;
+            const int bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
+            T        *row = acc + ((bz * P + b) * G + (by * P + a)) * G + bx * P;
 #pragma unroll
             for (int i = 0; i < N; ++i)
               row[i] += q[i];
           }
-        // the first barrier of the next round orders these LDS updates before any thread of a
-        // neighbouring cell touches the same accumulator entries 7 barriers later
       }
     __syncthreads();
 
