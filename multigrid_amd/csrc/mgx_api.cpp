@@ -16,6 +16,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -520,29 +521,75 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   if (desc->n_constrained)
     MGX_HIP(hipMemcpy(d.constrained, desc->constrained, sizeof(uint32_t) * desc->n_constrained,
                       hipMemcpyHostToDevice));
+  // 1D mass and stiffness matrices of the separable form, M = S^T W S, K = S^T D^T W D S
+  double M1[kMaxN * kMaxN], K1[kMaxN * kMaxN];
+  {
+    long double G[kMaxN * kMaxN]; // G = D S: derivative of the nodal basis at the quadrature points
+    for (int q = 0; q < n; ++q)
+      for (int i = 0; i < n; ++i)
+        {
+          long double g = 0;
+          for (int r = 0; r < n; ++r)
+            g += (long double)op->D[q * n + r] * op->S[r * n + i];
+          G[q * n + i] = g;
+        }
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        {
+          long double m = 0, k = 0;
+          for (int q = 0; q < n; ++q)
+            {
+              m += (long double)op->w[q] * op->S[q * n + i] * op->S[q * n + j];
+              k += (long double)op->w[q] * G[q * n + i] * G[q * n + j];
+            }
+          M1[i * n + j] = (double)m;
+          K1[i * n + j] = (double)k;
+        }
+  }
+  auto fill_basis = [&](auto &b) {
+    using T = std::remove_reference_t<decltype(b.S[0])>;
+    for (int i = 0; i < n * n; ++i)
+      {
+        b.S[i] = (T)op->S[i];
+        b.D[i] = (T)op->D[i];
+      }
+    for (int i = 0; i < n; ++i)
+      b.w[i] = (T)op->w[i];
+    const int H = n / 2;
+    auto      eo = [&](auto &E, const double *A) {
+      for (int a = 0; a < H; ++a)
+        {
+          for (int i = 0; i < H; ++i)
+            {
+              E.ee[a * H + i] = (T)(0.5 * (A[a * n + i] + A[a * n + n - 1 - i]));
+              E.eo[a * H + i] = (T)(0.5 * (A[a * n + i] - A[a * n + n - 1 - i]));
+            }
+          E.mc[a] = (n % 2) ? (T)A[a * n + H] : (T)0;
+        }
+      E.mhh = (n % 2) ? (T)A[H * n + H] : (T)0;
+    };
+    eo(b.mass, M1);
+    eo(b.lapl, K1);
+  };
+  // the separable fast path needs the symmetry A[a][b] = A[n-1-a][n-1-b] of M and K (true for
+  // any symmetric node/quadrature set); MGX_GENERAL_KERNEL=1 forces the quadrature-point form
+  d.separable = !std::getenv("MGX_GENERAL_KERNEL");
+  for (int a = 0; a < n && d.separable; ++a)
+    for (int bb = 0; bb < n; ++bb)
+      if (std::fabs(M1[a * n + bb] - M1[(n - 1 - a) * n + n - 1 - bb]) > 1e-12 ||
+          std::fabs(K1[a * n + bb] - K1[(n - 1 - a) * n + n - 1 - bb]) > 1e-10 * std::fabs(K1[0]))
+        d.separable = false;
   if (d.number == MGX_F64)
     {
       Basis1D<double> b{};
-      for (int i = 0; i < n * n; ++i)
-        {
-          b.S[i] = op->S[i];
-          b.D[i] = op->D[i];
-        }
-      for (int i = 0; i < n; ++i)
-        b.w[i] = op->w[i];
+      fill_basis(b);
       MGX_HIP(hipMalloc(&d.basis, sizeof(b)));
       MGX_HIP(hipMemcpy(d.basis, &b, sizeof(b), hipMemcpyHostToDevice));
     }
   else
     {
       Basis1D<float> b{};
-      for (int i = 0; i < n * n; ++i)
-        {
-          b.S[i] = (float)op->S[i];
-          b.D[i] = (float)op->D[i];
-        }
-      for (int i = 0; i < n; ++i)
-        b.w[i] = (float)op->w[i];
+      fill_basis(b);
       MGX_HIP(hipMalloc(&d.basis, sizeof(b)));
       MGX_HIP(hipMemcpy(d.basis, &b, sizeof(b), hipMemcpyHostToDevice));
     }

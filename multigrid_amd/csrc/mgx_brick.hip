@@ -344,6 +344,252 @@ namespace mgx
   }
 
   // ------------------------------------------------------------------------------------------
+  // Separable fast path.  On a Cartesian mesh with a constant coefficient the merged coefficient
+  // is one diagonal tensor for the whole mesh (laplace_operator.h:374-387, 447-491) and the
+  // quadrature weights factorise, so   S^T [sum_d D_d^T (c_d w) D_d] S  =  sum_d c_d (M x M x K_d)
+  // with the 1D matrices M = S^T W S and K = S^T D^T W D S:
+  //     t1 = M_x u, k1 = K_x u ;  t2 = M_y t1, s2 = c_x M_y k1 + c_y K_y t1 ;
+  //     out = M_z s2 + c_z K_z t2
+  // 7 sweeps instead of 12 and 2 LDS transposes instead of 8; M and K are symmetric and
+  // persymmetric, so every sweep runs in even-odd form with coefficients that stay in SGPRs.
+  // ------------------------------------------------------------------------------------------
+  template <int N, typename T>
+  __device__ __forceinline__ void eo_split(const T (&x)[N], T (&xe)[N / 2 + 1], T (&xo)[N / 2 + 1])
+  {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+      {
+        xe[i] = x[i] + x[N - 1 - i];
+        xo[i] = x[i] - x[N - 1 - i];
+      }
+    xe[H] = (N % 2) ? x[H] : T(0); // middle entry
+    xo[H] = T(0);
+  }
+
+  template <int N, typename T>
+  __device__ __forceinline__ void eo_apply(const EOMat<T> &A, const T (&xe)[N / 2 + 1], const T (&xo)[N / 2 + 1],
+                                           T (&y)[N])
+  {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+      {
+        T r0 = A.ee[a * H] * xe[0];
+        T r1 = A.eo[a * H] * xo[0];
+#pragma unroll
+        for (int i = 1; i < H; ++i)
+          {
+            r0 = fma(A.ee[a * H + i], xe[i], r0);
+            r1 = fma(A.eo[a * H + i], xo[i], r1);
+          }
+        if (N % 2)
+          r0 = fma(A.mc[a], xe[H], r0);
+        y[a]         = r0 + r1;
+        y[N - 1 - a] = r0 - r1;
+      }
+    if (N % 2)
+      {
+        T r = A.mhh * xe[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+          r = fma(A.mc[i], xe[i], r);
+        y[H] = r;
+      }
+  }
+
+  template <int P, typename T, int MODE>
+  __global__ void __launch_bounds__(BCfg<P>::THREADS)
+    brick_sep_kernel(const T *__restrict__ src, uint32_t brick_first, const uint32_t *__restrict__ ent_base,
+                     const uint8_t *__restrict__ ent_flags, const Basis1D<T> *__restrict__ B, T c0, T c1, T c2,
+                     BrickPost<T> post)
+  {
+    using C          = BCfg<P>;
+    constexpr int N  = C::N;
+    constexpr int LN = C::LN;
+    constexpr int PL = N * LN;
+    constexpr int G  = C::G;
+    constexpr int E1 = C::NE1;
+    constexpr int H1 = N / 2 + 1;
+    static_assert(C::TPC <= 32 && C::THREADS == 256, "two cells per wave, four waves");
+    __shared__ T        acc[G * G * G];
+    __shared__ T        U[8 * C::CELL_LDS];
+    __shared__ uint32_t ebase[C::NE];
+    __shared__ uint8_t  eflags[C::NE];
+
+    const int      tid   = threadIdx.x;
+    const uint32_t brick = brick_first + blockIdx.x;
+    for (int i = tid; i < C::NE; i += C::THREADS)
+      {
+        ebase[i]  = ent_base[(size_t)brick * C::NE + i];
+        eflags[i] = ent_flags[(size_t)brick * C::NE + i];
+      }
+    for (int i = tid; i < G * G * G; i += C::THREADS)
+      acc[i] = T(0);
+
+    const int  lane    = tid & 63;
+    const int  t       = lane & 31;
+    const bool compute = t < C::TPC;
+    const int  lc      = 2 * (tid >> 6) + (lane >> 5);
+    const int  a       = compute ? t % N : 0;
+    const int  b       = compute ? t / N : 0;
+    T         *Uc      = U + lc * C::CELL_LDS;
+    const int  xl      = (b * N + a) * LN;
+    const int  yl      = b * PL + a;
+    const int  zl      = b * LN + a;
+    const int cy = (a == 0) ? 0 : (a == P ? 2 : 1), oy = (cy == 1) ? a - 1 : 0;
+    const int cz = (b == 0) ? 0 : (b == P ? 2 : 1), oz = (cz == 1) ? b - 1 : 0;
+    const uint32_t loff = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
+    const int hx = 2 * (lc & 1), hy = 2 * ((lc >> 1) & 1), hz = 2 * (lc >> 2);
+    const EOMat<T> &M = B->mass, &K = B->lapl;
+    __syncthreads();
+
+    uint32_t nvalid = 0;
+    auto gather = [&](int round, T(&r)[N]) {
+      const int       bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
+      const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
+      const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
+      nvalid = (b0 != kInvalid ? 1u : 0u) | (b1 != kInvalid ? 2u : 0u) | (b2 != kInvalid ? 4u : 0u);
+      r[0] = src[b0 != kInvalid ? b0 + loff : 0u];
+      const uint32_t m1 = b1 != kInvalid ? b1 + loff * (uint32_t)(P - 1) : 0u;
+#pragma unroll
+      for (int i = 0; i < P - 1; ++i)
+        r[1 + i] = src[m1 + (uint32_t)i];
+      r[P] = src[b2 != kInvalid ? b2 + loff : 0u];
+    };
+    T rn[N];
+    gather(0, rn);
+
+#pragma unroll 1
+    for (int round = 0; round < 8; ++round)
+      {
+        T r[N], t1[N], k1[N], xe[H1], xo[H1];
+        r[0] = (nvalid & 1u) ? rn[0] : T(0);
+#pragma unroll
+        for (int i = 1; i < P; ++i)
+          r[i] = (nvalid & 2u) ? rn[i] : T(0);
+        r[P] = (nvalid & 4u) ? rn[P] : T(0);
+        if (round < 7)
+          gather(round + 1, rn);
+        // x: t1 = M u, k1 = K u
+        eo_split<N, T>(r, xe, xo);
+        eo_apply<N, T>(M, xe, xo, t1);
+        eo_apply<N, T>(K, xe, xo, k1);
+        if (compute)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[xl + i] = t1[i];
+          }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          t1[i] = Uc[yl + i * LN]; // y-line of M_x u
+        wave_sync();
+        if (compute)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[xl + i] = k1[i];
+          }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          k1[i] = Uc[yl + i * LN]; // y-line of K_x u
+        wave_sync();
+        // y: t2 = M t1 ; s2 = c_x M k1 + c_y K t1
+        T t2[N], s2[N];
+        eo_split<N, T>(t1, xe, xo);
+        eo_apply<N, T>(M, xe, xo, t2);
+        eo_apply<N, T>(K, xe, xo, s2);
+        eo_split<N, T>(k1, xe, xo);
+        eo_apply<N, T>(M, xe, xo, r);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          s2[i] = fma(c0, r[i], c1 * s2[i]);
+        if (compute)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[yl + i * LN] = t2[i];
+          }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          t2[i] = Uc[zl + i * PL]; // z-line of M_y M_x u
+        wave_sync();
+        if (compute)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[yl + i * LN] = s2[i];
+          }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          s2[i] = Uc[zl + i * PL];
+        // z: out = M s2 + c_z K t2
+        eo_split<N, T>(s2, xe, xo);
+        eo_apply<N, T>(M, xe, xo, r);
+        eo_split<N, T>(t2, xe, xo);
+        eo_apply<N, T>(K, xe, xo, t1);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = fma(c2, t1[i], r[i]);
+        lds_barrier(); // all accumulator updates of the previous round have landed
+        if (compute)
+          {
+            // thread (i = a, j = b) owns the z-line: accumulate the column of the brick array
+            const int bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
+            T        *col = acc + ((bz * P) * G + (by * P + b)) * G + bx * P + a;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              col[i * G * G] += r[i];
+          }
+      }
+    __syncthreads();
+
+    // write-out with the fused post-operation; the point index advances by 256 = 15 G + 1 (G = 17)
+    // per iteration for p = 4, so the coordinates are updated incrementally where that is cheap
+    for (int pnt = tid; pnt < G * G * G; pnt += C::THREADS)
+      {
+        const int gx = pnt % G, gy = (pnt / G) % G, gz = pnt / (G * G);
+        const int rx = gx % P, ry = gy % P, rz = gz % P;
+        const int ex = 2 * (gx / P) + (rx != 0), ey = 2 * (gy / P) + (ry != 0), ez = 2 * (gz / P) + (rz != 0);
+        const int nx = rx ? P - 1 : 1, ny = ry ? P - 1 : 1;
+        const int ox = rx ? rx - 1 : 0, oy2 = ry ? ry - 1 : 0, oz2 = rz ? rz - 1 : 0;
+        const int e  = (ez * E1 + ey) * E1 + ex;
+        const uint32_t base = ebase[e];
+        if (base == kInvalid)
+          continue;
+        const uint32_t idx = base + (uint32_t)((oz2 * ny + oy2) * nx + ox);
+        const uint8_t  fl  = eflags[e];
+        T              val = acc[pnt];
+        if (!(fl & 1))
+          val += post.partial[idx];
+        if (fl & 2)
+          {
+            if (MODE == kPlain)
+              post.out[idx] = val;
+            else if (MODE == kResidual)
+              post.out[idx] = post.a[idx] - val;
+            else
+              {
+                const T xi = src[idx];
+                T       xn = xi + post.f2 * post.b[idx] * (post.a[idx] - val);
+                if (MODE == kCheb)
+                  xn += post.f1 * (xi - post.out[idx]);
+                else if (MODE == kChebZeroOld)
+                  xn += post.f1 * xi;
+                post.out[idx] = xn;
+              }
+          }
+        else
+          post.partial[idx] = val;
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
   template <int P, typename T, int MODE>
   static void brick_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post)
   {
@@ -354,9 +600,14 @@ namespace mgx
         const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
         if (count == 0)
           continue;
-        hipLaunchKernelGGL((brick_loop_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
-                           bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
-                           (T)op.coef[2], post);
+        if (op.separable)
+          hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
+                             bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
+                             (T)op.coef[2], post);
+        else
+          hipLaunchKernelGGL((brick_loop_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
+                             bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
+                             (T)op.coef[2], post);
       }
   }
 

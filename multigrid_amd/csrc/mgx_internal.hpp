@@ -14,6 +14,19 @@ namespace mgx
 
   // 1D data of the element in the operator's number type, resident in device memory and read
   // through wave-uniform (scalar) loads.
+  // Even-odd (Appendix B of SURVEY.md, matrix_vector_kernel.h:47-113) form of a symmetric and
+  // persymmetric n x n matrix A (A[a][b] = A[b][a] = A[n-1-a][n-1-b]), H = n/2:
+  //   ee[a*H+i] = (A[a][i] + A[a][n-1-i])/2, eo[a*H+i] = (A[a][i] - A[a][n-1-i])/2  (a,i < H)
+  //   mc[a] = A[a][H] (odd n: middle column = middle row), mhh = A[H][H]
+  template <typename T>
+  struct EOMat
+  {
+    T ee[(kMaxN / 2) * (kMaxN / 2)];
+    T eo[(kMaxN / 2) * (kMaxN / 2)];
+    T mc[kMaxN / 2];
+    T mhh;
+  };
+
   template <typename T>
   struct Basis1D
   {
@@ -21,6 +34,9 @@ namespace mgx
     T D[kMaxN * kMaxN];       // D[q*n+r]   collocation derivative
     T w[kMaxN];               // quadrature weights
     T P1[2 * kMaxN * kMaxN];  // P1[a*n+i]  prolongation, a in [0,2p]
+    // 1D mass and stiffness matrices of the separable (Cartesian, constant coefficient) cell
+    // matrix  A_cell = sum_d c_d (M x M x K_d):  M = S^T W S,  K = S^T D^T W D S
+    EOMat<T> mass, lapl;
   };
 
   // Brick schedule of a level (mgx_brick.hip): 64-cell bricks sorted by colour, one launch per
@@ -52,6 +68,7 @@ namespace mgx
     void     *inv_diag      = nullptr; // device, number type
     double    coef[6]       = {0, 0, 0, 0, 0, 0};
     BrickData bricks;
+    bool      separable     = true; // Cartesian constant-coefficient fast path of the brick loop
   };
 
   struct TransferData
@@ -70,6 +87,8 @@ namespace mgx
   // `partial` carries partial sums of brick-surface DoFs between the colour launches
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2);
+  // true: the brick loop evaluates the separable form (7 sweeps); false: the general
+  // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)
   // a1d[i] = sum_q w_q (dphi_i(x_q))^2, m1d[i] = sum_q w_q phi_i(x_q)^2 (host arrays, n entries)
   void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a1d,

@@ -1,0 +1,25 @@
+"""Runs N finest-level fp64 matvecs (and optionally Chebyshev steps) -- profiling target."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multigrid_amd as mg
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+mode = sys.argv[3] if len(sys.argv) > 3 else "vmult"
+ns, nr = cells, 0
+while ns % 2 == 0 and ns > 1:
+    ns //= 2; nr += 1
+ctx = mg.Context(0)
+cube = mg.Cube(4, ns, nr)
+l = cube.max_level
+op = mg.LaplaceOperator.from_cube(ctx, cube, l)
+x = ctx.vector(cube.n_dofs(l), data=cube.seeded_vector(l, 42))
+y = ctx.vector(cube.n_dofs(l))
+if mode == "vmult":
+    for _ in range(n):
+        op.vmult(y, x)
+else:
+    sm = mg.Chebyshev(op, 20., 3, 15)
+    for _ in range(n):
+        sm.step(y, x)
+ctx.sync()
+print("done", cube.n_dofs(l))
