@@ -190,7 +190,10 @@ namespace
     hipStream_t    s = op->ctx->stream;
     ProfileBracket pb(op);
     if (op->d.bricks.available())
-      launch_brick_loop(s, op->d, 0, src, nullptr, nullptr, dst, dst, 0., 0.);
+      {
+        static const int ablate = std::getenv("MGX_BRICK_ABLATE") ? std::atoi(std::getenv("MGX_BRICK_ABLATE")) : 0;
+        launch_brick_loop(s, op->d, ablate, src, nullptr, nullptr, dst, dst, 0., 0.);
+      }
     else
       {
         // "zero dst within the loop" (laplace_operator.h:590)

@@ -74,7 +74,11 @@ namespace mgx
     kResidual = 1, // out = a - A src                               (vmult_residual, :605)
     kCheb     = 2, // out = x + f1 (x - out) + f2 b (a - A x)       (PreconditionChebyshev update)
     kChebFirst = 3, // out = x + f2 b (a - A x)                     (first step: no x_old term)
-    kChebZeroOld = 4 // out = x + f1 x + f2 b (a - A x)              (x_old known to be zero)
+    kChebZeroOld = 4, // out = x + f1 x + f2 b (a - A x)             (x_old known to be zero)
+    // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
+    kNoStore   = 8, // rounds only, no write-out
+    kNoCompute = 9, // write-out only, no rounds
+    kInitOnly  = 10 // prologue only
   };
 
   template <typename T>
@@ -86,6 +90,211 @@ namespace mgx
     T       *partial; // carrier of partial sums between colour launches (may alias out)
     T        f1, f2;
   };
+
+
+  // ------------------------------------------------------------------------------------------
+  // Write-out of the brick accumulator with the fused post-operation, one mesh-entity class at a
+  // time (class = which directions are cell-interior: hexes, 3 kinds of quads, 3 kinds of lines,
+  // vertices).  Consecutive work items are consecutive DoFs of one entity, i.e. consecutive
+  // global addresses: runs of (p-1)^3, (p-1)^2, (p-1) or 1 values instead of the runs of p-1 a
+  // lexicographic sweep over the brick points would give.
+  // ------------------------------------------------------------------------------------------
+  // Pass 1 of the write-out: everything that has to be READ (partial sums of earlier launches and
+  // the operands of the fused post-operation) is loaded with unconditional, branch-free loads
+  // (masked entries read element 0) and folded into the accumulator value.  Pass 2 then only
+  // STORES.  Keeping loads and stores in separate passes matters on gfx950: vmcnt counts stores
+  // too, so a load that follows stores would wait for every earlier store's acknowledgement.
+  template <int P, typename T, int MODE>
+  __device__ __forceinline__ T post_value(const T *__restrict__ src, const BrickPost<T> &post, bool valid,
+                                          uint32_t idx, uint8_t fl, T val)
+  {
+    const bool     need_partial = valid && !(fl & 1);
+    const bool     last         = valid && (fl & 2);
+    const uint32_t ip           = need_partial ? idx : 0u;
+    const uint32_t il           = last ? idx : 0u;
+    const T        pv           = post.partial[ip];
+    if (MODE == kPlain || MODE == kNoCompute)
+      return need_partial ? val + pv : val;
+    else if (MODE == kResidual)
+      {
+        const T av = post.a[il];
+        val        = need_partial ? val + pv : val;
+        return last ? av - val : val;
+      }
+    else
+      {
+        const T av = post.a[il], bv = post.b[il], xi = src[il];
+        T       ov = T(0);
+        if (MODE == kCheb)
+          ov = post.out[il];
+        val  = need_partial ? val + pv : val;
+        T xn = xi + post.f2 * bv * (av - val);
+        if (MODE == kCheb)
+          xn += post.f1 * (xi - ov);
+        else if (MODE == kChebZeroOld)
+          xn += post.f1 * xi;
+        return last ? xn : val;
+      }
+  }
+
+  // Cell-block order: the DoFs on the high side / in the interior of a cell (p^3 per cell, in
+  // the order {hex, x-face, y-face, xy-line, z-face, xz-line, yz-line, vertex} = entities
+  // 13,14,16,17,22,23,25,26 of the 27-entry table).  With a first-touch, cell-by-cell numbering
+  // (mgx_cube; deal.II's matrix-free renumbering is of the same kind) these p^3 values are one
+  // contiguous block per cell, so one wave instruction moves one 512-B cell block at p = 4.  The
+  // mapping is correct for every numbering that satisfies the entity-contiguity contract; only
+  // the coalescing depends on it.
+  template <int P>
+  __device__ __forceinline__ void decode_cell_dof(int kk, int &slot_rel, int &pnt_rel, int &k)
+  {
+    // kk in [0, p^3): find the entity (codes cx,cy,cz in {1,2}) and the offset inside it
+    constexpr int G = BCfg<P>::G, E1 = BCfg<P>::NE1;
+    int           off = 0;
+    slot_rel = pnt_rel = k = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      {
+        const int cx = 1 + (j & 1), cy = 1 + ((j >> 1) & 1), cz = 1 + (j >> 2);
+        const int nx = cx == 1 ? P - 1 : 1, ny = cy == 1 ? P - 1 : 1, nz = cz == 1 ? P - 1 : 1;
+        const int sz = nx * ny * nz;
+        if (sz > 0 && kk >= off && kk < off + sz)
+          {
+            const int kl = kk - off;
+            const int ox = kl % nx, oy = (kl / nx) % ny, oz = kl / (nx * ny);
+            const int lx = cx == 1 ? 1 + ox : P, ly = cy == 1 ? 1 + oy : P, lz = cz == 1 ? 1 + oz : P;
+            slot_rel = (cz * E1 + cy) * E1 + cx;
+            pnt_rel  = (lz * G + ly) * G + lx;
+            k        = kl;
+          }
+        off += sz;
+      }
+  }
+
+  template <int P, typename T, int MODE>
+  __device__ __forceinline__ void store_brick(int tid, T *acc, const uint32_t *ebase, const uint8_t *eflags,
+                                              const T *__restrict__ src, const BrickPost<T> &post)
+  {
+    using C          = BCfg<P>;
+    constexpr int G  = C::G;
+    constexpr int E1 = C::NE1;
+    constexpr int P3 = P * P * P;
+    constexpr int NA = 64 * P3;
+    constexpr bool kFixedLane = (C::THREADS % P3) == 0; // per-thread decode hoisted out of the loops
+    constexpr int NBF = G * G * G - (G - 1) * (G - 1) * (G - 1);
+    int slot_rel = 0, pnt_rel = 0, k = 0;
+    if (kFixedLane)
+      decode_cell_dof<P>(tid % P3, slot_rel, pnt_rel, k);
+
+    // work item -> (entity slot, accumulator index, offset inside the entity).  With a thread
+    // count that is a multiple of p^3 a thread keeps its position inside the cell block and
+    // iteration `it` only advances the cell by a compile-time constant: the cell index is
+    // m = m_thread + CPI * it with CPI = THREADS / p^3 a power of two, so the Morton bits of the
+    // two parts are disjoint and (after full unrolling) the second part folds to immediates.
+    constexpr int CPI = kFixedLane ? C::THREADS / P3 : 1;
+    auto cell_slot = [](int m) {
+      const int bx = (m & 1) | ((m >> 2) & 2), by = ((m >> 1) & 1) | ((m >> 3) & 2), bz = ((m >> 2) & 1) | ((m >> 4) & 2);
+      return ((2 * bz) * E1 + 2 * by) * E1 + 2 * bx;
+    };
+    auto cell_pnt = [](int m) {
+      const int bx = (m & 1) | ((m >> 2) & 2), by = ((m >> 1) & 1) | ((m >> 3) & 2), bz = ((m >> 2) & 1) | ((m >> 4) & 2);
+      return ((bz * P) * G + by * P) * G + bx * P;
+    };
+    const int m_thread = kFixedLane ? tid / P3 : 0;
+    const int e_thread = slot_rel + cell_slot(m_thread), pnt_thread = pnt_rel + cell_pnt(m_thread);
+    auto item_a = [&](int it, int &e, int &pnt, uint32_t &off) {
+      if (kFixedLane)
+        {
+          e   = e_thread + cell_slot(CPI * it);
+          pnt = pnt_thread + cell_pnt(CPI * it);
+          off = (uint32_t)k;
+        }
+      else
+        {
+          const int w = tid + it * C::THREADS, m = w / P3;
+          decode_cell_dof<P>(w - m * P3, slot_rel, pnt_rel, k);
+          e   = slot_rel + cell_slot(m);
+          pnt = pnt_rel + cell_pnt(m);
+          off = (uint32_t)k;
+        }
+    };
+    constexpr int ITA = (NA + C::THREADS - 1) / C::THREADS; // iterations of part A
+    auto item_b = [&](int w, int &e, int &pnt, uint32_t &off) {
+      int gx, gy, gz;
+      if (w < G * G)
+        {
+          gz = 0;
+          gy = w / G;
+          gx = w - gy * G;
+        }
+      else if (w < G * G + G * (G - 1))
+        {
+          const int v = w - G * G;
+          gy          = 0;
+          gz          = 1 + v / G;
+          gx          = v % G;
+        }
+      else
+        {
+          const int v = w - G * G - G * (G - 1);
+          gx          = 0;
+          gz          = 1 + v / (G - 1);
+          gy          = 1 + v % (G - 1);
+        }
+      const int rx = gx % P, ry = gy % P, rz = gz % P;
+      const int ex = 2 * (gx / P) + (rx != 0), ey = 2 * (gy / P) + (ry != 0), ez = 2 * (gz / P) + (rz != 0);
+      const int nx = rx ? P - 1 : 1, ny = ry ? P - 1 : 1;
+      const int ox = rx ? rx - 1 : 0, oy = ry ? ry - 1 : 0, oz = rz ? rz - 1 : 0;
+      e   = (ez * E1 + ey) * E1 + ex;
+      pnt = (gz * G + gy) * G + gx;
+      off = (uint32_t)((oz * ny + oy) * nx + ox);
+    };
+
+    // ---- pass 1: loads + post-operation, result back into the accumulator (same thread) ----
+#pragma unroll
+    for (int it = 0; it < ITA; ++it)
+      {
+        if (tid + it * C::THREADS >= NA)
+          break;
+        int      e, pnt;
+        uint32_t off;
+        item_a(it, e, pnt, off);
+        const uint32_t base = ebase[e];
+        acc[pnt] = post_value<P, T, MODE>(src, post, base != kInvalid, base + off, eflags[e], acc[pnt]);
+      }
+#pragma unroll 2
+    for (int w = tid; w < NBF; w += C::THREADS)
+      {
+        int      e, pnt;
+        uint32_t off;
+        item_b(w, e, pnt, off);
+        const uint32_t base = ebase[e];
+        acc[pnt] = post_value<P, T, MODE>(src, post, base != kInvalid, base + off, eflags[e], acc[pnt]);
+      }
+    // ---- pass 2: stores only.  Part A writes the p^3 DoFs on the high side / in the interior
+    // of each cell; with a first-touch cell-by-cell numbering that is one contiguous block per
+    // cell (one 512-B wave instruction at p = 4).  Part B: the low faces of the brick. ----
+#pragma unroll
+    for (int it = 0; it < ITA; ++it)
+      {
+        if (tid + it * C::THREADS >= NA)
+          break;
+        int      e, pnt;
+        uint32_t off;
+        item_a(it, e, pnt, off);
+        const uint32_t base = ebase[e];
+        if (base != kInvalid)
+          ((eflags[e] & 2) ? post.out : post.partial)[base + off] = acc[pnt];
+      }
+    for (int w = tid; w < NBF; w += C::THREADS)
+      {
+        int      e, pnt;
+        uint32_t off;
+        item_b(w, e, pnt, off);
+        const uint32_t base = ebase[e];
+        if (base != kInvalid)
+          ((eflags[e] & 2) ? post.out : post.partial)[base + off] = acc[pnt];
+      }
+  }
 
   // wave-local ordering of LDS traffic: the two cells of a wave exchange data only among the
   // lanes of that wave, which execute in lockstep; the LDS services one wave's operations in
@@ -304,43 +513,7 @@ namespace mgx
       }
     __syncthreads();
 
-    // write-out with the fused post-operation
-    for (int pnt = tid; pnt < G * G * G; pnt += C::THREADS)
-      {
-        const int gx = pnt % G, gy = (pnt / G) % G, gz = pnt / (G * G);
-        const int rx = gx % P, ry = gy % P, rz = gz % P;
-        const int ex = 2 * (gx / P) + (rx != 0), ey = 2 * (gy / P) + (ry != 0), ez = 2 * (gz / P) + (rz != 0);
-        const int nx = rx ? P - 1 : 1, ny = ry ? P - 1 : 1;
-        const int ox = rx ? rx - 1 : 0, oy2 = ry ? ry - 1 : 0, oz2 = rz ? rz - 1 : 0;
-        const int e  = (ez * E1 + ey) * E1 + ex;
-        const uint32_t base = ebase[e];
-        if (base == kInvalid)
-          continue;
-        const uint32_t idx = base + (uint32_t)((oz2 * ny + oy2) * nx + ox);
-        const uint8_t  fl  = eflags[e];
-        T              val = acc[pnt];
-        if (!(fl & 1))
-          val += post.partial[idx];
-        if (fl & 2)
-          {
-            if (MODE == kPlain)
-              post.out[idx] = val;
-            else if (MODE == kResidual)
-              post.out[idx] = post.a[idx] - val;
-            else
-              {
-                const T xi = src[idx];
-                T       xn = xi + post.f2 * post.b[idx] * (post.a[idx] - val);
-                if (MODE == kCheb)
-                  xn += post.f1 * (xi - post.out[idx]);
-                else if (MODE == kChebZeroOld)
-                  xn += post.f1 * xi;
-                post.out[idx] = xn;
-              }
-          }
-        else
-          post.partial[idx] = val;
-      }
+    store_brick<P, T, MODE>(tid, acc, ebase, eflags, src, post);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -461,7 +634,7 @@ namespace mgx
     gather(0, rn);
 
 #pragma unroll 1
-    for (int round = 0; round < 8; ++round)
+    for (int round = 0; round < ((MODE == kNoCompute || MODE == kInitOnly) ? 0 : 8); ++round)
       {
         T r[N], t1[N], k1[N], xe[H1], xo[H1];
         r[0] = (nvalid & 1u) ? rn[0] : T(0);
@@ -549,44 +722,13 @@ namespace mgx
       }
     __syncthreads();
 
-    // write-out with the fused post-operation; the point index advances by 256 = 15 G + 1 (G = 17)
-    // per iteration for p = 4, so the coordinates are updated incrementally where that is cheap
-    for (int pnt = tid; pnt < G * G * G; pnt += C::THREADS)
+    if (MODE == kNoStore || MODE == kInitOnly)
       {
-        const int gx = pnt % G, gy = (pnt / G) % G, gz = pnt / (G * G);
-        const int rx = gx % P, ry = gy % P, rz = gz % P;
-        const int ex = 2 * (gx / P) + (rx != 0), ey = 2 * (gy / P) + (ry != 0), ez = 2 * (gz / P) + (rz != 0);
-        const int nx = rx ? P - 1 : 1, ny = ry ? P - 1 : 1;
-        const int ox = rx ? rx - 1 : 0, oy2 = ry ? ry - 1 : 0, oz2 = rz ? rz - 1 : 0;
-        const int e  = (ez * E1 + ey) * E1 + ex;
-        const uint32_t base = ebase[e];
-        if (base == kInvalid)
-          continue;
-        const uint32_t idx = base + (uint32_t)((oz2 * ny + oy2) * nx + ox);
-        const uint8_t  fl  = eflags[e];
-        T              val = acc[pnt];
-        if (!(fl & 1))
-          val += post.partial[idx];
-        if (fl & 2)
-          {
-            if (MODE == kPlain)
-              post.out[idx] = val;
-            else if (MODE == kResidual)
-              post.out[idx] = post.a[idx] - val;
-            else
-              {
-                const T xi = src[idx];
-                T       xn = xi + post.f2 * post.b[idx] * (post.a[idx] - val);
-                if (MODE == kCheb)
-                  xn += post.f1 * (xi - post.out[idx]);
-                else if (MODE == kChebZeroOld)
-                  xn += post.f1 * xi;
-                post.out[idx] = xn;
-              }
-          }
-        else
-          post.partial[idx] = val;
+        if (acc[tid] == T(12345.678))
+          post.out[tid] = acc[tid]; // keep the rounds alive
+        return;
       }
+    store_brick<P, T, MODE>(tid, acc, ebase, eflags, src, post);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -600,14 +742,14 @@ namespace mgx
         const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
         if (count == 0)
           continue;
-        if (op.separable)
+        if (op.separable || MODE >= kNoStore)
           hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
                              bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
                              (T)op.coef[2], post);
         else
-          hipLaunchKernelGGL((brick_loop_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
-                             bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
-                             (T)op.coef[2], post);
+          hipLaunchKernelGGL((brick_loop_kernel<P, T, (MODE >= kNoStore ? 0 : MODE)>), dim3(count),
+                             dim3(C::THREADS), 0, s, src, first, bd.ent_base, bd.ent_flags,
+                             (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
       }
   }
 
@@ -630,6 +772,9 @@ namespace mgx
         case kResidual: brick_launch<PP, T, kResidual>(s, op, (const T *)src, post); break; \
         case kCheb: brick_launch<PP, T, kCheb>(s, op, (const T *)src, post); break; \
         case kChebFirst: brick_launch<PP, T, kChebFirst>(s, op, (const T *)src, post); break; \
+        case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post); break; \
+        case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post); break; \
+        case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post); break; \
         default: brick_launch<PP, T, kChebZeroOld>(s, op, (const T *)src, post); break; \
       }                                                                            \
     break;
