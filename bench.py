@@ -132,7 +132,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = ctx.profile_read()
+    prof = {form: ctx.profile_read(form) for form in range(5)}
     ctx.profile_enable(False)
     if dist is not None:
         import torch
@@ -155,10 +155,26 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     total_dofs = n_dofs * world
-    # dominant kernel: the finest-level fp64 cell loop; algorithmic bytes = 16 B/DoF (read src once,
-    # write dst once) x DoFs of one launch
-    avg_kernel_ms = kernel_ms / max(launches, 1)
-    achieved = 16.0 * n_dofs / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+    # Roofline of the dominant kernel.  Of the 7 finest-level cell loops of one step, 3 are the
+    # fused Chebyshev iteration (form 2: x, x_old, b, D^-1 read + x_new written = 5 accesses =
+    # 40 B/DoF algorithmic, the reference's own 5-access model, matvec_dg_cheby/program.cc:178);
+    # the plain matvec (form 0) moves 16 B/DoF algorithmic.  One application =
+    # n_colours launches, each over n_dofs / n_colours DoFs.
+    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0}
+    NAMES = {0: "kPlain", 1: "kResidual", 2: "kCheb", 3: "kChebFirst", 4: "kChebZeroOld"}
+
+    def roof(form):
+        launches, ms = prof[form]
+        if not launches:
+            return None
+        n_col = 8
+        avg = ms / launches
+        per_launch_bytes = ALG[form] * n_dofs / n_col
+        ach = per_launch_bytes / (avg * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "mgx::brick_sep_kernel<%d,double,%s> (finest level, per colour launch)"
+                % (args.degree, NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches, "avg_launch_ms": avg,
+                "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_bytes_per_dof": ALG[form]}
     out = {
         "metric": "DoFs/s for Laplace matvec + V-cycle, poisson_cube p=%d fp64" % args.degree,
         "value": total_dofs / (elapsed / args.steps),
@@ -173,10 +189,8 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else "%d independent replicas (no halo exchange yet)" % world},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
-        "roofline": {"bound": "hbm", "kernel": "mgx::cell_loop_kernel<%d,double> (finest level)" % args.degree,
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "launches": launches, "avg_launch_ms": avg_kernel_ms,
-                     "algorithmic_bytes_per_launch": 16.0 * n_dofs},
+        "roofline": roof(2) if vnum == mg.F64 else roof(0),
+        "roofline_matvec": roof(0),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

@@ -66,8 +66,13 @@ void *mgx_context_stream(mgx_context_t ctx);
  * poisson_cube/program.cc:281-296,347-354; here: HIP events on the context's stream around every
  * launch of the cell-loop kernel of the operators flagged with mgx_operator_set_profiled) ---- */
 int mgx_profile_enable(mgx_context_t ctx, int enable);
-/* synchronises, returns the number of bracketed launches and their summed duration, resets */
-int mgx_profile_read(mgx_context_t ctx, uint64_t *launches, double *total_ms);
+/* Synchronises and returns, for one form of the cell loop, the number of bracketed kernel launches
+ * and their summed duration; resets that form's record.  form: 0 plain vmult (16 B/DoF
+ * algorithmic: src read + dst write), 1 residual (24 B/DoF), 2 fused Chebyshev iteration
+ * (40 B/DoF: x, x_old, b, D^-1 read, x_new written), 3 first Chebyshev step (32 B/DoF),
+ * 4 Chebyshev iteration with zero x_old (32 B/DoF).  One bracket spans the colour launches of
+ * one application (8 on a structured mesh); `launches` counts the individual kernel launches. */
+int mgx_profile_read(mgx_context_t ctx, int form, uint64_t *launches, double *total_ms);
 
 /* ---- device vectors (LinearAlgebra::distributed::Vector<number> storage) ---- */
 int mgx_malloc(mgx_context_t ctx, void **dptr, size_t bytes);

@@ -41,10 +41,11 @@ class Context:
     def profile_enable(self, on=True):
         check(self.lib.mgx_profile_enable(self.h, int(on)))
 
-    def profile_read(self):
-        """(number of bracketed cell-loop launches, their summed duration in ms); resets"""
+    def profile_read(self, form):
+        """(kernel launches, summed duration in ms) of one form of the profiled cell loop:
+        0 plain vmult, 1 residual, 2 fused Chebyshev iteration, 3 first step, 4 zero x_old; resets"""
         n, ms = C.c_uint64(), C.c_double()
-        check(self.lib.mgx_profile_read(self.h, C.byref(n), C.byref(ms)))
+        check(self.lib.mgx_profile_read(self.h, form, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
     def close(self):

@@ -56,7 +56,7 @@ SIGNATURES = {
     "mgx_sync": (C.c_int, [vp]),
     "mgx_context_stream": (vp, [vp]),
     "mgx_profile_enable": (C.c_int, [vp, C.c_int]),
-    "mgx_profile_read": (C.c_int, [vp, C.POINTER(C.c_uint64), f64p]),
+    "mgx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64), f64p]),
     "mgx_operator_set_profiled": (C.c_int, [vp, C.c_int]),
     "mgx_malloc": (C.c_int, [vp, C.POINTER(vp), C.c_size_t]),
     "mgx_free": (C.c_int, [vp, vp]),

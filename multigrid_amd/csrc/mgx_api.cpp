@@ -89,7 +89,12 @@ struct mgx_context_s
   double     *result_host = nullptr; // pinned
   // cell-loop launch profiling (mgx_profile_*)
   bool                                        profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool, ev_used;
+  struct Bracket
+  {
+    hipEvent_t start, stop;
+    int        form, launches;
+  };
+  std::vector<Bracket> ev_pool, ev_used;
 };
 
 struct mgx_operator_s
@@ -150,10 +155,10 @@ namespace
   // HIP-event bracket around the cell loop of a profiled operator
   struct ProfileBracket
   {
-    mgx_context_t ctx;
-    bool          on;
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    ProfileBracket(mgx_operator_t op)
+    mgx_context_t          ctx;
+    bool                   on;
+    mgx_context_s::Bracket ev;
+    ProfileBracket(mgx_operator_t op, int form)
       : ctx(op->ctx)
       , on(op->ctx->profile && op->profiled)
     {
@@ -161,7 +166,7 @@ namespace
         return;
       if (ctx->ev_pool.empty())
         {
-          if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+          if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess)
             {
               on = false;
               return;
@@ -172,13 +177,15 @@ namespace
           ev = ctx->ev_pool.back();
           ctx->ev_pool.pop_back();
         }
-      (void)hipEventRecord(ev.first, ctx->stream);
+      ev.form     = form;
+      ev.launches = op->d.bricks.available() ? op->d.bricks.n_colours : 1;
+      (void)hipEventRecord(ev.start, ctx->stream);
     }
     ~ProfileBracket()
     {
       if (on)
         {
-          (void)hipEventRecord(ev.second, ctx->stream);
+          (void)hipEventRecord(ev.stop, ctx->stream);
           ctx->ev_used.push_back(ev);
         }
     }
@@ -188,7 +195,7 @@ namespace
   int apply_plain(mgx_operator_t op, void *dst, const void *src)
   {
     hipStream_t    s = op->ctx->stream;
-    ProfileBracket pb(op);
+    ProfileBracket pb(op, 0);
     if (op->d.bricks.available())
       {
         static const int ablate = std::getenv("MGX_BRICK_ABLATE") ? std::atoi(std::getenv("MGX_BRICK_ABLATE")) : 0;
@@ -311,8 +318,8 @@ int mgx_context_destroy(mgx_context_t ctx)
   for (auto *pool : {&ctx->ev_pool, &ctx->ev_used})
     for (auto &ev : *pool)
       {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
       }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -335,21 +342,29 @@ int mgx_profile_enable(mgx_context_t ctx, int enable)
   return MGX_OK;
 }
 
-int mgx_profile_read(mgx_context_t ctx, uint64_t *launches, double *total_ms)
+int mgx_profile_read(mgx_context_t ctx, int form, uint64_t *launches, double *total_ms)
 {
   MGX_REQUIRE(ctx && launches && total_ms, "mgx_profile_read: null argument");
   MGX_HIP(hipStreamSynchronize(ctx->stream));
-  double sum = 0;
+  double                              sum = 0;
+  uint64_t                            n   = 0;
+  std::vector<mgx_context_s::Bracket> keep;
   for (auto &ev : ctx->ev_used)
     {
+      if (ev.form != form)
+        {
+          keep.push_back(ev);
+          continue;
+        }
       float ms = 0;
-      MGX_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+      MGX_HIP(hipEventElapsedTime(&ms, ev.start, ev.stop));
       sum += ms;
+      n += (uint64_t)ev.launches;
       ctx->ev_pool.push_back(ev);
     }
-  *launches = ctx->ev_used.size();
+  ctx->ev_used.swap(keep);
+  *launches = n;
   *total_ms = sum;
-  ctx->ev_used.clear();
   return MGX_OK;
 }
 
@@ -670,7 +685,7 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
   if (op->d.bricks.available())
     {
       // zeroing (:617-623) and rhs - A lhs (:624-631) are fused into the brick loop
-      ProfileBracket pb(op);
+      ProfileBracket pb(op, 1);
       launch_brick_loop(s, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0.);
     }
   else
@@ -880,7 +895,7 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, vo
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
   {
-    ProfileBracket pb(op);
+    ProfileBracket pb(op, mode);
     launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2);
   }
   launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
@@ -1017,6 +1032,26 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
         }
     MGX_HIP(hipMalloc((void **)&tr->d.weight_shift, shift.size()));
     MGX_HIP(hipMemcpy(tr->d.weight_shift, shift.data(), shift.size(), hipMemcpyHostToDevice));
+    // ownership of the fine entities for the atomic-free prolongation: first cell in cell order
+    std::vector<uint32_t> own(fine->d.n_cells, 0u);
+    {
+      std::vector<uint8_t> seen(fine->d.n_dofs, 0);
+      for (uint32_t c = 0; c < fine->d.n_cells; ++c)
+        for (int e = 0; e < 27; ++e)
+          {
+            const int size = (e % 3 == 1 ? p - 1 : 1) * ((e / 3) % 3 == 1 ? p - 1 : 1) * (e / 9 == 1 ? p - 1 : 1);
+            if (size == 0)
+              continue;
+            const uint32_t base = idxf[27 * (size_t)c + e];
+            if (!seen[base])
+              {
+                seen[base] = 1;
+                own[c] |= 1u << e;
+              }
+          }
+    }
+    MGX_HIP(hipMalloc((void **)&tr->d.own27, sizeof(uint32_t) * own.size()));
+    MGX_HIP(hipMemcpy(tr->d.own27, own.data(), sizeof(uint32_t) * own.size(), hipMemcpyHostToDevice));
   }
   // 1D prolongation matrix into the coarse operator's basis block
   const size_t np1 = (size_t)(2 * p + 1) * n;
@@ -1042,6 +1077,7 @@ int mgx_transfer_destroy(mgx_transfer_t tr)
   (void)hipStreamSynchronize(tr->coarse->ctx->stream);
   (void)hipFree(tr->d.children);
   (void)hipFree(tr->d.weight_shift);
+  (void)hipFree(tr->d.own27);
   delete tr;
   return MGX_OK;
 }

@@ -76,6 +76,8 @@ namespace mgx
     const OperatorData *coarse = nullptr, *fine = nullptr;
     uint32_t           *children = nullptr;    // device [n_coarse_cells*8]
     uint8_t            *weight_shift = nullptr; // device [n_coarse_cells*27]: weight = 2^-shift
+    uint32_t           *own27 = nullptr;        // device [n_fine_cells]: bit e set iff the fine cell is
+                                                // the first (in cell order) containing its entity e
   };
 
   // ---- cell loops (mgx_kernels.hip) ----

@@ -318,7 +318,7 @@ namespace mgx
   __global__ void __launch_bounds__(TCfg<P>::THREADS)
     prolongate_kernel(T *__restrict__ fine, const T *__restrict__ coarse, const uint32_t *__restrict__ idx_c,
                       const uint32_t *__restrict__ idx_f, const uint32_t *__restrict__ children,
-                      const uint8_t *__restrict__ wshift, uint32_t n_parents, const Basis1D<T> *__restrict__ B,
+                      const uint32_t *__restrict__ own27, uint32_t n_parents, const Basis1D<T> *__restrict__ B,
                       int add)
   {
     constexpr int N = P + 1, M = 2 * P + 1;
@@ -374,7 +374,12 @@ namespace mgx
         out[o] = s;
       }
     __syncthreads();
-    // distribute to the 8 children
+    // distribute to the 8 children.  Every fine DoF is written by exactly one fine cell, the first
+    // cell (in cell order) that contains its entity (own27 bit mask, computed on the host from
+    // the index table).  The values the different parents/children compute for a shared DoF are
+    // bitwise identical (the 1D prolongation rows at coinciding nodes are exact unit vectors),
+    // so "owner writes once" equals deal.II's "every cell adds value/multiplicity" -- without
+    // atomics and bitwise reproducibly.
     for (int w = tid; w < 8 * N * N; w += nt)
       {
         const int      ch = w / (N * N), t = w % (N * N), j = t % N, k = t / N;
@@ -382,50 +387,32 @@ namespace mgx
         const int      ox = (ch & 1) * P, oy = ((ch >> 1) & 1) * P, oz = (ch >> 2) * P;
         const int      b = oy + j, c = oz + k;
         LineIndex<P>   L = line_index<P>(idx_f, fc, j, k);
+        int            cy, o1, cz, o2;
+        node_code<P>(j, cy, o1);
+        node_code<P>(k, cz, o2);
+        const uint32_t own = own27[fc] >> (9 * cz + 3 * cy); // bits 0,1,2: left, interior, right
         T              r[N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
           r[i] = out[(c * M + b) * M + ox + i];
-        if (!add)
+        if (L.b0 != kInvalid && (own & 1u))
           {
-            // overwrite: every child stores all its values; DoFs shared between children or
-            // parents receive bitwise identical values from each of them
-            if (L.b0 != kInvalid)
-              fine[L.b0 + L.off] = r[0];
-            if (L.b1 != kInvalid)
-              {
-#pragma unroll
-                for (int i = 0; i < P - 1; ++i)
-                  fine[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i] = r[1 + i];
-              }
-            if (L.b2 != kInvalid)
-              fine[L.b2 + L.off] = r[P];
+            T *p = fine + L.b0 + L.off;
+            *p   = add ? *p + r[0] : r[0];
           }
-        else
+        if (L.b1 != kInvalid && (own & 2u))
           {
-            // add: a patch point is distributed once per parent (by the first child holding
-            // it), weighted with 1/(number of parent patches sharing it)
-            const bool line_dup = (((ch >> 1) & 1) && j == 0) || ((ch >> 2) && k == 0);
-            if (line_dup)
-              continue;
-            const uint8_t *ws = wshift + 27u * (size_t)pc + 9 * patch_code<P>(c) + 3 * patch_code<P>(b);
 #pragma unroll
-            for (int i = 0; i < N; ++i)
+            for (int i = 0; i < P - 1; ++i)
               {
-                const int sh = ws[patch_code<P>(ox + i)];
-                r[i] *= T(1) / T(1 << sh);
+                T *p = fine + L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i;
+                *p   = add ? *p + r[1 + i] : r[1 + i];
               }
-            // i == 0 of an x-upper child duplicates i == p of its sibling
-            if (L.b0 != kInvalid && !(ch & 1))
-              unsafeAtomicAdd(&fine[L.b0 + L.off], r[0]);
-            if (L.b1 != kInvalid)
-              {
-#pragma unroll
-                for (int i = 0; i < P - 1; ++i)
-                  unsafeAtomicAdd(&fine[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i], r[1 + i]);
-              }
-            if (L.b2 != kInvalid)
-              unsafeAtomicAdd(&fine[L.b2 + L.off], r[P]);
+          }
+        if (L.b2 != kInvalid && (own & 4u))
+          {
+            T *p = fine + L.b2 + L.off;
+            *p   = add ? *p + r[P] : r[P];
           }
       }
   }
@@ -585,7 +572,7 @@ namespace mgx
     const OperatorData &c = *t.coarse, &f = *t.fine;
     const uint32_t     *idx_c = with_constraints ? c.idx27 : c.idx27_plain;
     hipLaunchKernelGGL((prolongate_kernel<P, T>), dim3(c.n_cells), dim3(TCfg<P>::THREADS), 0, s, (T *)fine,
-                       (const T *)coarse, idx_c, f.idx27_plain, t.children, t.weight_shift, c.n_cells,
+                       (const T *)coarse, idx_c, f.idx27_plain, t.children, t.own27, c.n_cells,
                        (const Basis1D<T> *)c.basis, add ? 1 : 0);
   }
 
