@@ -62,6 +62,46 @@ int mgx_sync(mgx_context_t ctx);
 /* raw HIP stream (hipStream_t) the context enqueues on, for callers that time with HIP events */
 void *mgx_context_stream(mgx_context_t ctx);
 
+/* ---- domain decomposition (replaces the MPI layer of deal.II's LinearAlgebra::distributed::Vector:
+ * ghost exchange inside every cell_loop, MPI_Allreduce in l2_norm / operator*).
+ * Interface DoFs are duplicated on the ranks that share them and kept consistent; after a cell
+ * loop the partial sums of the interface DoFs are exchanged and added (one exchange per operator
+ * application).  The transport is a pair of callbacks so that the same library runs over RCCL
+ * (torch.distributed "nccl", one process per GPU), over gloo (CPU tests) or over MPI (deal.II). */
+typedef struct
+{
+  int   rank, size;
+  void *user;
+  /* Blocking exchange of one plan: on entry every send buffer is complete (device memory,
+   * counts[k] entries of `number` type for neighbour ranks[k]) and the context's stream is idle;
+   * on return recv[k] must hold what rank ranks[k] put into its send buffer for this rank.
+   * Return 0 on success. */
+  int (*exchange)(void *user, int plan_id, int number, int n_neighbors, const int *ranks, const uint32_t *counts,
+                  void *const *send, void *const *recv);
+  /* in-place sum over all ranks of `count` doubles on the host */
+  int (*allreduce_sum)(void *user, double *values, int count);
+} mgx_comm_desc;
+int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm);
+
+/* exchange plan of one level vector layout (host lists, copied) */
+typedef struct
+{
+  int                    plan_id;       /* caller's identifier, passed back to exchange() */
+  int                    n_neighbors;
+  const int             *neighbor_rank; /* ascending */
+  const uint32_t        *count;         /* entries per neighbour */
+  const uint32_t *const *index;         /* index[k][i]: local DoF of entry i for neighbour k; both sides
+                                           enumerate an interface in the same (global) order */
+  const uint32_t        *shared;        /* union of the lists */
+  uint32_t               n_shared;
+  const uint32_t        *not_owned;     /* shared DoFs owned by a lower rank (skipped in dot products) */
+  uint32_t               n_not_owned;
+  /* optional caller-owned device buffers (count[k] entries of the operator's number type each),
+   * e.g. torch CUDA tensors handed to RCCL; NULL: the library allocates them */
+  void *const           *send_buf;
+  void *const           *recv_buf;
+} mgx_exchange_desc;
+
 /* ---- instrumentation (the reference brackets its phases with LIKWID markers,
  * poisson_cube/program.cc:281-296,347-354; here: HIP events on the context's stream around every
  * launch of the cell-loop kernel of the operators flagged with mgx_operator_set_profiled) ---- */
@@ -80,6 +120,7 @@ int mgx_free(mgx_context_t ctx, void *dptr);
 int mgx_upload(mgx_context_t ctx, void *dptr, const void *hptr, size_t bytes);
 int mgx_download(mgx_context_t ctx, void *hptr, const void *dptr, size_t bytes);
 int mgx_memset_zero(mgx_context_t ctx, void *dptr, size_t bytes); /* Vector::operator=(0) */
+int mgx_copy_device(mgx_context_t ctx, void *dst, const void *src, size_t bytes); /* device to device */
 
 /* vector kernels used by the driver; `number` = MGX_F32 / MGX_F64 */
 /* dst = src with precision cast: multigrid_solver.h:437,503,507 */
@@ -130,6 +171,13 @@ typedef struct
    * a colouring in which bricks that share DoFs differ.  Without the hint a greedy colouring is
    * computed; the brick structure itself is always verified against idx27. */
   const uint8_t *brick_colour;
+  /* Optional, may be NULL: a numbering-independent global index per local DoF (the provider's
+   * lexicographic grid id).  Used for the start vector of the smoother's eigenvalue estimate
+   * (deal.II: "global index mod 11"), so that results do not depend on cell order or on the
+   * domain decomposition.  NULL: the local index. */
+  const uint32_t *global_index;
+  /* Optional, may be NULL: interface exchange plan of a decomposed mesh */
+  const mgx_exchange_desc *exchange;
 } mgx_operator_desc;
 
 /* LaplaceOperator::initialize + evaluate_coefficient (laplace_operator.h:184-220, 357-432) */
@@ -137,6 +185,11 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
 int mgx_operator_destroy(mgx_operator_t op);
 uint32_t mgx_operator_n_dofs(mgx_operator_t op); /* Base::m() */
 int mgx_operator_set_profiled(mgx_operator_t op, int profiled);
+/* device buffers of neighbour k of the operator's exchange plan */
+int mgx_operator_exchange_buffers(mgx_operator_t op, int k, void **send, void **recv, uint32_t *count, int *rank);
+/* sums the duplicated interface entries of a level vector over the ranks that share them (in
+ * ascending rank order on every rank => bitwise identical copies): Vector::compress(add) */
+int mgx_exchange_add(mgx_operator_t op, void *vec);
 int mgx_operator_number(mgx_operator_t op);
 /* LaplaceOperator::vmult(dst, src) laplace_operator.h:573-601 */
 int mgx_vmult(mgx_operator_t op, void *dst, const void *src);
@@ -171,6 +224,10 @@ typedef struct
   const uint32_t *children;
   /* prolong_1d[a*(p+1)+i], a in [0,2p]: coarse 1D basis i at the fine patch point a */
   const double *prolong_1d;
+  /* optional, may be NULL: weight_shift[27*parent + e] = log2(multiplicity) of patch entity e
+   * (deal.II's weights_on_refined, 3^dim per cell); needed on a decomposed mesh where the
+   * multiplicity counts parents of other ranks.  NULL: computed from the local tables. */
+  const uint8_t *weight_shift;
 } mgx_transfer_desc;
 int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_transfer_desc *desc,
                         mgx_transfer_t *transfer);

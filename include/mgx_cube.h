@@ -27,6 +27,41 @@ extern "C" {
 typedef struct mgx_cube_s *mgx_cube_t;
 
 int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *cube);
+
+/* General form: a box of roots[0] x roots[1] x roots[2] cubic coarse cells of size h0 with lower
+ * corner (origin,origin,origin), refined n_refine times, distributed over a procs[0] x procs[1] x
+ * procs[2] process grid (rank = (pz*procs[1] + py)*procs[0] + px); every rank owns
+ * roots[d]/procs[d] coarse cells per direction on every level.  With roots = {1|2} per direction,
+ * origin = -1, h0 = 1.9 this is the reference's "doubling" mesh family
+ * (GridGenerator::subdivided_hyper_rectangle, poisson_cube/program.cc:509-529), which is also how
+ * the problem is scaled over several GPUs: one coarse cube per rank.
+ * Interface DoFs are duplicated on the ranks that share them; the lists below
+ * drive the exchange (mgx_exchange_desc in mgx.h). */
+typedef struct
+{
+  int    degree, n_refine;
+  int    roots[3];
+  double origin, h0;
+  int    procs[3];
+  int    rank;
+} mgx_cube_box_desc;
+int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
+int mgx_cube_rank(mgx_cube_t cube);
+int mgx_cube_size(mgx_cube_t cube);
+void mgx_cube_cells_per_dim3(mgx_cube_t cube, int level, uint32_t local[3], uint32_t global[3]);
+/* neighbours of this rank on a level, ascending rank; index lists are ordered by the global grid
+ * id of the DoF, so that both sides of an interface enumerate it identically */
+int             mgx_cube_n_neighbors(mgx_cube_t cube, int level);
+int             mgx_cube_neighbor_rank(mgx_cube_t cube, int level, int k);
+uint32_t        mgx_cube_neighbor_count(mgx_cube_t cube, int level, int k);
+const uint32_t *mgx_cube_neighbor_index(mgx_cube_t cube, int level, int k);
+/* union of the lists, and the subset owned by a lower rank (excluded from this rank's dot products) */
+uint32_t        mgx_cube_n_shared(mgx_cube_t cube, int level);
+const uint32_t *mgx_cube_shared(mgx_cube_t cube, int level);
+uint32_t        mgx_cube_n_not_owned(mgx_cube_t cube, int level);
+const uint32_t *mgx_cube_not_owned(mgx_cube_t cube, int level);
+/* level >= 1: log2 of the global multiplicity of the 27 patch entities of every parent cell */
+const uint8_t  *mgx_cube_weight_shift(mgx_cube_t cube, int level);
 int mgx_cube_destroy(mgx_cube_t cube);
 
 int      mgx_cube_n_levels(mgx_cube_t cube);
@@ -43,7 +78,7 @@ const uint32_t *mgx_cube_idx27_plain(mgx_cube_t cube, int level);
 const uint32_t *mgx_cube_constrained(mgx_cube_t cube, int level);
 const uint32_t *mgx_cube_children(mgx_cube_t cube, int level); /* level >= 1: [n_cells(level-1)*8] */
 const uint32_t *mgx_cube_cell_coords(mgx_cube_t cube, int level);
-/* dof -> lexicographic grid id ((gz*G+gy)*G+gx, G = N*p+1); computed on first use */
+/* dof -> GLOBAL lexicographic grid id ((gz*Gy+gy)*Gx+gx, G_d = N_d*p+1 of the whole mesh) */
 const uint32_t *mgx_cube_dof_grid(mgx_cube_t cube, int level);
 const double   *mgx_cube_shape_values(mgx_cube_t cube);
 const double   *mgx_cube_colloc_grad(mgx_cube_t cube);
@@ -61,10 +96,16 @@ const double   *mgx_cube_bc_value(mgx_cube_t cube, int level);
 
 /* fills desc for LaplaceOperator<3,p,number> on `level` (pointers stay owned by the cube) */
 int mgx_cube_operator_desc(mgx_cube_t cube, int level, int number, mgx_operator_desc *desc);
+/* fills the exchange plan of `level` for a decomposed mesh; the three scratch arrays (at least 26
+ * entries each) receive the per-neighbour pointers and must outlive the descriptor's use */
+int mgx_cube_exchange_desc(mgx_cube_t cube, int level, int plan_id, mgx_exchange_desc *desc,
+                           const uint32_t **index_scratch, int *rank_scratch, uint32_t *count_scratch);
 
 /* MultigridSolver::compute_l2_error (multigrid_solver.h:298-343) for a host copy of
  * solution[level] (boundary values already inserted) */
 double mgx_cube_l2_error(mgx_cube_t cube, int level, const double *solution_host);
+/* the two local sums (error^2 and volume) of the above, to be added over the ranks */
+void mgx_cube_l2_error_parts(mgx_cube_t cube, int level, const double *solution_host, double *err2, double *vol);
 
 /* seeded benchmark vector of SURVEY.md 8d: value depends only on the global grid index, uniform
  * in [-1,1) (splitmix64 of seed+grid id), written in the level's DoF numbering */

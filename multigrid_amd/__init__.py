@@ -17,7 +17,97 @@ from . import _lib
 from ._lib import F32, F64, INVALID_INDEX, MgxError, check
 
 __all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
-           "F32", "F64", "INVALID_INDEX", "MgxError"]
+           "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError"]
+
+
+def process_grid(size):
+    """1 / 2x1x1 / 2x2x1 / 2x2x2; generally the most cubic power-of-two grid"""
+    procs = [1, 1, 1]
+    d = 0
+    while size > 1:
+        if size % 2:
+            raise ValueError("number of ranks must be a power of two")
+        procs[d] *= 2
+        size //= 2
+        d = (d + 1) % 3
+    return tuple(procs)
+
+
+class Communicator:
+    """Transport of the interface exchange and of the scalar reductions (mgx_comm_desc) on top of
+    torch.distributed: backend "nccl" (= RCCL over xGMI, one process per GPU) or "gloo" (CPU
+    processes; used by the tests, also with several processes sharing one GPU).
+
+    exchange(plan): the library has packed its send buffers (device memory); they are delivered
+    with one batch of point-to-point operations (at most 7 neighbours in a 2x2x2 process grid,
+    each a direct xGMI peer)."""
+
+    def __init__(self, ctx, dist, device_transport=None):
+        self.ctx, self.dist = ctx, dist
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.device_transport = (dist.get_backend() == "nccl") if device_transport is None else device_transport
+        self._ex = _lib.EXCHANGE_FN(self._exchange)
+        self._ar = _lib.ALLREDUCE_FN(self._allreduce)
+        self.desc = _lib.CommDesc(self.rank, self.size, None, self._ex, self._ar)
+        check(ctx.lib.mgx_context_set_comm(ctx.h, C.byref(self.desc)))
+        ctx._comm = self  # keep the callbacks alive
+
+    def _exchange(self, user, plan_id, number, n_neighbors, ranks, counts, send, recv):
+        try:
+            import torch
+            dt = torch.float64 if number == F64 else torch.float32
+            es = 8 if number == F64 else 4
+            lib, h = self.ctx.lib, self.ctx.h
+            ops, bufs = [], []
+            for k in range(n_neighbors):
+                rk, cnt = ranks[k], counts[k]
+                if self.device_transport:
+                    st = torch.empty(cnt, dtype=dt, device="cuda")
+                    rt = torch.empty(cnt, dtype=dt, device="cuda")
+                    check(lib.mgx_copy_device(h, C.c_void_p(st.data_ptr()), C.c_void_p(send[k]), cnt * es))
+                else:
+                    st = torch.empty(cnt, dtype=dt)
+                    rt = torch.empty(cnt, dtype=dt)
+                    check(lib.mgx_download(h, C.c_void_p(st.data_ptr()), C.c_void_p(send[k]), cnt * es))
+                bufs.append((st, rt, recv[k], cnt))
+                ops.append(self.dist.P2POp(self.dist.isend, st, rk))
+                ops.append(self.dist.P2POp(self.dist.irecv, rt, rk))
+            if ops:
+                for req in self.dist.batch_isend_irecv(ops):
+                    req.wait()
+            if self.device_transport:
+                torch.cuda.synchronize()
+            for (st, rt, rbuf, cnt) in bufs:
+                if self.device_transport:
+                    check(lib.mgx_copy_device(h, C.c_void_p(rbuf), C.c_void_p(rt.data_ptr()), cnt * es))
+                else:
+                    check(lib.mgx_upload(h, C.c_void_p(rbuf), C.c_void_p(rt.data_ptr()), cnt * es))
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            print("mgx Communicator.exchange failed:", repr(e), file=sys.stderr, flush=True)
+            return 1
+
+    def _allreduce(self, user, values, count):
+        try:
+            import torch
+            a = np.ctypeslib.as_array(values, shape=(count,))
+            t = torch.from_numpy(a.copy())
+            if self.device_transport:
+                t = t.cuda()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception as e:
+            import sys
+            print("mgx Communicator.allreduce failed:", repr(e), file=sys.stderr, flush=True)
+            return 1
+
+    def allreduce(self, values):
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        if self._allreduce(None, a.ctypes.data_as(_lib.f64p), a.size) != 0:
+            raise RuntimeError("allreduce failed")
+        return a
 
 _DT = {F32: np.float32, F64: np.float64}
 
@@ -116,11 +206,20 @@ class DeviceVector:
 class Cube:
     """Host-side discretisation of poisson_cube (include/mgx_cube.h): what deal.II supplies."""
 
-    def __init__(self, degree, n_subdiv=1, n_refine=3):
+    def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0):
+        """box=None: the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction.
+        box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1),
+        program.cc:509-529), optionally distributed over the process grid `procs`; this rank owns
+        box[d]/procs[d] coarse cells per direction."""
         self.lib = _lib.load()
         h = C.c_void_p()
-        check(self.lib.mgx_cube_create(degree, n_subdiv, n_refine, C.byref(h)))
+        if box is None:
+            check(self.lib.mgx_cube_create(degree, n_subdiv, n_refine, C.byref(h)))
+        else:
+            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), -1.0, 1.9, (C.c_int * 3)(*procs), rank)
+            check(self.lib.mgx_cube_create_box(C.byref(d), C.byref(h)))
         self.h = h
+        self.rank, self.size = self.lib.mgx_cube_rank(h), self.lib.mgx_cube_size(h)
         self.degree = degree
         self.n_levels = self.lib.mgx_cube_n_levels(h)
         self.max_level = self.n_levels - 1
@@ -146,10 +245,11 @@ class Cube:
         return self.lib.mgx_cube_cell_size(self.h, l)
 
     def _arr(self, fn, shape, *args):
-        p = getattr(self.lib, fn)(self.h, *args)
+        f = getattr(self.lib, fn)
+        p = f(self.h, *args)
         n = int(np.prod(shape))
         if n == 0:
-            return np.zeros(shape, dtype=np.uint32 if "u32" in str(type(p)) else np.float64)
+            return np.zeros(shape, dtype=np.dtype(f.restype._type_))
         return np.ctypeslib.as_array(p, shape=(n,)).reshape(shape).copy()
 
     def idx27(self, l):
@@ -197,6 +297,32 @@ class Cube:
     def bc(self, l):
         n = self.lib.mgx_cube_bc_count(self.h, l)
         return self._arr("mgx_cube_bc_index", (n,), l), self._arr("mgx_cube_bc_value", (n,), l)
+
+    def neighbors(self, l):
+        """[(rank, index array)] of the interface exchange on level l (ascending rank)"""
+        out = []
+        for k in range(self.lib.mgx_cube_n_neighbors(self.h, l)):
+            n = self.lib.mgx_cube_neighbor_count(self.h, l, k)
+            out.append((self.lib.mgx_cube_neighbor_rank(self.h, l, k),
+                        self._arr("mgx_cube_neighbor_index", (n,), l, k)))
+        return out
+
+    def shared(self, l):
+        return self._arr("mgx_cube_shared", (self.lib.mgx_cube_n_shared(self.h, l),), l)
+
+    def not_owned(self, l):
+        return self._arr("mgx_cube_not_owned", (self.lib.mgx_cube_n_not_owned(self.h, l),), l)
+
+    def cells_per_dim3(self, l):
+        a, b = (C.c_uint32 * 3)(), (C.c_uint32 * 3)()
+        self.lib.mgx_cube_cells_per_dim3(self.h, l, C.byref(a), C.byref(b))
+        return tuple(a), tuple(b)
+
+    def l2_error_parts(self, l, solution):
+        s = np.ascontiguousarray(solution, dtype=np.float64)
+        e, v = C.c_double(), C.c_double()
+        self.lib.mgx_cube_l2_error_parts(self.h, l, s.ctypes.data_as(_lib.f64p), C.byref(e), C.byref(v))
+        return e.value, v.value
 
     def operator_desc(self, l, number=F64):
         d = _lib.OperatorDesc()
@@ -325,11 +451,15 @@ class MultigridSolver:
     ctor arguments follow the reference: (dof_handler -> cube, degree_pre, degree_post, n_cycles);
     `vcycle_number` is the template parameter Number (program.cc:76: float; BASELINE: double)."""
 
-    def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64):
+    def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64, comm=None):
         assert degree_pre == degree_post  # multigrid_solver.h:126
         self.ctx, self.cube, self.lib = ctx, cube, ctx.lib
         self.vnumber = vcycle_number
+        self.comm = comm
         self.s = _lib.CubeSolver()
+        if cube.size > 1:
+            if comm is None:
+                raise ValueError("a decomposed cube needs a Communicator")
         check(self.lib.mgx_cube_solver_create(ctx.h, cube.h, vcycle_number, degree_pre, n_cycles, C.byref(self.s)))
         self.n_levels = self.s.n_levels
         self.max_level = self.n_levels - 1
@@ -383,7 +513,11 @@ class MultigridSolver:
 
     def compute_l2_error(self, level=None):
         level = self.max_level if level is None else level
-        return self.cube.l2_error(level, self.get_solution(level, True).download())
+        sol = self.get_solution(level, True).download()
+        if self.cube.size == 1:
+            return self.cube.l2_error(level, sol)
+        e, v = self.comm.allreduce(self.cube.l2_error_parts(level, sol))
+        return float(np.sqrt(e / v))
 
     def enable_timings(self, on=True):
         check(self.lib.mgx_solver_enable_timings(self.h, int(on)))

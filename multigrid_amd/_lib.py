@@ -18,11 +18,33 @@ u32p = C.POINTER(C.c_uint32)
 f64p = C.POINTER(C.c_double)
 
 
+class ExchangeDesc(C.Structure):
+    _fields_ = [("plan_id", C.c_int), ("n_neighbors", C.c_int), ("neighbor_rank", C.POINTER(C.c_int)),
+                ("count", u32p), ("index", C.POINTER(u32p)), ("shared", u32p), ("n_shared", C.c_uint32),
+                ("not_owned", u32p), ("n_not_owned", C.c_uint32), ("send_buf", C.POINTER(vp)),
+                ("recv_buf", C.POINTER(vp))]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), u32p, C.POINTER(vp), C.POINTER(vp))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, f64p, C.c_int)
+
+
+class CommDesc(C.Structure):
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", vp), ("exchange", EXCHANGE_FN),
+                ("allreduce_sum", ALLREDUCE_FN)]
+
+
+class CubeBoxDesc(C.Structure):
+    _fields_ = [("degree", C.c_int), ("n_refine", C.c_int), ("roots", C.c_int * 3), ("origin", C.c_double),
+                ("h0", C.c_double), ("procs", C.c_int * 3), ("rank", C.c_int)]
+
+
 class OperatorDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("number", C.c_int), ("n_cells", C.c_uint32), ("n_dofs", C.c_uint32),
                 ("idx27", u32p), ("idx27_plain", u32p), ("constrained", u32p), ("n_constrained", C.c_uint32),
                 ("coef", C.c_double * 6), ("shape_values", f64p), ("colloc_grad", f64p), ("qweights", f64p),
-                ("brick_colour", C.POINTER(C.c_uint8))]
+                ("brick_colour", C.POINTER(C.c_uint8)), ("global_index", u32p),
+                ("exchange", C.POINTER(ExchangeDesc))]
 
 
 class SmootherInfo(C.Structure):
@@ -31,7 +53,7 @@ class SmootherInfo(C.Structure):
 
 
 class TransferDesc(C.Structure):
-    _fields_ = [("children", u32p), ("prolong_1d", f64p)]
+    _fields_ = [("children", u32p), ("prolong_1d", f64p), ("weight_shift", C.POINTER(C.c_uint8))]
 
 
 class SolverDesc(C.Structure):
@@ -55,6 +77,10 @@ SIGNATURES = {
     "mgx_context_destroy": (C.c_int, [vp]),
     "mgx_sync": (C.c_int, [vp]),
     "mgx_context_stream": (vp, [vp]),
+    "mgx_context_set_comm": (C.c_int, [vp, C.POINTER(CommDesc)]),
+    "mgx_copy_device": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "mgx_operator_exchange_buffers": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(C.c_int)]),
+    "mgx_exchange_add": (C.c_int, [vp, vp]),
     "mgx_profile_enable": (C.c_int, [vp, C.c_int]),
     "mgx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64), f64p]),
     "mgx_operator_set_profiled": (C.c_int, [vp, C.c_int]),
@@ -100,6 +126,22 @@ SIGNATURES = {
     "mgx_solver_enable_timings": (C.c_int, [vp, C.c_int]),
     # mgx_cube.h
     "mgx_cube_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "mgx_cube_create_box": (C.c_int, [C.POINTER(CubeBoxDesc), C.POINTER(vp)]),
+    "mgx_cube_rank": (C.c_int, [vp]),
+    "mgx_cube_size": (C.c_int, [vp]),
+    "mgx_cube_cells_per_dim3": (None, [vp, C.c_int, C.POINTER(C.c_uint32 * 3), C.POINTER(C.c_uint32 * 3)]),
+    "mgx_cube_n_neighbors": (C.c_int, [vp, C.c_int]),
+    "mgx_cube_neighbor_rank": (C.c_int, [vp, C.c_int, C.c_int]),
+    "mgx_cube_neighbor_count": (C.c_uint32, [vp, C.c_int, C.c_int]),
+    "mgx_cube_neighbor_index": (u32p, [vp, C.c_int, C.c_int]),
+    "mgx_cube_n_shared": (C.c_uint32, [vp, C.c_int]),
+    "mgx_cube_shared": (u32p, [vp, C.c_int]),
+    "mgx_cube_n_not_owned": (C.c_uint32, [vp, C.c_int]),
+    "mgx_cube_not_owned": (u32p, [vp, C.c_int]),
+    "mgx_cube_weight_shift": (C.POINTER(C.c_uint8), [vp, C.c_int]),
+    "mgx_cube_exchange_desc": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(ExchangeDesc), C.POINTER(u32p),
+                                        C.POINTER(C.c_int), u32p]),
+    "mgx_cube_l2_error_parts": (None, [vp, C.c_int, f64p, f64p, f64p]),
     "mgx_cube_destroy": (C.c_int, [vp]),
     "mgx_cube_n_levels": (C.c_int, [vp]),
     "mgx_cube_degree": (C.c_int, [vp]),

@@ -80,6 +80,19 @@ namespace
   while (0)
 } // namespace
 
+struct ExchangePlan
+{
+  int                    plan_id = 0, number = MGX_F64, self_pos = 0;
+  std::vector<int>       rank;
+  std::vector<uint32_t>  count;
+  std::vector<uint32_t *> index_dev;
+  std::vector<void *>    send, recv;
+  std::vector<uint8_t>   owns_buffers;
+  uint32_t              *shared_dev = nullptr, *not_owned_dev = nullptr;
+  uint32_t               n_shared = 0, n_not_owned = 0;
+  void                  *own_buf = nullptr;
+};
+
 struct mgx_context_s
 {
   int         device = 0;
@@ -95,6 +108,10 @@ struct mgx_context_s
     int        form, launches;
   };
   std::vector<Bracket> ev_pool, ev_used;
+  // domain decomposition
+  bool                                      has_comm = false;
+  mgx_comm_desc                             comm{};
+  std::vector<std::pair<size_t, struct ExchangePlan *>> plans; // (vector length, plan) for dot products
 };
 
 struct mgx_operator_s
@@ -104,6 +121,9 @@ struct mgx_operator_s
   double        S[kMaxN * kMaxN], D[kMaxN * kMaxN], w[kMaxN];
   bool          has_diag = false;
   bool          profiled = false;
+  uint32_t     *global_index_dev = nullptr; // optional numbering-independent index (smoother start vector)
+  double        start_sum = 0, start_count = 0; // sum of (index mod 11) and number of the owned DoFs
+  std::unique_ptr<ExchangePlan> plan;       // interface exchange of a decomposed mesh
 };
 
 struct mgx_smoother_s
@@ -117,6 +137,7 @@ struct mgx_transfer_s
 {
   mgx_operator_t coarse = nullptr, fine = nullptr;
   TransferData   d;
+  void          *scratch = nullptr; // decomposed mesh: coarse-level scratch of restrict_and_add
 };
 
 struct mgx_solver_s
@@ -146,10 +167,56 @@ namespace
     return MGX_OK;
   }
 
+  // x.y over the DoFs this rank owns, summed over the ranks (Vector::operator* / l2_norm with
+  // MPI_Allreduce in the reference).  The exchange plan is looked up by the vector length.
   int dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *out)
   {
     launch_dot(ctx->stream, number, x, y, n, ctx->partial_dev, ctx->result_dev);
-    return read_result(ctx, out);
+    MGX_TRY(read_result(ctx, out));
+    if (!ctx->has_comm)
+      return MGX_OK;
+    for (auto &pr : ctx->plans)
+      if (pr.first == n && pr.second->n_not_owned > 0)
+        {
+          double dup = 0;
+          launch_dot_list(ctx->stream, number, x, y, pr.second->not_owned_dev, pr.second->n_not_owned,
+                          ctx->partial_dev, ctx->result_dev);
+          MGX_TRY(read_result(ctx, &dup));
+          *out -= dup;
+          break;
+        }
+    if (ctx->comm.allreduce_sum(ctx->comm.user, out, 1) != 0)
+      return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+    return MGX_OK;
+  }
+
+  // Vector::compress(add) for duplicated interface DoFs: every rank ends up with the sum of all
+  // sharers' entries, added in ascending rank order on every rank (bitwise identical copies).
+  int exchange_add(mgx_operator_t op, void *vec)
+  {
+    ExchangePlan *P = op->plan.get();
+    if (!P)
+      return MGX_OK;
+    mgx_context_t ctx = op->ctx;
+    hipStream_t   s   = ctx->stream;
+    const int     num = op->d.number;
+    for (size_t k = 0; k < P->rank.size(); ++k)
+      launch_pack(s, num, P->send[k], vec, P->index_dev[k], P->count[k]);
+    launch_pack(s, num, P->own_buf, vec, P->shared_dev, P->n_shared);
+    launch_constrained_set(s, num, vec, 0.0, P->shared_dev, P->n_shared);
+    MGX_HIP(hipStreamSynchronize(s));
+    if (ctx->comm.exchange(ctx->comm.user, P->plan_id, num, (int)P->rank.size(), P->rank.data(), P->count.data(),
+                           P->send.data(), P->recv.data()) != 0)
+      return fail(MGX_ERR_HIP, "exchange callback failed");
+    for (size_t k = 0; k <= P->rank.size(); ++k)
+      {
+        if ((int)k == P->self_pos)
+          launch_unpack_add(s, num, vec, P->own_buf, P->shared_dev, P->n_shared);
+        if (k < P->rank.size())
+          launch_unpack_add(s, num, vec, P->recv[k], P->index_dev[k], P->count[k]);
+      }
+    MGX_HIP(hipGetLastError());
+    return MGX_OK;
   }
 
   // HIP-event bracket around the cell loop of a profiled operator
@@ -207,7 +274,7 @@ namespace
         MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
         launch_cell_loop(s, op->d, dst, src);
       }
-    return MGX_OK;
+    return exchange_add(op, dst); // no-op on a single rank
   }
 
   struct Stopwatch
@@ -334,6 +401,27 @@ int mgx_sync(mgx_context_t ctx)
 }
 
 void *mgx_context_stream(mgx_context_t ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm)
+{
+  MGX_REQUIRE(ctx && comm && comm->exchange && comm->allreduce_sum && comm->size >= 1 && comm->rank >= 0 &&
+                comm->rank < comm->size,
+              "mgx_context_set_comm: bad communicator");
+  ctx->comm     = *comm;
+  ctx->has_comm = comm->size > 1;
+  return MGX_OK;
+}
+
+int mgx_copy_device(mgx_context_t ctx, void *dst, const void *src, size_t bytes)
+{
+  MGX_REQUIRE(ctx && (bytes == 0 || (dst && src)), "mgx_copy_device: null argument");
+  if (bytes)
+    {
+      MGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      MGX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  return MGX_OK;
+}
 
 int mgx_profile_enable(mgx_context_t ctx, int enable)
 {
@@ -618,7 +706,9 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
     {
       BrickHost   bh;
       std::string why;
-      if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour, bh, why))
+      const mgx_exchange_desc *ex = desc->exchange;
+      if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour,
+                       ex ? ex->shared : nullptr, ex ? ex->n_shared : 0, bh, why))
         {
           BrickData &b = d.bricks;
           b.n_bricks   = bh.n_bricks;
@@ -635,8 +725,101 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       else
         MGX_TRACE("operator_create: per-cell kernel (%s)", why.c_str());
     }
+  // smoother start vector statistics over the DoFs this rank owns
+  {
+    std::vector<uint8_t> skip(desc->n_dofs, 0);
+    if (desc->exchange)
+      for (uint32_t i = 0; i < desc->exchange->n_not_owned; ++i)
+        skip[desc->exchange->not_owned[i]] = 1;
+    double sum = 0, cnt = 0;
+    for (uint32_t i = 0; i < desc->n_dofs; ++i)
+      if (!skip[i])
+        {
+          sum += (double)((desc->global_index ? desc->global_index[i] : i) % 11u);
+          cnt += 1;
+        }
+    op->start_sum   = sum;
+    op->start_count = cnt;
+  }
+  if (desc->global_index)
+    {
+      MGX_HIP(hipMalloc((void **)&op->global_index_dev, sizeof(uint32_t) * desc->n_dofs));
+      MGX_HIP(hipMemcpy(op->global_index_dev, desc->global_index, sizeof(uint32_t) * desc->n_dofs,
+                        hipMemcpyHostToDevice));
+    }
+  if (desc->exchange)
+    {
+      const mgx_exchange_desc &e = *desc->exchange;
+      MGX_REQUIRE(ctx->has_comm, "mgx_operator_create: exchange plan given but no communicator set on the context");
+      MGX_REQUIRE(e.n_neighbors >= 0 && (e.n_neighbors == 0 || (e.neighbor_rank && e.count && e.index)),
+                  "mgx_operator_create: incomplete exchange plan");
+      auto P     = std::make_unique<ExchangePlan>();
+      P->plan_id = e.plan_id;
+      P->number  = d.number;
+      const size_t es = number_size(d.number);
+      for (int k = 0; k < e.n_neighbors; ++k)
+        {
+          MGX_REQUIRE(e.neighbor_rank[k] != ctx->comm.rank && (k == 0 || e.neighbor_rank[k] > e.neighbor_rank[k - 1]),
+                      "mgx_operator_create: neighbour ranks must be ascending and differ from the own rank");
+          for (uint32_t i = 0; i < e.count[k]; ++i)
+            if (e.index[k][i] >= desc->n_dofs)
+              return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: exchange index out of range");
+          if (e.neighbor_rank[k] < ctx->comm.rank)
+            P->self_pos = k + 1;
+          P->rank.push_back(e.neighbor_rank[k]);
+          P->count.push_back(e.count[k]);
+          uint32_t *idx = nullptr;
+          MGX_HIP(hipMalloc((void **)&idx, sizeof(uint32_t) * (e.count[k] + 1)));
+          MGX_HIP(hipMemcpy(idx, e.index[k], sizeof(uint32_t) * e.count[k], hipMemcpyHostToDevice));
+          P->index_dev.push_back(idx);
+          void *sb = e.send_buf ? e.send_buf[k] : nullptr, *rb = e.recv_buf ? e.recv_buf[k] : nullptr;
+          const bool own = !(sb && rb);
+          if (own)
+            {
+              MGX_HIP(hipMalloc(&sb, es * (e.count[k] + 1)));
+              MGX_HIP(hipMalloc(&rb, es * (e.count[k] + 1)));
+            }
+          P->send.push_back(sb);
+          P->recv.push_back(rb);
+          P->owns_buffers.push_back(own ? 1 : 0);
+        }
+      for (uint32_t i = 0; i < e.n_shared; ++i)
+        if (e.shared[i] >= desc->n_dofs)
+          return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: shared index out of range");
+      P->n_shared    = e.n_shared;
+      P->n_not_owned = e.n_not_owned;
+      MGX_HIP(hipMalloc((void **)&P->shared_dev, sizeof(uint32_t) * (e.n_shared + 1)));
+      MGX_HIP(hipMalloc((void **)&P->not_owned_dev, sizeof(uint32_t) * (e.n_not_owned + 1)));
+      MGX_HIP(hipMalloc(&P->own_buf, es * (e.n_shared + 1)));
+      if (e.n_shared)
+        MGX_HIP(hipMemcpy(P->shared_dev, e.shared, sizeof(uint32_t) * e.n_shared, hipMemcpyHostToDevice));
+      if (e.n_not_owned)
+        MGX_HIP(hipMemcpy(P->not_owned_dev, e.not_owned, sizeof(uint32_t) * e.n_not_owned, hipMemcpyHostToDevice));
+      ctx->plans.push_back({(size_t)desc->n_dofs, P.get()});
+      op->plan = std::move(P);
+    }
   *out = op.release();
   return MGX_OK;
+}
+
+int mgx_operator_exchange_buffers(mgx_operator_t op, int k, void **send, void **recv, uint32_t *count, int *rank)
+{
+  MGX_REQUIRE(op && op->plan && k >= 0 && k < (int)op->plan->rank.size(), "mgx_operator_exchange_buffers: bad argument");
+  if (send)
+    *send = op->plan->send[k];
+  if (recv)
+    *recv = op->plan->recv[k];
+  if (count)
+    *count = op->plan->count[k];
+  if (rank)
+    *rank = op->plan->rank[k];
+  return MGX_OK;
+}
+
+int mgx_exchange_add(mgx_operator_t op, void *vec)
+{
+  MGX_REQUIRE(op && vec, "mgx_exchange_add: null argument");
+  return exchange_add(op, vec);
 }
 
 int mgx_operator_destroy(mgx_operator_t op)
@@ -651,6 +834,26 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.inv_diag);
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
+  (void)hipFree(op->global_index_dev);
+  if (op->plan)
+    {
+      ExchangePlan *P = op->plan.get();
+      auto         &v = op->ctx->plans;
+      v.erase(std::remove_if(v.begin(), v.end(), [P](const std::pair<size_t, ExchangePlan *> &x) { return x.second == P; }),
+              v.end());
+      for (size_t k = 0; k < P->rank.size(); ++k)
+        {
+          (void)hipFree(P->index_dev[k]);
+          if (P->owns_buffers[k])
+            {
+              (void)hipFree(P->send[k]);
+              (void)hipFree(P->recv[k]);
+            }
+        }
+      (void)hipFree(P->shared_dev);
+      (void)hipFree(P->not_owned_dev);
+      (void)hipFree(P->own_buf);
+    }
   delete op;
   return MGX_OK;
 }
@@ -685,8 +888,16 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
   if (op->d.bricks.available())
     {
       // zeroing (:617-623) and rhs - A lhs (:624-631) are fused into the brick loop
-      ProfileBracket pb(op, 1);
-      launch_brick_loop(s, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0.);
+      {
+        ProfileBracket pb(op, 1);
+        launch_brick_loop(s, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0.);
+      }
+      if (op->plan)
+        {
+          // interface DoFs hold partial sums of A lhs: complete them, then rhs - (.)
+          MGX_TRY(exchange_add(op, res));
+          launch_list_residual(s, op->d.number, res, rhs, op->plan->shared_dev, op->plan->n_shared);
+        }
     }
   else
     {
@@ -722,6 +933,7 @@ int mgx_compute_diagonal(mgx_operator_t op)
     }
   MGX_HIP(hipMemsetAsync(op->d.inv_diag, 0, number_size(op->d.number) * op->d.n_dofs, s));
   launch_cell_diagonal(s, op->d, op->d.inv_diag, a1d, m1d);
+  MGX_TRY(exchange_add(op, op->d.inv_diag)); // Vector::compress(add) of the reference's cell_loop
   // set_constrained_entries_to_one + invert (laplace_operator.h:757-765)
   launch_constrained_set(s, op->d.number, op->d.inv_diag, 1.0, op->d.constrained, op->d.n_constrained);
   launch_invert(s, op->d.number, op->d.inv_diag, op->d.n_dofs);
@@ -762,20 +974,11 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
   MGX_HIP(hipMalloc(&z, bytes));
   MGX_HIP(hipMalloc(&d, bytes));
   {
-    std::vector<double> v(n);
-    double              mean = 0;
-    for (size_t i = 0; i < n; ++i)
-      mean += (double)(i % 11);
-    mean /= (double)n;
-    for (size_t i = 0; i < n; ++i)
-      v[i] = (double)(i % 11) - mean;
-    if (num == MGX_F64)
-      MGX_HIP(hipMemcpy(r, v.data(), bytes, hipMemcpyHostToDevice));
-    else
-      {
-        std::vector<float> vf(v.begin(), v.end());
-        MGX_HIP(hipMemcpy(r, vf.data(), bytes, hipMemcpyHostToDevice));
-      }
+    // deal.II: v_i = (global index of i) mod 11 minus the global mean
+    double sc[2] = {op->start_sum, op->start_count};
+    if (ctx->has_comm && ctx->comm.allreduce_sum(ctx->comm.user, sc, 2) != 0)
+      return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+    launch_index_mod11(s, num, r, op->global_index_dev, sc[0] / sc[1], n);
   }
   MGX_HIP(hipMemsetAsync(x, 0, bytes, s));
   std::vector<double> diag, off;
@@ -789,7 +992,10 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
       ++it;
       rz_old = rz;
       launch_jacobi_dot(s, num, z, op->d.inv_diag, r, n, ctx->partial_dev, ctx->result_dev);
-      MGX_TRY(read_result(ctx, &rz));
+      if (ctx->has_comm)
+        MGX_TRY(dot(ctx, num, r, z, n, &rz));
+      else
+        MGX_TRY(read_result(ctx, &rz));
       if (it > 1)
         {
           beta = rz / rz_old;
@@ -803,7 +1009,10 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
       MGX_TRY(dot(ctx, num, d, h, n, &dh));
       alpha = rz / dh;
       launch_cg_update(s, num, x, r, d, h, alpha, n, ctx->partial_dev, ctx->result_dev);
-      MGX_TRY(read_result(ctx, &res));
+      if (ctx->has_comm)
+        MGX_TRY(dot(ctx, num, r, r, n, &res)); // duplicated interface DoFs must count once
+      else
+        MGX_TRY(read_result(ctx, &res));
       res = std::sqrt(res);
       if (it == 1)
         diag.push_back(1. / alpha);
@@ -898,6 +1107,14 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, vo
     ProfileBracket pb(op, mode);
     launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2);
   }
+  if (op->plan)
+    {
+      // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the
+      // update there
+      MGX_TRY(exchange_add(op, sm->tmp));
+      launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
+                              op->plan->n_shared, sm->tmp);
+    }
   launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
                           op->d.n_constrained);
   MGX_HIP(hipGetLastError());
@@ -1030,6 +1247,17 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
             return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: fine DoF multiplicity is not 1/2/4/8");
           shift[27 * (size_t)pc + e] = c == 1 ? 0 : (c == 2 ? 1 : (c == 4 ? 2 : 3));
         }
+    if (desc->weight_shift) // multiplicities that count the parents of other ranks as well
+      {
+        for (size_t i = 0; i < shift.size(); ++i)
+          {
+            if (desc->weight_shift[i] > 3 || desc->weight_shift[i] < shift[i])
+              return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_transfer_create: inconsistent weight_shift");
+            shift[i] = desc->weight_shift[i];
+          }
+      }
+    else if (coarse->plan)
+      return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_transfer_create: a decomposed mesh needs the global weight_shift");
     MGX_HIP(hipMalloc((void **)&tr->d.weight_shift, shift.size()));
     MGX_HIP(hipMemcpy(tr->d.weight_shift, shift.data(), shift.size(), hipMemcpyHostToDevice));
     // ownership of the fine entities for the atomic-free prolongation: first cell in cell order
@@ -1078,6 +1306,7 @@ int mgx_transfer_destroy(mgx_transfer_t tr)
   (void)hipFree(tr->d.children);
   (void)hipFree(tr->d.weight_shift);
   (void)hipFree(tr->d.own27);
+  (void)hipFree(tr->scratch);
   delete tr;
   return MGX_OK;
 }
@@ -1093,7 +1322,24 @@ int mgx_prolongate(mgx_transfer_t tr, void *fine, const void *coarse, int add, i
 int mgx_restrict_and_add(mgx_transfer_t tr, void *coarse, const void *fine, int with_constraints)
 {
   MGX_REQUIRE(tr && fine && coarse, "mgx_restrict_and_add: null argument");
-  launch_restrict_add(tr->coarse->ctx->stream, tr->d, coarse, fine, with_constraints != 0);
+  mgx_operator_t cop = tr->coarse;
+  hipStream_t    s   = cop->ctx->stream;
+  if (!cop->plan)
+    {
+      launch_restrict_add(s, tr->d, coarse, fine, with_constraints != 0);
+      MGX_HIP(hipGetLastError());
+      return MGX_OK;
+    }
+  // decomposed mesh: restrict into a zeroed scratch vector, sum the interface entries over the
+  // ranks, then add (adding into `coarse` first would count its existing interface values once
+  // per sharing rank)
+  const size_t bytes = number_size(cop->d.number) * cop->d.n_dofs;
+  if (!tr->scratch)
+    MGX_HIP(hipMalloc(&tr->scratch, bytes));
+  MGX_HIP(hipMemsetAsync(tr->scratch, 0, bytes, s));
+  launch_restrict_add(s, tr->d, tr->scratch, fine, with_constraints != 0);
+  MGX_TRY(exchange_add(cop, tr->scratch));
+  launch_add_cast(s, coarse, cop->d.number, tr->scratch, cop->d.number, cop->d.n_dofs);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }
@@ -1174,6 +1420,9 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
       S->solution.push_back(p);
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
       MGX_HIP(hipMemcpy(p, desc->rhs[l], 8 * n, hipMemcpyHostToDevice));
+      // a rank assembles the rhs over its own cells: complete the interface entries
+      // (dst.compress(add) in compute_residual, laplace_operator.h:843)
+      MGX_TRY(exchange_add(desc->matrix_dp[l], p));
       S->rhs.push_back(p);
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
       MGX_HIP(hipMemsetAsync(p, 0, 8 * n, ctx->stream));
@@ -1388,7 +1637,10 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
       double dh = 0;
       MGX_TRY(dot(ctx, MGX_F64, d, h, n, &dh));
       launch_cg_update(s, MGX_F64, x, r, d, h, rz / dh, n, ctx->partial_dev, ctx->result_dev);
-      MGX_TRY(read_result(ctx, &res));
+      if (ctx->has_comm)
+        MGX_TRY(dot(ctx, MGX_F64, r, r, n, &res));
+      else
+        MGX_TRY(read_result(ctx, &res));
       res = std::sqrt(res);
     }
   if (iterations)

@@ -35,7 +35,8 @@ namespace mgx
   } // namespace
 
   bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
-                    const uint8_t *colour_hint, BrickHost &out, std::string &why)
+                    const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, BrickHost &out,
+                    std::string &why)
   {
     out = BrickHost();
     if (p < 1 || p > 4)
@@ -203,6 +204,17 @@ namespace mgx
         out.ent_flags[(size_t)refs[lo].brick * NE + refs[lo].slot] |= 1;
         out.ent_flags[(size_t)refs[hi].brick * NE + refs[hi].slot] |= 2;
         i = j;
+      }
+    // 4b. interface entities of a decomposed mesh are complete only after the exchange
+    if (n_shared > 0)
+      {
+        std::vector<uint8_t> is_shared(n_dofs, 0);
+        for (uint32_t i = 0; i < n_shared; ++i)
+          is_shared[shared[i]] = 1;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < out.ent_base.size(); ++i)
+          if (out.ent_base[i] != kInvalid && is_shared[out.ent_base[i]])
+            out.ent_flags[i] &= (uint8_t)~2u;
       }
     // 5. sort the bricks by colour (stable in cell order) and permute the tables
     std::vector<uint32_t> order(nb);

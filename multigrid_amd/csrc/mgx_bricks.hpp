@@ -17,6 +17,9 @@ namespace mgx
   };
 
   // false (with a reason) if the level cannot be scheduled as 4x4x4 bricks
+  // shared/n_shared: DoFs duplicated on other ranks (domain decomposition); their entities are
+  // never flagged LAST because the sum is only complete after the interface exchange
   bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
-                    const uint8_t *colour_hint, BrickHost &out, std::string &why);
+                    const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, BrickHost &out,
+                    std::string &why);
 } // namespace mgx

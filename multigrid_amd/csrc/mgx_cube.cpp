@@ -139,15 +139,26 @@ namespace
       }
   }
 
+  struct Neighbor
+  {
+    int                   rank = -1;
+    std::vector<uint32_t> index; // local DoFs shared with that rank, ordered by global grid id
+  };
+
   struct Level
   {
     int                   level = 0;
-    uint32_t              N = 0, n_cells = 0, n_dofs = 0, n_free = 0;
+    uint32_t              N = 0;          // local cells in x (all directions for a cube)
+    uint32_t              Nl[3] = {0, 0, 0}, Ng[3] = {0, 0, 0}, off[3] = {0, 0, 0}; // local/global cells, offset
+    uint32_t              n_cells = 0, n_dofs = 0, n_free = 0;
     double                h = 0;
     std::vector<uint32_t> idx27, idx27_plain, constrained, children, coords, dof_grid;
     std::vector<uint8_t>  brick_colour; // parity colouring of the 4x4x4 Morton bricks (level >= 2)
+    std::vector<uint8_t>  weight_shift; // level >= 1: [n_parents*27] log2(global multiplicity) of patch entities
     std::vector<double>   rhs, bc_value;
     std::vector<uint32_t> bc_index;
+    std::vector<Neighbor> neighbors;    // domain decomposition: interface exchange lists
+    std::vector<uint32_t> shared, not_owned; // union of the lists; those owned by a lower rank
   };
 
   inline uint32_t compact3(uint32_t m)
@@ -170,34 +181,47 @@ namespace
 
 struct mgx_cube_s
 {
-  int                p = 0, n_subdiv = 1;
+  int                p = 0;
+  int                groots[3] = {1, 1, 1}; // coarse cells of the whole mesh
+  int                procs[3]  = {1, 1, 1}; // process grid; every rank owns groots/procs coarse cells
+  int                pcoord[3] = {0, 0, 0}, rank = 0, size = 1;
+  int                lroots[3] = {1, 1, 1}, roff[3] = {0, 0, 0}; // this rank's coarse cells and offset
+  double             origin = -0.9, h0 = 1.9;
   Basis              basis;
   std::vector<Level> levels;
 };
 
 namespace
 {
-  // offsets of a cell's DoFs: entity e = 9cz+3cy+cx; size of the entity and the position of the
-  // grid point of local DoF (ox,oy,oz)
+  // Level of the (rank-local part of the) mesh.  Local cells in forest/Morton order over the
+  // rank's coarse cells; all DoFs of the local cells get local indices (interface DoFs are
+  // duplicated on the ranks that share them), Dirichlet DoFs of the GLOBAL boundary last.
   void build_level(mgx_cube_s &C, Level &L, int level)
   {
-    const int      p  = C.p;
-    const uint32_t N  = (uint32_t)C.n_subdiv << level;
-    L.level           = level;
-    L.N               = N;
-    L.n_cells         = N * N * N;
-    L.h               = 1.9 / N;
-    const uint32_t nc = L.n_cells, ns = (uint32_t)C.n_subdiv, per_root = 1u << (3 * level);
+    const int p = C.p;
+    L.level     = level;
+    for (int d = 0; d < 3; ++d)
+      {
+        L.Nl[d]  = (uint32_t)C.lroots[d] << level;
+        L.Ng[d]  = (uint32_t)C.groots[d] << level;
+        L.off[d] = (uint32_t)C.roff[d] << level;
+      }
+    L.N               = L.Nl[0];
+    L.n_cells         = L.Nl[0] * L.Nl[1] * L.Nl[2];
+    L.h               = C.h0 / (double)(1u << level);
+    const uint32_t nc = L.n_cells, per_root = 1u << (3 * level);
+    const uint32_t rsx = (uint32_t)C.lroots[0], rsy = (uint32_t)C.lroots[1];
     L.coords.resize(3 * (size_t)nc);
     for (uint32_t c = 0; c < nc; ++c)
       {
         const uint32_t r = c / per_root, m = c % per_root;
-        L.coords[3 * (size_t)c + 0] = ((r % ns) << level) + compact3(m);
-        L.coords[3 * (size_t)c + 1] = (((r / ns) % ns) << level) + compact3(m >> 1);
-        L.coords[3 * (size_t)c + 2] = ((r / (ns * ns)) << level) + compact3(m >> 2);
+        L.coords[3 * (size_t)c + 0] = ((r % rsx) << level) + compact3(m);
+        L.coords[3 * (size_t)c + 1] = (((r / rsx) % rsy) << level) + compact3(m >> 1);
+        L.coords[3 * (size_t)c + 2] = ((r / (rsx * rsy)) << level) + compact3(m >> 2);
       }
-    const size_t          E = 2 * (size_t)N + 1;
-    std::vector<uint32_t> first(E * E * E, MGX_INVALID_INDEX);
+    const size_t          Ex = 2 * (size_t)L.Nl[0] + 1, Ey = 2 * (size_t)L.Nl[1] + 1, Ez = 2 * (size_t)L.Nl[2] + 1;
+    const size_t          GEx = 2 * (size_t)L.Ng[0], GEy = 2 * (size_t)L.Ng[1], GEz = 2 * (size_t)L.Ng[2];
+    std::vector<uint32_t> first(Ex * Ey * Ez, MGX_INVALID_INDEX);
     auto                  esize = [p](int cx, int cy, int cz) {
       return (uint32_t)((cx == 1 ? p - 1 : 1) * (cy == 1 ? p - 1 : 1) * (cz == 1 ? p - 1 : 1));
     };
@@ -213,11 +237,13 @@ namespace
                 for (int cx = 0; cx < 3; ++cx)
                   {
                     const size_t ex = 2 * X + cx, ey = 2 * Y + cy, ez = 2 * Z + cz;
-                    const bool   on_boundary =
-                      ex == 0 || ex == E - 1 || ey == 0 || ey == E - 1 || ez == 0 || ez == E - 1;
+                    const size_t gex = 2 * (size_t)L.off[0] + ex, gey = 2 * (size_t)L.off[1] + ey,
+                                 gez = 2 * (size_t)L.off[2] + ez;
+                    const bool on_boundary =
+                      gex == 0 || gex == GEx || gey == 0 || gey == GEy || gez == 0 || gez == GEz;
                     if ((int)on_boundary != pass)
                       continue;
-                    uint32_t &f = first[(ez * E + ey) * E + ex];
+                    uint32_t &f = first[(ez * Ey + ey) * Ex + ex];
                     if (f == MGX_INVALID_INDEX)
                       {
                         f = next;
@@ -241,7 +267,7 @@ namespace
         for (int e = 0; e < 27; ++e)
           {
             const int      cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
-            const uint32_t base = first[((2 * Z + cz) * E + 2 * Y + cy) * E + 2 * X + cx];
+            const uint32_t base = first[((2 * Z + cz) * Ey + 2 * Y + cy) * Ex + 2 * X + cx];
             L.idx27_plain[27 * (size_t)c + e] = base;
             L.idx27[27 * (size_t)c + e]       = base >= L.n_free ? MGX_INVALID_INDEX : base;
           }
@@ -261,17 +287,38 @@ namespace
         L.children.resize(nc);
         for (uint32_t i = 0; i < nc; ++i)
           L.children[i] = i; // Morton order: children of parent c are 8c .. 8c+7
+        // 1/multiplicity weights of the transfer from the GLOBAL position of the
+        // parent: a patch-boundary point is shared with the neighbouring parent's patch unless
+        // it lies on the domain boundary -- also when that neighbour lives on another rank
+        const Level   &Lc   = C.levels[level - 1];
+        const uint32_t npar = nc / 8;
+        L.weight_shift.resize(27 * (size_t)npar);
+        for (uint32_t pc = 0; pc < npar; ++pc)
+          {
+            int sh[3][3];
+            for (int d = 0; d < 3; ++d)
+              {
+                const uint32_t g = Lc.off[d] + Lc.coords[3 * (size_t)pc + d];
+                sh[d][0]         = g > 0 ? 1 : 0;
+                sh[d][1]         = 0;
+                sh[d][2]         = g + 1 < Lc.Ng[d] ? 1 : 0;
+              }
+            for (int e = 0; e < 27; ++e)
+              L.weight_shift[27 * (size_t)pc + e] = (uint8_t)(sh[0][e % 3] + sh[1][(e / 3) % 3] + sh[2][e / 9]);
+          }
       }
   }
 
+  // dof -> global lexicographic grid id, and (for a decomposed mesh) the interface lists
   void build_dof_grid(const mgx_cube_s &C, Level &L)
   {
-    const int    p = C.p;
-    const size_t G = (size_t)L.N * p + 1;
+    const int    p  = C.p;
+    const size_t Gx = (size_t)L.Ng[0] * p + 1, Gy = (size_t)L.Ng[1] * p + 1;
     L.dof_grid.assign(L.n_dofs, 0);
     for (uint32_t c = 0; c < L.n_cells; ++c)
       {
-        const size_t X = L.coords[3 * (size_t)c], Y = L.coords[3 * (size_t)c + 1], Z = L.coords[3 * (size_t)c + 2];
+        const size_t X = L.off[0] + L.coords[3 * (size_t)c], Y = L.off[1] + L.coords[3 * (size_t)c + 1],
+                     Z = L.off[2] + L.coords[3 * (size_t)c + 2];
         for (int e = 0; e < 27; ++e)
           {
             const int      cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
@@ -284,10 +331,83 @@ namespace
                     const size_t gx = X * p + (cx == 0 ? 0 : (cx == 2 ? p : 1 + ox));
                     const size_t gy = Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
                     const size_t gz = Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
-                    L.dof_grid[base + (uint32_t)((oz * ny + oy) * nx + ox)] = (uint32_t)((gz * G + gy) * G + gx);
+                    L.dof_grid[base + (uint32_t)((oz * ny + oy) * nx + ox)] = (uint32_t)((gz * Gy + gy) * Gx + gx);
                   }
           }
       }
+  }
+
+  void build_interfaces(const mgx_cube_s &C, Level &L)
+  {
+    if (C.size == 1)
+      return;
+    const int    p  = C.p;
+    const size_t Gx = (size_t)L.Ng[0] * p + 1, Gy = (size_t)L.Ng[1] * p + 1;
+    // point range of this rank per direction
+    size_t lo[3], hi[3];
+    for (int d = 0; d < 3; ++d)
+      {
+        lo[d] = (size_t)L.off[d] * p;
+        hi[d] = (size_t)(L.off[d] + L.Nl[d]) * p;
+      }
+    std::vector<std::pair<uint32_t, uint32_t>> lists[27]; // (global id, local index) per neighbour offset
+    // Dirichlet DoFs are never written by the cell loop: they take no part in the exchange, but a
+    // duplicated one must still be counted once in dot products
+    std::vector<uint8_t> lower(L.n_dofs, 0), dup(L.n_dofs, 0);
+    for (uint32_t i = 0; i < L.n_dofs; ++i)
+      {
+        const size_t gid = L.dof_grid[i];
+        const size_t g[3] = {gid % Gx, (gid / Gx) % Gy, gid / (Gx * Gy)};
+        int          lo_ok[3], hi_ok[3];
+        bool         any = false;
+        for (int d = 0; d < 3; ++d)
+          {
+            lo_ok[d] = g[d] == lo[d] && C.pcoord[d] > 0;
+            hi_ok[d] = g[d] == hi[d] && C.pcoord[d] + 1 < C.procs[d];
+            any      = any || lo_ok[d] || hi_ok[d];
+          }
+        if (!any)
+          continue;
+        dup[i] = 1;
+        if (i < L.n_free)
+          L.shared.push_back(i);
+        for (int dz = -1; dz <= 1; ++dz)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+              {
+                if (!dx && !dy && !dz)
+                  continue;
+                const int dd[3] = {dx, dy, dz};
+                bool      ok    = true;
+                for (int d = 0; d < 3; ++d)
+                  ok = ok && (dd[d] == 0 || (dd[d] < 0 ? lo_ok[d] : hi_ok[d]));
+                if (!ok)
+                  continue;
+                if (i < L.n_free)
+                  lists[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1].push_back({(uint32_t)gid, i});
+                const int nr =
+                  ((C.pcoord[2] + dz) * C.procs[1] + C.pcoord[1] + dy) * C.procs[0] + C.pcoord[0] + dx;
+                if (nr < C.rank)
+                  lower[i] = 1;
+              }
+      }
+    for (uint32_t i = 0; i < L.n_dofs; ++i)
+      if (dup[i] && lower[i])
+        L.not_owned.push_back(i);
+    for (int k = 0; k < 27; ++k)
+      {
+        if (lists[k].empty())
+          continue;
+        const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+        Neighbor  nb;
+        nb.rank = ((C.pcoord[2] + dz) * C.procs[1] + C.pcoord[1] + dy) * C.procs[0] + C.pcoord[0] + dx;
+        std::sort(lists[k].begin(), lists[k].end());
+        nb.index.reserve(lists[k].size());
+        for (auto &pr : lists[k])
+          nb.index.push_back(pr.second);
+        L.neighbors.push_back(std::move(nb));
+      }
+    std::sort(L.neighbors.begin(), L.neighbors.end(), [](const Neighbor &a, const Neighbor &b) { return a.rank < b.rank; });
   }
 
   // host cell kernels (setup only): lexicographic gather through a 27-entry table
@@ -373,25 +493,29 @@ namespace
     // inhomogeneous_bc: analytic solution at the support points of boundary DoFs, nonzero only
     std::vector<double> bc_full(L.n_dofs, 0.);
     {
-      const size_t G = (size_t)L.N * p + 1;
-      // support point coordinate of grid index g along one direction
-      std::vector<double> x1(G);
-      for (size_t g = 0; g < G; ++g)
+      // support point coordinate of LOCAL grid index g along direction d
+      std::vector<double> xd[3];
+      for (int d = 0; d < 3; ++d)
         {
-          size_t cell = g / p, loc = g % p;
-          if (cell == L.N)
+          const size_t G = (size_t)L.Nl[d] * p + 1;
+          xd[d].resize(G);
+          for (size_t g = 0; g < G; ++g)
             {
-              cell = L.N - 1;
-              loc  = p;
+              size_t cell = g / p, loc = g % p;
+              if (cell == L.Nl[d])
+                {
+                  cell = L.Nl[d] - 1;
+                  loc  = p;
+                }
+              xd[d][g] = C.origin + L.h * ((double)(L.off[d] + cell) + B.gll[loc]);
             }
-          x1[g] = -0.9 + L.h * ((double)cell + B.gll[loc]);
         }
       // walk boundary entities through the cells that touch the boundary
       std::vector<uint8_t> done(L.n_dofs - L.n_free, 0);
       for (uint32_t c = 0; c < L.n_cells; ++c)
         {
           const size_t X = L.coords[3 * (size_t)c], Y = L.coords[3 * (size_t)c + 1], Z = L.coords[3 * (size_t)c + 2];
-          if (X != 0 && X != L.N - 1 && Y != 0 && Y != L.N - 1 && Z != 0 && Z != L.N - 1)
+          if (X != 0 && X != L.Nl[0] - 1 && Y != 0 && Y != L.Nl[1] - 1 && Z != 0 && Z != L.Nl[2] - 1)
             continue;
           for (int e = 0; e < 27; ++e)
             {
@@ -410,7 +534,7 @@ namespace
                       const size_t gx = X * p + (cx == 0 ? 0 : (cx == 2 ? p : 1 + ox));
                       const size_t gy = Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
                       const size_t gz = Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
-                      bc_full[base + (uint32_t)((oz * ny + oy) * nx + ox)] = u_exact(x1[gx], x1[gy], x1[gz]);
+                      bc_full[base + (uint32_t)((oz * ny + oy) * nx + ox)] = u_exact(xd[0][gx], xd[1][gy], xd[2][gz]);
                     }
             }
         }
@@ -439,8 +563,9 @@ namespace
           apply_1d(n, 0, B.D, false, t0, gx, false);
           apply_1d(n, 1, B.D, false, t0, gy, false);
           apply_1d(n, 2, B.D, false, t0, gz, false);
-          const double x0 = -0.9 + h * L.coords[3 * (size_t)c], y0 = -0.9 + h * L.coords[3 * (size_t)c + 1],
-                       z0 = -0.9 + h * L.coords[3 * (size_t)c + 2];
+          const double x0 = C.origin + h * (L.off[0] + L.coords[3 * (size_t)c]),
+                       y0 = C.origin + h * (L.off[1] + L.coords[3 * (size_t)c + 1]),
+                       z0 = C.origin + h * (L.off[2] + L.coords[3 * (size_t)c + 2]);
           for (int k = 0, q = 0; k < n; ++k)
             for (int j = 0; j < n; ++j)
               for (int i = 0; i < n; ++i, ++q)
@@ -491,26 +616,81 @@ namespace
 
 extern "C" {
 
-int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *out)
+static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
 {
-  if (!out || degree < 1 || degree > MGX_MAX_DEGREE || n_subdiv < 1 || n_refine < 0 || n_refine > 9)
+  const int degree = bd.degree, n_refine = bd.n_refine;
+  if (!out || degree < 1 || degree > MGX_MAX_DEGREE || n_refine < 0 || n_refine > 9)
     return MGX_ERR_INVALID_ARGUMENT;
-  const uint64_t N = (uint64_t)n_subdiv << n_refine;
-  if ((N * degree + 1) * (N * degree + 1) * (N * degree + 1) >= 0xFFFFFFFFull || N > 1023)
-    return MGX_ERR_UNSUPPORTED; // 32-bit DoF indices as in the reference's compressed table
+  uint64_t total = 1;
+  int      size  = 1;
+  for (int d = 0; d < 3; ++d)
+    {
+      if (bd.roots[d] < 1 || bd.procs[d] < 1 || bd.roots[d] % bd.procs[d] != 0)
+        return MGX_ERR_INVALID_ARGUMENT;
+      const uint64_t N = (uint64_t)bd.roots[d] << n_refine;
+      if (N > 2047)
+        return MGX_ERR_UNSUPPORTED;
+      total *= N * degree + 1;
+      size *= bd.procs[d];
+    }
+  if (total >= 0xFFFFFFFFull)
+    return MGX_ERR_UNSUPPORTED; // 32-bit (global) DoF indices as in the reference's compressed table
+  if (bd.rank < 0 || bd.rank >= size || !(bd.h0 > 0))
+    return MGX_ERR_INVALID_ARGUMENT;
   omp_set_num_threads(effective_threads());
-  auto C      = std::make_unique<mgx_cube_s>();
-  C->p        = degree;
-  C->n_subdiv = n_subdiv;
+  auto C    = std::make_unique<mgx_cube_s>();
+  C->p      = degree;
+  C->origin = bd.origin;
+  C->h0     = bd.h0;
+  C->rank   = bd.rank;
+  C->size   = size;
+  int r     = bd.rank;
+  for (int d = 0; d < 3; ++d)
+    {
+      C->groots[d] = bd.roots[d];
+      C->procs[d]  = bd.procs[d];
+      C->pcoord[d] = r % bd.procs[d];
+      r /= bd.procs[d];
+      C->lroots[d] = bd.roots[d] / bd.procs[d];
+      C->roff[d]   = C->pcoord[d] * C->lroots[d];
+    }
   make_basis(C->basis, degree);
   C->levels.resize(n_refine + 1);
   for (int l = 0; l <= n_refine; ++l)
     {
       build_level(*C, C->levels[l], l);
+      build_dof_grid(*C, C->levels[l]);
+      build_interfaces(*C, C->levels[l]);
       build_rhs(*C, C->levels[l]);
     }
   *out = C.release();
   return MGX_OK;
+}
+
+int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *out)
+{
+  // "square" mesh: subdivided_hyper_cube(n_subdiv, -0.9, 1.0) (poisson_cube/program.cc:542)
+  if (n_subdiv < 1)
+    return MGX_ERR_INVALID_ARGUMENT;
+  mgx_cube_box_desc bd;
+  bd.degree   = degree;
+  bd.n_refine = n_refine;
+  bd.origin   = -0.9;
+  bd.h0       = 1.9 / n_subdiv;
+  bd.rank     = 0;
+  for (int d = 0; d < 3; ++d)
+    {
+      bd.roots[d] = n_subdiv;
+      bd.procs[d] = 1;
+    }
+  return create_impl(bd, out);
+}
+
+int mgx_cube_create_box(const mgx_cube_box_desc *bd, mgx_cube_t *out)
+{
+  if (!bd)
+    return MGX_ERR_INVALID_ARGUMENT;
+  return create_impl(*bd, out);
 }
 
 int mgx_cube_destroy(mgx_cube_t cube)
@@ -532,11 +712,25 @@ const uint32_t *mgx_cube_idx27_plain(mgx_cube_t c, int l) { return c->levels[l].
 const uint32_t *mgx_cube_constrained(mgx_cube_t c, int l) { return c->levels[l].constrained.data(); }
 const uint32_t *mgx_cube_children(mgx_cube_t c, int l) { return l > 0 ? c->levels[l].children.data() : nullptr; }
 const uint32_t *mgx_cube_cell_coords(mgx_cube_t c, int l) { return c->levels[l].coords.data(); }
-const uint32_t *mgx_cube_dof_grid(mgx_cube_t c, int l)
+const uint32_t *mgx_cube_dof_grid(mgx_cube_t c, int l) { return c->levels[l].dof_grid.data(); }
+int             mgx_cube_rank(mgx_cube_t c) { return c->rank; }
+int             mgx_cube_size(mgx_cube_t c) { return c->size; }
+int             mgx_cube_n_neighbors(mgx_cube_t c, int l) { return (int)c->levels[l].neighbors.size(); }
+int             mgx_cube_neighbor_rank(mgx_cube_t c, int l, int k) { return c->levels[l].neighbors[k].rank; }
+uint32_t        mgx_cube_neighbor_count(mgx_cube_t c, int l, int k) { return (uint32_t)c->levels[l].neighbors[k].index.size(); }
+const uint32_t *mgx_cube_neighbor_index(mgx_cube_t c, int l, int k) { return c->levels[l].neighbors[k].index.data(); }
+uint32_t        mgx_cube_n_shared(mgx_cube_t c, int l) { return (uint32_t)c->levels[l].shared.size(); }
+const uint32_t *mgx_cube_shared(mgx_cube_t c, int l) { return c->levels[l].shared.data(); }
+uint32_t        mgx_cube_n_not_owned(mgx_cube_t c, int l) { return (uint32_t)c->levels[l].not_owned.size(); }
+const uint32_t *mgx_cube_not_owned(mgx_cube_t c, int l) { return c->levels[l].not_owned.data(); }
+const uint8_t  *mgx_cube_weight_shift(mgx_cube_t c, int l) { return l > 0 ? c->levels[l].weight_shift.data() : nullptr; }
+void            mgx_cube_cells_per_dim3(mgx_cube_t c, int l, uint32_t local[3], uint32_t global[3])
 {
-  if (c->levels[l].dof_grid.empty())
-    build_dof_grid(*c, c->levels[l]);
-  return c->levels[l].dof_grid.data();
+  for (int d = 0; d < 3; ++d)
+    {
+      local[d]  = c->levels[l].Nl[d];
+      global[d] = c->levels[l].Ng[d];
+    }
 }
 const double *mgx_cube_shape_values(mgx_cube_t c) { return c->basis.S; }
 const double *mgx_cube_colloc_grad(mgx_cube_t c) { return c->basis.D; }
@@ -570,10 +764,45 @@ int mgx_cube_operator_desc(mgx_cube_t c, int l, int number, mgx_operator_desc *d
   d->colloc_grad  = c->basis.D;
   d->qweights     = c->basis.gw;
   d->brick_colour = L.brick_colour.empty() ? nullptr : L.brick_colour.data();
+  d->global_index = L.dof_grid.data();
+  d->exchange     = nullptr; // decomposed meshes: see mgx_cube_exchange_desc
+  return MGX_OK;
+}
+
+int mgx_cube_exchange_desc(mgx_cube_t c, int l, int plan_id, mgx_exchange_desc *e, const uint32_t **index_scratch,
+                           int *rank_scratch, uint32_t *count_scratch)
+{
+  if (!c || !e || l < 0 || l >= (int)c->levels.size())
+    return MGX_ERR_INVALID_ARGUMENT;
+  const Level &L = c->levels[l];
+  for (size_t k = 0; k < L.neighbors.size(); ++k)
+    {
+      index_scratch[k] = L.neighbors[k].index.data();
+      rank_scratch[k]  = L.neighbors[k].rank;
+      count_scratch[k] = (uint32_t)L.neighbors[k].index.size();
+    }
+  e->plan_id       = plan_id;
+  e->n_neighbors   = (int)L.neighbors.size();
+  e->neighbor_rank = rank_scratch;
+  e->count         = count_scratch;
+  e->index         = index_scratch;
+  e->shared        = L.shared.data();
+  e->n_shared      = (uint32_t)L.shared.size();
+  e->not_owned     = L.not_owned.data();
+  e->n_not_owned   = (uint32_t)L.not_owned.size();
+  e->send_buf      = nullptr;
+  e->recv_buf      = nullptr;
   return MGX_OK;
 }
 
 double mgx_cube_l2_error(mgx_cube_t c, int l, const double *sol)
+{
+  double err2 = 0, vol = 0;
+  mgx_cube_l2_error_parts(c, l, sol, &err2, &vol);
+  return std::sqrt(err2 / vol);
+}
+
+void mgx_cube_l2_error_parts(mgx_cube_t c, int l, const double *sol, double *err2_out, double *vol_out)
 {
   const Level &L = c->levels[l];
   const Basis &B = c->basis;
@@ -591,8 +820,9 @@ double mgx_cube_l2_error(mgx_cube_t c, int l, const double *sol)
         apply_1d(n, 0, B.S, false, u, t0, false);
         apply_1d(n, 1, B.S, false, t0, u, false);
         apply_1d(n, 2, B.S, false, u, t0, false);
-        const double x0 = -0.9 + h * L.coords[3 * (size_t)cell], y0 = -0.9 + h * L.coords[3 * (size_t)cell + 1],
-                     z0 = -0.9 + h * L.coords[3 * (size_t)cell + 2];
+        const double x0 = c->origin + h * (L.off[0] + L.coords[3 * (size_t)cell]),
+                     y0 = c->origin + h * (L.off[1] + L.coords[3 * (size_t)cell + 1]),
+                     z0 = c->origin + h * (L.off[2] + L.coords[3 * (size_t)cell + 2]);
         for (int k = 0, q = 0; k < n; ++k)
           for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i, ++q)
@@ -604,7 +834,8 @@ double mgx_cube_l2_error(mgx_cube_t c, int l, const double *sol)
               }
       }
   }
-  return std::sqrt(err / vol);
+  *err2_out = err;
+  *vol_out  = vol;
 }
 
 int mgx_cube_seeded_vector(mgx_cube_t c, int l, uint64_t seed, double *out)
@@ -670,6 +901,16 @@ int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int 
     {
       mgx_operator_desc d;
       mgx_cube_operator_desc(cube, l, MGX_F64, &d);
+      // decomposed mesh: plan ids 2*level (fp64 operator) and 2*level+1 (V-cycle operator)
+      mgx_exchange_desc ex;
+      const uint32_t   *idx[27];
+      int               ranks[27];
+      uint32_t          counts[27];
+      if (cube->size > 1)
+        {
+          mgx_cube_exchange_desc(cube, l, 2 * l, &ex, idx, ranks, counts);
+          d.exchange = &ex;
+        }
       status = mgx_operator_create(ctx, &d, &out->matrix_dp[l]);
       if (status != MGX_OK)
         break;
@@ -677,15 +918,17 @@ int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int 
         out->matrix[l] = out->matrix_dp[l];
       else
         {
-          d.number = MGX_F32;
-          status   = mgx_operator_create(ctx, &d, &out->matrix[l]);
+          d.number   = MGX_F32;
+          ex.plan_id = 2 * l + 1;
+          status     = mgx_operator_create(ctx, &d, &out->matrix[l]);
         }
     }
   for (int l = 1; l < nl && status == MGX_OK; ++l)
     {
       mgx_transfer_desc t;
-      t.children   = cube->levels[l].children.data();
-      t.prolong_1d = cube->basis.P1;
+      t.children     = cube->levels[l].children.data();
+      t.prolong_1d   = cube->basis.P1;
+      t.weight_shift = cube->levels[l].weight_shift.data();
       status       = mgx_transfer_create(out->matrix_dp[l - 1], out->matrix_dp[l], &t, &out->transfer_dp[l]);
       if (status != MGX_OK)
         break;

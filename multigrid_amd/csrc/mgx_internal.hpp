@@ -124,8 +124,19 @@ namespace mgx
   void launch_cheb_update(hipStream_t s, int number, int mode, void *x, void *x_old, const void *b,
                           const void *t, const void *dinv, double f1, double f2, size_t n);
   void launch_cheb_init(hipStream_t s, int number, void *x, const void *b, const void *dinv, double f2, size_t n);
+  // ax == nullptr: (A x)_c = x_c (constrained rows); otherwise the product is read from ax
   void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
-                               const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count);
+                               const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count,
+                               const void *ax = nullptr);
+  // interface exchange helpers
+  void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
+  void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count);
+  void launch_list_residual(hipStream_t s, int number, void *res, const void *rhs, const uint32_t *list,
+                            uint32_t count); // res[i] = rhs[i] - res[i]
+  void launch_dot_list(hipStream_t s, int number, const void *x, const void *y, const uint32_t *list,
+                       uint32_t count, double *partial_dev, double *result_dev);
+  void launch_index_mod11(hipStream_t s, int number, void *v, const uint32_t *global_index_dev, double mean,
+                          size_t n); // v[i] = (gid(i) % 11) - mean  (gid = i if the index array is null)
   // partial[0..n_blocks) block sums of x.y, then reduced into *result_dev (double)
   void launch_dot(hipStream_t s, int number, const void *x, const void *y, size_t n, double *partial_dev,
                   double *result_dev);

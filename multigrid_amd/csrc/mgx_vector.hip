@@ -127,19 +127,54 @@ namespace mgx
   template <typename T>
   __global__ void __launch_bounds__(256)
     k_cheb_constrained(int mode, const T *__restrict__ x, T *__restrict__ out, const T *__restrict__ b,
-                       const T *__restrict__ dinv, T f1, T f2, const uint32_t *__restrict__ list, uint32_t count)
+                       const T *__restrict__ dinv, T f1, T f2, const uint32_t *__restrict__ list, uint32_t count,
+                       const T *__restrict__ ax)
   {
     GRID_STRIDE(i, count)
     {
       const uint32_t c  = list[i];
       const T        xi = x[c];
-      T              xn = xi + f2 * dinv[c] * (b[c] - xi);
+      T              xn = xi + f2 * dinv[c] * (b[c] - (ax ? ax[c] : xi));
       if (mode == 2)
         xn += f1 * (xi - out[c]);
       else if (mode == 4)
         xn += f1 * xi;
       out[c] = xn;
     }
+  }
+
+  // ---- interface exchange (domain decomposition) ----
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_pack(T *__restrict__ buf, const T *__restrict__ v, const uint32_t *__restrict__ list, uint32_t count)
+  {
+    GRID_STRIDE(i, count) buf[i] = v[list[i]];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_unpack_add(T *__restrict__ v, const T *__restrict__ buf, const uint32_t *__restrict__ list, uint32_t count)
+  {
+    GRID_STRIDE(i, count) v[list[i]] += buf[i];
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_list_residual(T *__restrict__ res, const T *__restrict__ rhs, const uint32_t *__restrict__ list,
+                    uint32_t count)
+  {
+    GRID_STRIDE(i, count)
+    {
+      const uint32_t c = list[i];
+      res[c]           = rhs[c] - res[c];
+    }
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_index_mod11(T *__restrict__ v, const uint32_t *__restrict__ gid, double mean, size_t n)
+  {
+    GRID_STRIDE(i, n) v[i] = (T)((double)((gid ? gid[i] : (uint32_t)i) % 11u) - mean);
   }
 
   // ---- reductions: deterministic two-stage sum (block partials, then one block) ----
@@ -222,6 +257,22 @@ namespace mgx
       const T zi = dinv[i] * r[i];
       z[i]       = zi;
       s += (double)r[i] * (double)zi;
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = s;
+  }
+
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_dot_list_partial(const T *__restrict__ x, const T *__restrict__ y, const uint32_t *__restrict__ list,
+                       uint32_t count, double *__restrict__ partial)
+  {
+    double s = 0;
+    GRID_STRIDE(i, count)
+    {
+      const uint32_t c = list[i];
+      s += (double)x[c] * (double)y[c];
     }
     s = block_sum(s);
     if (threadIdx.x == 0)
@@ -363,13 +414,46 @@ namespace mgx
   }
 
   void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
-                               const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count)
+                               const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count,
+                               const void *ax)
   {
     if (count == 0)
       return;
     BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_constrained<T>), stream_grid(count), dim3(256), 0, s, mode,
                                          (const T *)x, (T *)out, (const T *)b, (const T *)dinv, (T)f1, (T)f2, list,
-                                         count));
+                                         count, (const T *)ax));
+  }
+
+  void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_pack<T>), stream_grid(count), dim3(256), 0, s, (T *)buf, (const T *)v,
+                                         list, count));
+  }
+
+  void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_unpack_add<T>), stream_grid(count), dim3(256), 0, s, (T *)v,
+                                         (const T *)buf, list, count));
+  }
+
+  void launch_list_residual(hipStream_t s, int number, void *res, const void *rhs, const uint32_t *list,
+                            uint32_t count)
+  {
+    if (count == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_list_residual<T>), stream_grid(count), dim3(256), 0, s, (T *)res,
+                                         (const T *)rhs, list, count));
+  }
+
+  void launch_index_mod11(hipStream_t s, int number, void *v, const uint32_t *gid, double mean, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_index_mod11<T>), stream_grid(n), dim3(256), 0, s, (T *)v, gid, mean, n));
   }
 
   void launch_dot(hipStream_t s, int number, const void *x, const void *y, size_t n, double *partial_dev,
@@ -378,6 +462,15 @@ namespace mgx
     const dim3 g = reduce_grid(n);
     BY_NUMBER(number, hipLaunchKernelGGL((k_dot_partial<T>), g, dim3(256), 0, s, (const T *)x, (const T *)y, n,
                                          partial_dev));
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+
+  void launch_dot_list(hipStream_t s, int number, const void *x, const void *y, const uint32_t *list,
+                       uint32_t count, double *partial_dev, double *result_dev)
+  {
+    const dim3 g = reduce_grid(count);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_dot_list_partial<T>), g, dim3(256), 0, s, (const T *)x, (const T *)y,
+                                         list, count, partial_dev));
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
   }
 

@@ -43,6 +43,9 @@ def lib():
     vp = C.c_void_p
     L.orc_create.restype = vp
     L.orc_create.argtypes = [C.c_int] * 6
+    L.orc_create_box.restype = vp
+    L.orc_create_box.argtypes = [C.c_int] * 8
+    L.orc_cells_per_dim3.argtypes = [vp, C.c_int, C.POINTER(C.c_int * 3)]
     L.orc_destroy.argtypes = [vp]
     for name in ("orc_n_levels", "orc_degree"):
         getattr(L, name).restype = C.c_int
@@ -98,9 +101,14 @@ def _p(a):
 class Oracle:
     """MultigridSolver<3,p,Number,double> of the reference, restated on the CPU."""
 
-    def __init__(self, p, n_subdiv=1, n_refine=3, degree=3, n_cycles=1, vfloat=False):
+    def __init__(self, p, n_subdiv=1, n_refine=3, degree=3, n_cycles=1, vfloat=False, box=None):
+        """box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1));
+        otherwise the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction"""
         self.L = lib()
-        self.h = self.L.orc_create(p, n_subdiv, n_refine, degree, n_cycles, int(vfloat))
+        if box is not None:
+            self.h = self.L.orc_create_box(p, box[0], box[1], box[2], n_refine, degree, n_cycles, int(vfloat))
+        else:
+            self.h = self.L.orc_create(p, n_subdiv, n_refine, degree, n_cycles, int(vfloat))
         if not self.h:
             raise ValueError("orc_create failed")
         self.p = p
@@ -130,6 +138,11 @@ class Oracle:
 
     def cells_per_dim(self, l):
         return self.L.orc_cells_per_dim(self.h, l)
+
+    def cells_per_dim3(self, l):
+        out = (C.c_int * 3)()
+        self.L.orc_cells_per_dim3(self.h, l, C.byref(out))
+        return tuple(out)
 
     def _u32(self, fn, l, n):
         return np.ctypeslib.as_array(getattr(self.L, fn)(self.h, l), shape=(n,)).copy()

@@ -220,7 +220,8 @@ static void tridiag_extreme_eigs(int n, const double *d, const double *e, double
  * ------------------------------------------------------------------------------------------ */
 typedef struct
 {
-  int       level, N;
+  int       level, N;      /* N = cells in x (all directions for the cube) */
+  int       Nd[3];         /* cells per direction */
   uint32_t  n_cells, n_dofs, n_constrained;
   uint32_t *idx27, *idx27_plain, *constrained, *cell_coords, *dof_grid;
   uint32_t  colour_start[9];
@@ -232,6 +233,9 @@ typedef struct
 struct orc_problem
 {
   int        p, n_subdiv, n_levels, degree, n_cycles, vfloat;
+  int        roots[3];  /* coarse cells per direction */
+  double     origin;    /* lower corner of the domain (all directions) */
+  double     h0;        /* size of a coarse cell */
   orc_basis  basis;
   orc_level *levels;
   void      *Bd, *Bf; /* basis_d / basis_f  */
@@ -253,13 +257,16 @@ static inline uint32_t morton_compact(uint32_t m)
   return r;
 }
 
-static void level_init(orc_level *L, int p, int n_subdiv, int level)
+static void level_init(orc_level *L, int p, const int roots[3], double h0, int level)
 {
-  const int N  = n_subdiv << level;
+  const int Nx = roots[0] << level, Ny = roots[1] << level, Nz = roots[2] << level;
   L->level     = level;
-  L->N         = N;
-  L->n_cells   = (uint32_t)N * N * N;
-  L->h         = 1.9 / N;
+  L->N         = Nx;
+  L->Nd[0]     = Nx;
+  L->Nd[1]     = Ny;
+  L->Nd[2]     = Nz;
+  L->n_cells   = (uint32_t)Nx * Ny * Nz;
+  L->h         = h0 / (1 << level);
   /* merged_coefficient = a * JxW * J^-T J^-1 = h^3 / h^2 (laplace_operator.h:374-387) */
   L->coef[0] = L->coef[1] = L->coef[2] = L->h;
   L->coef[3] = L->coef[4] = L->coef[5] = 0.;
@@ -269,7 +276,7 @@ static void level_init(orc_level *L, int p, int n_subdiv, int level)
   for (uint32_t c = 0; c < nc; ++c)
     {
       const uint32_t r = c / per_root, m = c % per_root;
-      const uint32_t rx = r % n_subdiv, ry = (r / n_subdiv) % n_subdiv, rz = r / (n_subdiv * n_subdiv);
+      const uint32_t rx = r % roots[0], ry = (r / roots[0]) % roots[1], rz = r / (roots[0] * roots[1]);
       L->cell_coords[3 * (size_t)c + 0] = (rx << level) + morton_compact(m);
       L->cell_coords[3 * (size_t)c + 1] = (ry << level) + morton_compact(m >> 1);
       L->cell_coords[3 * (size_t)c + 2] = (rz << level) + morton_compact(m >> 2);
@@ -292,10 +299,11 @@ static void level_init(orc_level *L, int p, int n_subdiv, int level)
                       ((L->cell_coords[3 * (size_t)c + 2] & 1) << 2);
       L->colour_cells[pos[col]++] = c;
     }
-  /* entity numbering: entity grid (2N+1)^3, even coordinate = vertex plane, odd = cell interior */
-  const size_t E   = (size_t)(2 * N + 1);
-  uint32_t    *ent = (uint32_t *)malloc(sizeof(uint32_t) * E * E * E);
-  for (size_t i = 0; i < E * E * E; ++i)
+  /* entity numbering: entity grid (2Nx+1)(2Ny+1)(2Nz+1), even coordinate = vertex plane, odd =
+   * cell interior */
+  const size_t Ex = (size_t)(2 * Nx + 1), Ey = (size_t)(2 * Ny + 1), Ez = (size_t)(2 * Nz + 1);
+  uint32_t    *ent = (uint32_t *)malloc(sizeof(uint32_t) * Ex * Ey * Ez);
+  for (size_t i = 0; i < Ex * Ey * Ez; ++i)
     ent[i] = ORC_INVALID;
   L->idx27       = (uint32_t *)malloc(sizeof(uint32_t) * 27 * (size_t)nc);
   L->idx27_plain = (uint32_t *)malloc(sizeof(uint32_t) * 27 * (size_t)nc);
@@ -311,11 +319,11 @@ static void level_init(orc_level *L, int p, int n_subdiv, int level)
               for (int cx = 0; cx < 3; ++cx)
                 {
                   const size_t ex = 2 * X + cx, ey = 2 * Y + cy, ez = 2 * Z + cz;
-                  const int    bdry = ex == 0 || ex == 2 * (size_t)N || ey == 0 ||
-                                   ey == 2 * (size_t)N || ez == 0 || ez == 2 * (size_t)N;
+                  const int    bdry = ex == 0 || ex == Ex - 1 || ey == 0 || ey == Ey - 1 || ez == 0 ||
+                                   ez == Ez - 1;
                   if (bdry != pass)
                     continue;
-                  const size_t eid = (ez * E + ey) * E + ex;
+                  const size_t eid = (ez * Ey + ey) * Ex + ex;
                   if (ent[eid] == ORC_INVALID)
                     {
                       ent[eid] = next;
@@ -334,8 +342,8 @@ static void level_init(orc_level *L, int p, int n_subdiv, int level)
   for (uint32_t i = 0; i < L->n_constrained; ++i)
     L->constrained[i] = n_uncons + i;
   /* tables + dof -> lexicographic grid id map */
-  const size_t G = (size_t)N * p + 1;
-  L->dof_grid    = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)L->n_dofs);
+  const size_t Gx = (size_t)Nx * p + 1, Gy = (size_t)Ny * p + 1;
+  L->dof_grid     = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)L->n_dofs);
   for (uint32_t c = 0; c < nc; ++c)
     {
       const uint32_t X = L->cell_coords[3 * (size_t)c], Y = L->cell_coords[3 * (size_t)c + 1],
@@ -345,7 +353,7 @@ static void level_init(orc_level *L, int p, int n_subdiv, int level)
           for (int cx = 0; cx < 3; ++cx)
             {
               const size_t   ex = 2 * X + cx, ey = 2 * Y + cy, ez = 2 * Z + cz;
-              const uint32_t base = ent[(ez * E + ey) * E + ex];
+              const uint32_t base = ent[(ez * Ey + ey) * Ex + ex];
               const int      e    = 9 * cz + 3 * cy + cx;
               L->idx27_plain[27 * (size_t)c + e] = base;
               L->idx27[27 * (size_t)c + e]       = base >= n_uncons ? ORC_INVALID : base;
@@ -358,7 +366,7 @@ static void level_init(orc_level *L, int p, int n_subdiv, int level)
                       const size_t gy = (size_t)Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
                       const size_t gz = (size_t)Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
                       L->dof_grid[base + (uint32_t)((oz * ny + oy) * nx + ox)] =
-                        (uint32_t)((gz * G + gy) * G + gx);
+                        (uint32_t)((gz * Gy + gy) * Gx + gx);
                     }
             }
     }
@@ -422,18 +430,18 @@ static double f_rhs(double x, double y, double z)
 
 static void grid_to_xyz(const orc_problem *P, const orc_level *L, uint32_t gid, double xyz[3])
 {
-  const int    p = P->p;
-  const size_t G = (size_t)L->N * p + 1;
-  size_t       g[3] = {gid % G, (gid / G) % G, gid / (G * G)};
+  const int    p  = P->p;
+  const size_t Gx = (size_t)L->Nd[0] * p + 1, Gy = (size_t)L->Nd[1] * p + 1;
+  size_t       g[3] = {gid % Gx, (gid / Gx) % Gy, gid / (Gx * Gy)};
   for (int d = 0; d < 3; ++d)
     {
       size_t cell = g[d] / p, loc = g[d] % p;
-      if (cell == (size_t)L->N)
+      if (cell == (size_t)L->Nd[d])
         {
-          cell = L->N - 1;
+          cell = L->Nd[d] - 1;
           loc  = p;
         }
-      xyz[d] = -0.9 + L->h * ((double)cell + P->basis.gll[loc]);
+      xyz[d] = P->origin + L->h * ((double)cell + P->basis.gll[loc]);
     }
 }
 
@@ -466,9 +474,9 @@ static void compute_rhs(const orc_problem *P, const orc_level *L, double *dst, c
             sweep_d(n, 0, B->D, t0, gx, 0);
             sweep_d(n, 1, B->D, t0, gy, 0);
             sweep_d(n, 2, B->D, t0, gz, 0);
-            const double x0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c],
-                         y0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 1],
-                         z0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 2];
+            const double x0 = P->origin + L->h * L->cell_coords[3 * (size_t)c],
+                         y0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 1],
+                         z0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 2];
             for (int k = 0, q = 0; k < n; ++k)
               for (int j = 0; j < n; ++j)
                 for (int i = 0; i < n; ++i, ++q)
@@ -536,18 +544,44 @@ static int effective_threads(void)
   return n;
 }
 
+static orc_problem *create_impl(int p, const int roots[3], double origin, double h0, int n_refine, int degree,
+                                int n_cycles, int vfloat);
+
 orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cycles, int vfloat)
+{
+  /* "square" mesh: subdivided_hyper_cube(n_subdiv, -0.9, 1.0) (poisson_cube/program.cc:542) */
+  const int roots[3] = {n_subdiv, n_subdiv, n_subdiv};
+  if (n_subdiv < 1)
+    return NULL;
+  return create_impl(p, roots, -0.9, 1.9 / n_subdiv, n_refine, degree, n_cycles, vfloat);
+}
+
+orc_problem *orc_create_box(int p, int sx, int sy, int sz, int n_refine, int degree, int n_cycles, int vfloat)
+{
+  /* "doubling" mesh family: subdivided_hyper_rectangle with cubic coarse cells of size 1.9 from
+   * the corner (-1,-1,-1) (poisson_cube/program.cc:509-529) */
+  const int roots[3] = {sx, sy, sz};
+  if (sx < 1 || sy < 1 || sz < 1)
+    return NULL;
+  return create_impl(p, roots, -1.0, 1.9, n_refine, degree, n_cycles, vfloat);
+}
+
+static orc_problem *create_impl(int p, const int roots[3], double origin, double h0, int n_refine, int degree,
+                                int n_cycles, int vfloat)
 {
 #ifdef _OPENMP
   omp_set_num_threads(effective_threads());
 #endif
-  if (p < 1 || p > 9 || n_subdiv < 1 || n_refine < 0)
+  if (p < 1 || p > 9 || n_refine < 0)
     return NULL;
-  /* the 27-entry compressed path is what the reference uses for fe_degree > 2
-   * (laplace_operator.h:230,540); for p <= 2 it degenerates gracefully (empty interiors for p=1) */
   orc_problem *P = (orc_problem *)calloc(1, sizeof(orc_problem));
   P->p           = p;
-  P->n_subdiv    = n_subdiv;
+  P->n_subdiv    = roots[0];
+  P->roots[0]    = roots[0];
+  P->roots[1]    = roots[1];
+  P->roots[2]    = roots[2];
+  P->origin      = origin;
+  P->h0          = h0;
   P->n_levels    = n_refine + 1;
   P->degree      = degree;
   P->n_cycles    = n_cycles;
@@ -559,7 +593,7 @@ orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cyc
   basis_init_f((basis_f *)P->Bf, &P->basis);
   P->levels = (orc_level *)calloc(P->n_levels, sizeof(orc_level));
   for (int l = 0; l < P->n_levels; ++l)
-    level_init(&P->levels[l], p, n_subdiv, l);
+    level_init(&P->levels[l], p, P->roots, P->h0, l);
   P->solution = (double **)calloc(P->n_levels, sizeof(double *));
   P->rhs      = (double **)calloc(P->n_levels, sizeof(double *));
   P->residual = (double **)calloc(P->n_levels, sizeof(double *));
@@ -684,6 +718,11 @@ uint32_t orc_n_cells(const orc_problem *P, int l) { return P->levels[l].n_cells;
 uint32_t orc_n_dofs(const orc_problem *P, int l) { return P->levels[l].n_dofs; }
 uint32_t orc_n_constrained(const orc_problem *P, int l) { return P->levels[l].n_constrained; }
 int orc_cells_per_dim(const orc_problem *P, int l) { return P->levels[l].N; }
+void orc_cells_per_dim3(const orc_problem *P, int l, int out[3])
+{
+  for (int d = 0; d < 3; ++d)
+    out[d] = P->levels[l].Nd[d];
+}
 const uint32_t *orc_idx27(const orc_problem *P, int l) { return P->levels[l].idx27; }
 const uint32_t *orc_idx27_plain(const orc_problem *P, int l) { return P->levels[l].idx27_plain; }
 const uint32_t *orc_constrained(const orc_problem *P, int l) { return P->levels[l].constrained; }
@@ -739,7 +778,7 @@ void orc_vmult_dense_lex(const orc_problem *P, int l, double *dst, const double 
   const orc_level *L = &P->levels[l];
   const orc_basis *b = &P->basis;
   const int        p = P->p, n = p + 1, n3 = n * n * n;
-  const size_t     G = (size_t)L->N * p + 1;
+  const size_t     Gx = (size_t)L->Nd[0] * p + 1, Gy = (size_t)L->Nd[1] * p + 1, Gz = (size_t)L->Nd[2] * p + 1;
   double          *A = (double *)calloc((size_t)n3 * n3, sizeof(double));
   /* A_ij = h sum_q w_q grad phi_i . grad phi_j */
   for (int qz = 0; qz < n; ++qz)
@@ -763,33 +802,33 @@ void orc_vmult_dense_lex(const orc_problem *P, int l, double *dst, const double 
                 }
             }
         }
-  memset(dst, 0, sizeof(double) * G * G * G);
-  for (int Z = 0; Z < L->N; ++Z)
-    for (int Y = 0; Y < L->N; ++Y)
-      for (int X = 0; X < L->N; ++X)
+  memset(dst, 0, sizeof(double) * Gx * Gy * Gz);
+  for (int Z = 0; Z < L->Nd[2]; ++Z)
+    for (int Y = 0; Y < L->Nd[1]; ++Y)
+      for (int X = 0; X < L->Nd[0]; ++X)
         for (int i = 0; i < n3; ++i)
           {
-            const size_t gi = (((size_t)Z * p + i / (n * n)) * G + ((size_t)Y * p + (i / n) % n)) * G +
+            const size_t gi = (((size_t)Z * p + i / (n * n)) * Gy + ((size_t)Y * p + (i / n) % n)) * Gx +
                               (size_t)X * p + i % n;
-            const size_t ix = gi % G, iy = (gi / G) % G, iz = gi / (G * G);
-            if (ix == 0 || ix == G - 1 || iy == 0 || iy == G - 1 || iz == 0 || iz == G - 1)
+            const size_t ix = gi % Gx, iy = (gi / Gx) % Gy, iz = gi / (Gx * Gy);
+            if (ix == 0 || ix == Gx - 1 || iy == 0 || iy == Gy - 1 || iz == 0 || iz == Gz - 1)
               continue;
             double s = 0;
             for (int j = 0; j < n3; ++j)
               {
                 const size_t jx = (size_t)X * p + j % n, jy = (size_t)Y * p + (j / n) % n,
                              jz = (size_t)Z * p + j / (n * n);
-                if (jx == 0 || jx == G - 1 || jy == 0 || jy == G - 1 || jz == 0 || jz == G - 1)
+                if (jx == 0 || jx == Gx - 1 || jy == 0 || jy == Gy - 1 || jz == 0 || jz == Gz - 1)
                   continue;
-                s += A[(size_t)i * n3 + j] * src[(jz * G + jy) * G + jx];
+                s += A[(size_t)i * n3 + j] * src[(jz * Gy + jy) * Gx + jx];
               }
             dst[gi] += s;
           }
-  for (size_t iz = 0; iz < G; ++iz)
-    for (size_t iy = 0; iy < G; ++iy)
-      for (size_t ix = 0; ix < G; ++ix)
-        if (ix == 0 || ix == G - 1 || iy == 0 || iy == G - 1 || iz == 0 || iz == G - 1)
-          dst[(iz * G + iy) * G + ix] = src[(iz * G + iy) * G + ix];
+  for (size_t iz = 0; iz < Gz; ++iz)
+    for (size_t iy = 0; iy < Gy; ++iy)
+      for (size_t ix = 0; ix < Gx; ++ix)
+        if (ix == 0 || ix == Gx - 1 || iy == 0 || iy == Gy - 1 || iz == 0 || iz == Gz - 1)
+          dst[(iz * Gy + iy) * Gx + ix] = src[(iz * Gy + iy) * Gx + ix];
   free(A);
 }
 
@@ -937,9 +976,9 @@ double orc_l2_error(orc_problem *P, int level)
         sweep_d(n, 0, B->S, u, t0, 0);
         sweep_d(n, 1, B->S, t0, u, 0);
         sweep_d(n, 2, B->S, u, t0, 0);
-        const double x0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c],
-                     y0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 1],
-                     z0 = -0.9 + L->h * L->cell_coords[3 * (size_t)c + 2];
+        const double x0 = P->origin + L->h * L->cell_coords[3 * (size_t)c],
+                     y0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 1],
+                     z0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 2];
         for (int k = 0, q = 0; k < n; ++k)
           for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i, ++q)

@@ -38,6 +38,10 @@ typedef struct orc_problem orc_problem;
  *   n_cycles : V-cycles per FMG level (multigrid_solver.h:451)
  *   vfloat   : 0 -> V-cycle vectors/operators in fp64, 1 -> fp32 (program.cc:76) */
 orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cycles, int vfloat);
+/* "doubling" mesh family (poisson_cube/program.cc:509-529): box of sx x sy x sz cubic coarse cells
+ * of size 1.9 with lower corner (-1,-1,-1), refined n_refine times */
+orc_problem *orc_create_box(int p, int sx, int sy, int sz, int n_refine, int degree, int n_cycles, int vfloat);
+void orc_cells_per_dim3(const orc_problem *P, int level, int out[3]);
 void orc_destroy(orc_problem *P);
 
 int orc_n_levels(const orc_problem *P);
