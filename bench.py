@@ -9,7 +9,10 @@ restriction, coarse solve, prolongation).  `value` = global DoFs / time per step
 and V-cycle-only rates are reported next to it (`matvec_dofs_per_s`, `vcycle_dofs_per_s`).
 
 N = 1: BASELINE config 1 -- 128^3 cells, 135 005 697 DoFs, one MI355X, inputs resident in HBM.
-N > 1: see DESIGN.md "multi-GPU": one process per GPU.
+N > 1: domain decomposition, one process per GPU over RCCL (torch.distributed "nccl"): the mesh is
+       the reference's "doubling" family (program.cc:509-529), one 128^3-cell coarse cube per rank on a
+       2x1x1 / 2x2x1 / 2x2x2 process grid (weak scaling), interface DoFs exchanged and summed once
+       per operator application.  `--replicas` runs N independent copies instead.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--cells 128] [--degree 4]
 """
@@ -35,6 +38,7 @@ def parse():
     ap.add_argument("--smoother-degree", type=int, default=3)
     ap.add_argument("--vcycle-number", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
     ap.add_argument("--cpu-cells", type=int, default=32, help="finest level of the CPU baseline sample")
     return ap.parse_args()
 
@@ -85,8 +89,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")  # "gloo": functional test on one GPU
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            dist.init_process_group(backend)
 
     import numpy as np
 
@@ -95,11 +104,26 @@ def main():
     ctx = mg.Context(local_rank)
     ns, nr = split_size(args.cells)
     t_setup = time.time()
-    cube = mg.Cube(args.degree, ns, nr)
     vnum = mg.F64 if args.vcycle_number == "f64" else mg.F32
-    solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum)
+    decomposed = world > 1 and not args.replicas
+    if decomposed:
+        if ns != 1:
+            raise SystemExit("--cells must be a power of two for N > 1 (one coarse cube per rank)")
+        procs = mg.process_grid(world)
+        comm = mg.Communicator(ctx, dist)
+        cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
+        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, comm=comm)
+        global_dofs = 1
+        for d in range(3):
+            global_dofs *= procs[d] * args.cells * args.degree + 1
+    else:
+        procs = (1, 1, 1)
+        cube = mg.Cube(args.degree, ns, nr)
+        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum)
     lmax = cube.max_level
     n_dofs = cube.n_dofs(lmax)
+    if not decomposed:
+        global_dofs = n_dofs * world
     # inputs resident in HBM: seeded vector for the matvec, rhs as V-cycle defect
     x = ctx.vector(n_dofs, data=cube.seeded_vector(lmax, 42))
     y = ctx.vector(n_dofs)
@@ -112,7 +136,8 @@ def main():
         ctx.sync()
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if dist.get_backend() == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     def step():
@@ -136,7 +161,7 @@ def main():
     ctx.profile_enable(False)
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -154,7 +179,7 @@ def main():
     t_vc = timed(lambda: solver.vmult(z, rhs), 5)
 
     ms_per_step = 1e3 * elapsed / args.steps
-    total_dofs = n_dofs * world
+    total_dofs = global_dofs
     # Roofline of the dominant kernel.  Of the 7 finest-level cell loops of one step, 3 are the
     # fused Chebyshev iteration (form 2: x, x_old, b, D^-1 read + x_new written = 5 accesses =
     # 40 B/DoF algorithmic, the reference's own 5-access model, matvec_dg_cheby/program.cc:178);
@@ -186,7 +211,10 @@ def main():
                                "step = 1 fp64 vmult + 1 V-cycle (Chebyshev degree %d)" %
                                (args.degree, args.cells, n_dofs, cube.n_levels, args.smoother_degree),
                    "cells_per_dim": args.cells, "degree": args.degree, "n_dofs_per_gpu": n_dofs,
-                   "parallelism": "1 GPU" if world == 1 else "%d independent replicas (no halo exchange yet)" % world},
+                   "global_dofs": total_dofs,
+                   "parallelism": "1 GPU" if world == 1 else
+                   ("domain decomposition %dx%dx%d, one %d^3-cell cube per GPU, interface exchange over RCCL" %
+                    (procs + (args.cells,)) if decomposed else "%d independent replicas" % world)},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
         "roofline": roof(2) if vnum == mg.F64 else roof(0),

@@ -80,6 +80,10 @@ typedef struct
                   void *const *send, void *const *recv);
   /* in-place sum over all ranks of `count` doubles on the host */
   int (*allreduce_sum)(void *user, double *values, int count);
+  /* optional (may be NULL): allocator for the send/recv buffers, so that the transport can own
+   * them (e.g. torch CUDA tensors that RCCL sends from / receives into without staging copies);
+   * the memory must stay valid for the life of the communicator.  NULL: hipMalloc. */
+  void *(*alloc_device)(void *user, size_t bytes);
 } mgx_comm_desc;
 int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm);
 

@@ -46,42 +46,63 @@ class Communicator:
         self.ctx, self.dist = ctx, dist
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.device_transport = (dist.get_backend() == "nccl") if device_transport is None else device_transport
+        self._tensors = {}   # device pointer -> torch CUDA tensor backing an exchange buffer
+        self._p2p = {}       # plan_id -> cached P2POp list
         self._ex = _lib.EXCHANGE_FN(self._exchange)
         self._ar = _lib.ALLREDUCE_FN(self._allreduce)
-        self.desc = _lib.CommDesc(self.rank, self.size, None, self._ex, self._ar)
+        self._al = _lib.ALLOC_FN(self._alloc) if self.device_transport else _lib.ALLOC_FN()
+        self.desc = _lib.CommDesc(self.rank, self.size, None, self._ex, self._ar, self._al)
         check(ctx.lib.mgx_context_set_comm(ctx.h, C.byref(self.desc)))
         ctx._comm = self  # keep the callbacks alive
+
+    def _alloc(self, user, nbytes):
+        """exchange buffers as torch CUDA tensors: RCCL sends from / receives into them directly"""
+        try:
+            import torch
+            t = torch.zeros(max(int(nbytes), 8), dtype=torch.uint8, device="cuda")
+            self._tensors[t.data_ptr()] = t
+            return t.data_ptr()
+        except Exception as e:
+            import sys
+            print("mgx Communicator.alloc failed:", repr(e), file=sys.stderr, flush=True)
+            return None
 
     def _exchange(self, user, plan_id, number, n_neighbors, ranks, counts, send, recv):
         try:
             import torch
             dt = torch.float64 if number == F64 else torch.float32
             es = 8 if number == F64 else 4
+            if self.device_transport:
+                ops = self._p2p.get(plan_id)
+                if ops is None:
+                    ops = []
+                    for k in range(n_neighbors):
+                        cnt = counts[k]
+                        st = self._tensors[send[k]][:cnt * es].view(dt)
+                        rt = self._tensors[recv[k]][:cnt * es].view(dt)
+                        ops.append(self.dist.P2POp(self.dist.isend, st, ranks[k]))
+                        ops.append(self.dist.P2POp(self.dist.irecv, rt, ranks[k]))
+                    self._p2p[plan_id] = ops
+                if ops:
+                    for req in self.dist.batch_isend_irecv(ops):
+                        req.wait()
+                    torch.cuda.synchronize()
+                return 0
             lib, h = self.ctx.lib, self.ctx.h
             ops, bufs = [], []
             for k in range(n_neighbors):
                 rk, cnt = ranks[k], counts[k]
-                if self.device_transport:
-                    st = torch.empty(cnt, dtype=dt, device="cuda")
-                    rt = torch.empty(cnt, dtype=dt, device="cuda")
-                    check(lib.mgx_copy_device(h, C.c_void_p(st.data_ptr()), C.c_void_p(send[k]), cnt * es))
-                else:
-                    st = torch.empty(cnt, dtype=dt)
-                    rt = torch.empty(cnt, dtype=dt)
-                    check(lib.mgx_download(h, C.c_void_p(st.data_ptr()), C.c_void_p(send[k]), cnt * es))
-                bufs.append((st, rt, recv[k], cnt))
+                st = torch.empty(cnt, dtype=dt)
+                rt = torch.empty(cnt, dtype=dt)
+                check(lib.mgx_download(h, C.c_void_p(st.data_ptr()), C.c_void_p(send[k]), cnt * es))
+                bufs.append((rt, recv[k], cnt))
                 ops.append(self.dist.P2POp(self.dist.isend, st, rk))
                 ops.append(self.dist.P2POp(self.dist.irecv, rt, rk))
             if ops:
                 for req in self.dist.batch_isend_irecv(ops):
                     req.wait()
-            if self.device_transport:
-                torch.cuda.synchronize()
-            for (st, rt, rbuf, cnt) in bufs:
-                if self.device_transport:
-                    check(lib.mgx_copy_device(h, C.c_void_p(rbuf), C.c_void_p(rt.data_ptr()), cnt * es))
-                else:
-                    check(lib.mgx_upload(h, C.c_void_p(rbuf), C.c_void_p(rt.data_ptr()), cnt * es))
+            for (rt, rbuf, cnt) in bufs:
+                check(lib.mgx_upload(h, C.c_void_p(rbuf), C.c_void_p(rt.data_ptr()), cnt * es))
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             import sys

@@ -27,11 +27,12 @@ class ExchangeDesc(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), u32p, C.POINTER(vp), C.POINTER(vp))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, f64p, C.c_int)
+ALLOC_FN = C.CFUNCTYPE(vp, vp, C.c_size_t)
 
 
 class CommDesc(C.Structure):
     _fields_ = [("rank", C.c_int), ("size", C.c_int), ("user", vp), ("exchange", EXCHANGE_FN),
-                ("allreduce_sum", ALLREDUCE_FN)]
+                ("allreduce_sum", ALLREDUCE_FN), ("alloc_device", ALLOC_FN)]
 
 
 class CubeBoxDesc(C.Structure):

@@ -773,7 +773,14 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
           MGX_HIP(hipMemcpy(idx, e.index[k], sizeof(uint32_t) * e.count[k], hipMemcpyHostToDevice));
           P->index_dev.push_back(idx);
           void *sb = e.send_buf ? e.send_buf[k] : nullptr, *rb = e.recv_buf ? e.recv_buf[k] : nullptr;
-          const bool own = !(sb && rb);
+          bool own = !(sb && rb);
+          if (own && ctx->comm.alloc_device)
+            {
+              sb  = ctx->comm.alloc_device(ctx->comm.user, es * (e.count[k] + 1));
+              rb  = ctx->comm.alloc_device(ctx->comm.user, es * (e.count[k] + 1));
+              own = false;
+              MGX_REQUIRE(sb && rb, "mgx_operator_create: the communicator's alloc_device failed");
+            }
           if (own)
             {
               MGX_HIP(hipMalloc(&sb, es * (e.count[k] + 1)));
