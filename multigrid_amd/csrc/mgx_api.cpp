@@ -131,6 +131,7 @@ struct mgx_smoother_s
   mgx_operator_t    op = nullptr;
   mgx_smoother_info info{};
   void             *x_old = nullptr, *tmp = nullptr;
+  void             *x_old2 = nullptr; // third iterate buffer (odd number of fused iterations in step())
 };
 
 struct mgx_transfer_s
@@ -155,6 +156,12 @@ struct mgx_solver_s
   double                     *cg_r = nullptr, *cg_z = nullptr, *cg_d = nullptr, *cg_h = nullptr;
   bool                        timing = false;
   std::vector<double>         timings; // n_levels*6
+  // The V-cycle below `graph_level` is a fixed sequence of small, launch-latency-bound kernels on
+  // fixed buffers: it is captured into a HIP graph on its second execution and replayed afterwards
+  int             graph_level = -1, graph_calls = 0;
+  bool            graph_failed = false;
+  hipGraph_t      graph = nullptr;
+  hipGraphExec_t  graph_exec = nullptr;
 };
 
 namespace
@@ -1068,6 +1075,7 @@ int mgx_smoother_destroy(mgx_smoother_t sm)
     return MGX_OK;
   (void)hipStreamSynchronize(sm->op->ctx->stream);
   (void)hipFree(sm->x_old);
+  (void)hipFree(sm->x_old2);
   (void)hipFree(sm->tmp);
   delete sm;
   return MGX_OK;
@@ -1105,14 +1113,14 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 // PreconditionChebyshev's update as the after-operation):
 //   out <- cur + f1 (cur - out) + f2 D^-1 (b - A cur);  mode 2 general, 3 without the f1 term,
 //   4 with out == 0 on entry.  sm->tmp carries the partial sums of brick-surface DoFs.
-static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, void *out, const void *b, double f1,
-                                double f2)
+static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, const void *old, void *out,
+                                const void *b, double f1, double f2)
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
   {
     ProfileBracket pb(op, mode);
-    launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2);
+    launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old);
   }
   if (op->plan)
     {
@@ -1120,25 +1128,28 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, vo
       // update there
       MGX_TRY(exchange_add(op, sm->tmp));
       launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
-                              op->plan->n_shared, sm->tmp);
+                              op->plan->n_shared, sm->tmp, old);
     }
   launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
-                          op->d.n_constrained);
+                          op->d.n_constrained, nullptr, old);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }
 
-// vmult (zero start) / step (nonzero start).  *px is the iterate; with allow_swap the result may
-// be handed back in the smoother's second buffer (pointer swap instead of a copy, as deal.II
-// swaps solution and solution_old).
-static int smoother_apply(mgx_smoother_t sm, void **px, const void *b, bool is_step, bool allow_swap)
+// vmult (zero start) / step (nonzero start) on a brick-scheduled level.  Every fused iteration
+// reads the current iterate (gathered by the cell loop) and x_old, and writes the new iterate into
+// a buffer that is not the current one.  The targets rotate over the caller's vector X and the
+// smoother's buffers Y (and Z for an odd number of iterations from a nonzero start) such that the
+// LAST iterate lands in X: no pointer swap (deal.II swaps solution/solution_old) and no copy, and
+// all pointers stay fixed from call to call (which lets the coarse part of the V-cycle be
+// replayed as a HIP graph).
+static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_step)
 {
   const mgx_smoother_info &I  = sm->info;
   mgx_operator_t           op = sm->op;
   hipStream_t              s  = op->ctx->stream;
   const int                num = op->d.number;
   const size_t             n   = op->d.n_dofs;
-  void                    *x   = *px;
   if (!op->d.bricks.available())
     {
       if (is_step)
@@ -1150,54 +1161,69 @@ static int smoother_apply(mgx_smoother_t sm, void **px, const void *b, bool is_s
         launch_cheb_update(s, num, 0, x, sm->x_old, b, nullptr, op->d.inv_diag, 0., 1. / I.theta, n);
       return cheb_loop(sm, x, b);
     }
-  void *cur = x, *other = sm->x_old;
-  bool  other_is_zero = false;
-  if (is_step)
+  const bool three_term = I.degree >= 2 && std::fabs(I.delta) >= 1e-40;
+  const int  n_loop     = three_term ? I.degree - 1 : 0; // iterations of the three-term recurrence
+  void      *X = x, *Y = sm->x_old;
+  if (!is_step)
     {
-      MGX_TRY(cheb_fused_iteration(sm, 3, cur, other, b, 0., 1. / I.theta));
-      std::swap(cur, other);
-    }
-  else
-    {
+      // x_1 = (1/theta) D^-1 b goes where an alternation over {X,Y} ends in X
+      void *cur = (n_loop % 2 == 0) ? X : Y, *old = nullptr;
       launch_cheb_init(s, num, cur, b, op->d.inv_diag, 1. / I.theta, n);
-      other_is_zero = true; // x_0 = 0
-    }
-  if (I.degree >= 2 && std::fabs(I.delta) >= 1e-40)
-    {
       double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
-      for (int k = 0; k < I.degree - 1; ++k)
+      for (int k = 0; k < n_loop; ++k)
+        {
+          const double rhokp = 1. / (2. * sigma - rhok);
+          const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
+          rhok      = rhokp;
+          void *out = (cur == X) ? Y : X;
+          MGX_TRY(cheb_fused_iteration(sm, k == 0 ? 4 : 2, cur, old, out, b, f1, f2)); // k = 0: x_0 = 0
+          old = cur;
+          cur = out;
+        }
+      return MGX_OK;
+    }
+  // step(): 1 + n_loop iterations starting from X
+  const int T = 1 + n_loop;
+  if (T % 2 == 1 && T >= 3 && !sm->x_old2)
+    MGX_HIP(hipMalloc(&sm->x_old2, number_size(num) * n));
+  void  *Z = sm->x_old2, *cur = X, *old = nullptr;
+  double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+  for (int k = 1; k <= T; ++k)
+    {
+      void *out;
+      if (T % 2 == 0)
+        out = (cur == X) ? Y : X;
+      else if (T == 1)
+        out = Y; // copied back below
+      else
+        out = k == 1 ? Y : (k == 2 ? Z : (k == 3 ? X : ((cur == X) ? Y : X)));
+      if (k == 1)
+        MGX_TRY(cheb_fused_iteration(sm, 3, cur, nullptr, out, b, 0., 1. / I.theta));
+      else
         {
           const double rhokp = 1. / (2. * sigma - rhok);
           const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
           rhok = rhokp;
-          MGX_TRY(cheb_fused_iteration(sm, other_is_zero ? 4 : 2, cur, other, b, f1, f2));
-          other_is_zero = false;
-          std::swap(cur, other);
+          MGX_TRY(cheb_fused_iteration(sm, 2, cur, old, out, b, f1, f2));
         }
+      old = cur;
+      cur = out;
     }
-  if (cur != x)
-    {
-      if (allow_swap)
-        {
-          sm->x_old = x;
-          *px       = cur;
-        }
-      else
-        launch_copy_cast(s, x, num, cur, num, n);
-    }
+  if (cur != X)
+    launch_copy_cast(s, X, num, cur, num, n);
   return MGX_OK;
 }
 
 int mgx_smoother_vmult(mgx_smoother_t sm, void *x, const void *b)
 {
   MGX_REQUIRE(sm && x && b && x != b, "mgx_smoother_vmult: bad argument");
-  return smoother_apply(sm, &x, b, false, false);
+  return smoother_apply(sm, x, b, false);
 }
 
 int mgx_smoother_step(mgx_smoother_t sm, void *x, const void *b)
 {
   MGX_REQUIRE(sm && x && b && x != b, "mgx_smoother_step: bad argument");
-  return smoother_apply(sm, &x, b, true, false);
+  return smoother_apply(sm, x, b, true);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1379,6 +1405,10 @@ int mgx_solver_destroy(mgx_solver_t S)
     (void)hipFree(p);
   for (auto p : S->bc_zero_dev)
     (void)hipFree(p);
+  if (S->graph_exec)
+    (void)hipGraphExecDestroy(S->graph_exec);
+  if (S->graph)
+    (void)hipGraphDestroy(S->graph);
   (void)hipFree(S->cg_r);
   (void)hipFree(S->cg_z);
   (void)hipFree(S->cg_d);
@@ -1479,6 +1509,10 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
                                     &sm)); // :282-284
       S->smooth.push_back(sm);
     }
+  if (!std::getenv("MGX_NO_GRAPH"))
+    for (int l = 0; l < nl; ++l)
+      if (S->matrix[l]->d.n_dofs <= 600000u)
+        S->graph_level = l;
   const size_t nmax = S->matrix[nl - 1]->d.n_dofs;
   MGX_HIP(hipMalloc((void **)&S->cg_r, 8 * nmax));
   MGX_HIP(hipMalloc((void **)&S->cg_z, 8 * nmax));
@@ -1494,15 +1528,60 @@ static void set_bc(mgx_solver_t S, int level, double *v, bool zero)
                         zero ? S->bc_zero_dev[level] : S->bc_value_dev[level], S->bc_count[level]);
 }
 
-// MultigridSolver::v_cycle (multigrid_solver.h:641-681)
+static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles);
+
+static bool graph_usable(mgx_solver_t S, int level)
+{
+  if (S->graph_level < 0 || level != S->graph_level || S->graph_failed || S->timing || S->ctx->has_comm)
+    return false;
+  if (S->ctx->profile)
+    for (int l = 0; l <= level; ++l)
+      if (S->matrix[l]->profiled)
+        return false; // HIP-event brackets must stay outside a captured region
+  return true;
+}
+
+// MultigridSolver::v_cycle (multigrid_solver.h:641-681), with graph replay of the coarse part
 static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
+{
+  if (my_n_cycles != 1 || !graph_usable(S, level))
+    return v_cycle_eager(S, level, my_n_cycles);
+  hipStream_t s = S->ctx->stream;
+  if (S->graph_exec)
+    {
+      MGX_HIP(hipGraphLaunch(S->graph_exec, s));
+      return MGX_OK;
+    }
+  if (S->graph_calls++ == 0)
+    return v_cycle_eager(S, level, 1); // first execution eager: lazy allocations happen here
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
+    {
+      S->graph_failed = true;
+      return v_cycle_eager(S, level, 1);
+    }
+  const int  status = v_cycle_eager(S, level, 1);
+  hipError_t e      = hipStreamEndCapture(s, &S->graph);
+  if (status != MGX_OK || e != hipSuccess || !S->graph ||
+      hipGraphInstantiate(&S->graph_exec, S->graph, nullptr, nullptr, 0) != hipSuccess)
+    {
+      S->graph_failed = true;
+      S->graph_exec   = nullptr;
+      (void)hipGetLastError();
+      return v_cycle_eager(S, level, 1); // nothing was executed during the capture
+    }
+  MGX_TRACE("v_cycle: levels 0..%d captured into a HIP graph", level);
+  MGX_HIP(hipGraphLaunch(S->graph_exec, s));
+  return MGX_OK;
+}
+
+static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
 {
   hipStream_t s = S->ctx->stream;
   if (level == 0)
     {
       Stopwatch sw(S, 0, 0);
       S->timings[1] += 1;
-      return smoother_apply(S->smooth[0], &S->solution_update[0], S->defect[0], false, true); // :647 (MGCoarseFromSmoother :72-91)
+      return smoother_apply(S->smooth[0], S->solution_update[0], S->defect[0], false); // :647 (MGCoarseFromSmoother :72-91)
     }
   const size_t nc = S->matrix[level - 1]->d.n_dofs;
   for (int c = 0; c < my_n_cycles; ++c)
@@ -1510,9 +1589,9 @@ static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
       {
         Stopwatch sw(S, level, 5);
         if (c == 0) // :656-659
-          MGX_TRY(smoother_apply(S->smooth[level], &S->solution_update[level], S->defect[level], false, true));
+          MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], false));
         else
-          MGX_TRY(smoother_apply(S->smooth[level], &S->solution_update[level], S->defect[level], true, true));
+          MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true));
       }
       {
         Stopwatch sw(S, level, 0);
@@ -1531,7 +1610,7 @@ static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
       }
       {
         Stopwatch sw(S, level, 5);
-        MGX_TRY(smoother_apply(S->smooth[level], &S->solution_update[level], S->defect[level], true, true)); // :678
+        MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true)); // :678
       }
     }
   return MGX_OK;
@@ -1547,8 +1626,8 @@ int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, dou
     Stopwatch    sw(S, 0, 0);
     const size_t n0 = S->matrix[0]->d.n_dofs;
     launch_copy_cast(s, S->defect[0], S->vnumber, S->rhs[0], MGX_F64, n0);
-    MGX_TRY(smoother_apply(S->smooth[0], &S->t[0], S->defect[0], false, true));
-    MGX_TRY(smoother_apply(S->smooth[0], &S->t[0], S->defect[0], true, true));
+    MGX_TRY(smoother_apply(S->smooth[0], S->t[0], S->defect[0], false));
+    MGX_TRY(smoother_apply(S->smooth[0], S->t[0], S->defect[0], true));
     launch_copy_cast(s, S->solution[0], MGX_F64, S->t[0], S->vnumber, n0);
     S->timings[1] += 2;
   }

@@ -86,6 +86,7 @@ namespace mgx
   {
     const T *a;       // kResidual: rhs ; kCheb: rhs b of the smoother
     const T *b;       // kCheb: inverse diagonal
+    const T *old;     // kCheb: previous iterate x_old (may alias out: read before written)
     T       *out;     // result vector
     T       *partial; // carrier of partial sums between colour launches (may alias out)
     T        f1, f2;
@@ -126,7 +127,7 @@ namespace mgx
         const T av = post.a[il], bv = post.b[il], xi = src[il];
         T       ov = T(0);
         if (MODE == kCheb)
-          ov = post.out[il];
+          ov = post.old[il];
         val  = need_partial ? val + pv : val;
         T xn = xi + post.f2 * bv * (av - val);
         if (MODE == kCheb)
@@ -755,11 +756,12 @@ namespace mgx
 
   template <typename T>
   static void brick_dispatch(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                             const void *b, void *out, void *partial, double f1, double f2)
+                             const void *b, void *out, void *partial, double f1, double f2, const void *old)
   {
     BrickPost<T> post;
     post.a       = (const T *)a;
     post.b       = (const T *)b;
+    post.old     = (const T *)old;
     post.out     = (T *)out;
     post.partial = (T *)partial;
     post.f1      = (T)f1;
@@ -790,11 +792,13 @@ namespace mgx
   }
 
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                         const void *b, void *out, void *partial, double f1, double f2)
+                         const void *b, void *out, void *partial, double f1, double f2, const void *old)
   {
+    if (!old)
+      old = out;
     if (op.number == 1)
-      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2);
+      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old);
     else
-      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2);
+      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old);
   }
 } // namespace mgx

@@ -128,7 +128,7 @@ namespace mgx
   __global__ void __launch_bounds__(256)
     k_cheb_constrained(int mode, const T *__restrict__ x, T *__restrict__ out, const T *__restrict__ b,
                        const T *__restrict__ dinv, T f1, T f2, const uint32_t *__restrict__ list, uint32_t count,
-                       const T *__restrict__ ax)
+                       const T *__restrict__ ax, const T *old)
   {
     GRID_STRIDE(i, count)
     {
@@ -136,7 +136,7 @@ namespace mgx
       const T        xi = x[c];
       T              xn = xi + f2 * dinv[c] * (b[c] - (ax ? ax[c] : xi));
       if (mode == 2)
-        xn += f1 * (xi - out[c]);
+        xn += f1 * (xi - old[c]);
       else if (mode == 4)
         xn += f1 * xi;
       out[c] = xn;
@@ -415,13 +415,15 @@ namespace mgx
 
   void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
                                const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count,
-                               const void *ax)
+                               const void *ax, const void *old)
   {
     if (count == 0)
       return;
+    if (!old)
+      old = out;
     BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_constrained<T>), stream_grid(count), dim3(256), 0, s, mode,
                                          (const T *)x, (T *)out, (const T *)b, (const T *)dinv, (T)f1, (T)f2, list,
-                                         count, (const T *)ax));
+                                         count, (const T *)ax, (const T *)old));
   }
 
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count)
