@@ -78,7 +78,9 @@ namespace mgx
     // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
     kNoStore   = 8, // rounds only, no write-out
     kNoCompute = 9, // write-out only, no rounds
-    kInitOnly  = 10 // prologue only
+    kInitOnly  = 10, // prologue only
+    kNoScatter = 11, // rounds without the accumulator update and its barrier, no write-out
+    kNoBarrier = 12  // rounds without the per-round barrier, no write-out
   };
 
   template <typename T>
@@ -618,8 +620,9 @@ namespace mgx
     const EOMat<T> &M = B->mass, &K = B->lapl;
     __syncthreads();
 
-    uint32_t nvalid = 0;
-    auto gather = [&](int round, T(&r)[N]) {
+    // source values are prefetched two rounds ahead (two register sets, statically indexed by
+    // unrolling the round loop by two): an HBM miss takes about as long as one round
+    auto gather = [&](int round, T(&r)[N], uint32_t &nvalid) {
       const int       bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
       const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
       const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
@@ -631,20 +634,20 @@ namespace mgx
         r[1 + i] = src[m1 + (uint32_t)i];
       r[P] = src[b2 != kInvalid ? b2 + loff : 0u];
     };
-    T rn[N];
-    gather(0, rn);
+    T        rA[N], rB[N];
+    uint32_t vA = 0, vB = 0;
+    gather(0, rA, vA);
+    gather(1, rB, vB);
 
-#pragma unroll 1
-    for (int round = 0; round < ((MODE == kNoCompute || MODE == kInitOnly) ? 0 : 8); ++round)
-      {
+    auto one_round = [&](int round, T(&rn)[N], uint32_t &nvalid) {
         T r[N], t1[N], k1[N], xe[H1], xo[H1];
         r[0] = (nvalid & 1u) ? rn[0] : T(0);
 #pragma unroll
         for (int i = 1; i < P; ++i)
           r[i] = (nvalid & 2u) ? rn[i] : T(0);
         r[P] = (nvalid & 4u) ? rn[P] : T(0);
-        if (round < 7)
-          gather(round + 1, rn);
+        if (round < 6)
+          gather(round + 2, rn, nvalid); // this register set is free again: refill it
         // x: t1 = M u, k1 = K u
         eo_split<N, T>(r, xe, xo);
         eo_apply<N, T>(M, xe, xo, t1);
@@ -710,8 +713,14 @@ namespace mgx
 #pragma unroll
         for (int i = 0; i < N; ++i)
           r[i] = fma(c2, t1[i], r[i]);
-        lds_barrier(); // all accumulator updates of the previous round have landed
-        if (compute)
+        if (MODE != kNoScatter && MODE != kNoBarrier)
+          lds_barrier(); // all accumulator updates of the previous round have landed
+        if (MODE == kNoScatter)
+          {
+            if (r[0] == T(12345.678))
+              acc[tid] = r[1]; // keep the sweeps alive
+          }
+        else if (compute)
           {
             // thread (i = a, j = b) owns the z-line: accumulate the column of the brick array
             const int bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
@@ -720,10 +729,19 @@ namespace mgx
             for (int i = 0; i < N; ++i)
               col[i * G * G] += r[i];
           }
+    };
+    if (MODE != kNoCompute && MODE != kInitOnly)
+      {
+#pragma unroll 1
+        for (int round = 0; round < 8; round += 2)
+          {
+            one_round(round, rA, vA);
+            one_round(round + 1, rB, vB);
+          }
       }
     __syncthreads();
 
-    if (MODE == kNoStore || MODE == kInitOnly)
+    if (MODE == kNoStore || MODE == kInitOnly || MODE == kNoScatter || MODE == kNoBarrier)
       {
         if (acc[tid] == T(12345.678))
           post.out[tid] = acc[tid]; // keep the rounds alive
@@ -777,6 +795,8 @@ namespace mgx
         case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post); break; \
         case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post); break; \
         case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post); break; \
+        case kNoScatter: brick_launch<PP, T, kNoScatter>(s, op, (const T *)src, post); break; \
+        case kNoBarrier: brick_launch<PP, T, kNoBarrier>(s, op, (const T *)src, post); break; \
         default: brick_launch<PP, T, kChebZeroOld>(s, op, (const T *)src, post); break; \
       }                                                                            \
     break;
