@@ -169,11 +169,12 @@ typedef struct
   const double *shape_values;
   const double *colloc_grad;
   const double *qweights;
-  /* Optional scheduling hint, may be NULL.  If cells [64k, 64k+64) form 4x4x4 bricks in Morton
-   * order (two uniform refinements of a common ancestor -- what p4est/deal.II produce), the
-   * library runs its atomic-free brick cell loop; brick_colour[k] (n_cells/64 entries, < 32) is
-   * a colouring in which bricks that share DoFs differ.  Without the hint a greedy colouring is
-   * computed; the brick structure itself is always verified against idx27. */
+  /* Optional scheduling hint, may be NULL.  If consecutive cells form bricks in Morton order
+   * -- 64 cells = 4x4x4 for p <= 4, 8 cells = 2x2x2 (the children of one parent) for p >= 5, which
+   * is what p4est/deal.II produce on uniformly refined meshes -- the library runs its atomic-free
+   * brick cell loop; brick_colour[k] (one entry per brick, < 32) is a colouring in which bricks
+   * that share DoFs differ.  Without the hint a greedy colouring is computed; the brick structure
+   * itself is always verified against idx27. */
   const uint8_t *brick_colour;
   /* Optional, may be NULL: a numbering-independent global index per local DoF (the provider's
    * lexicographic grid id).  Used for the start vector of the smoother's eigenvalue estimate

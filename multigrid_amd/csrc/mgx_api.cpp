@@ -709,13 +709,20 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   MGX_HIP(hipMalloc(&d.inv_diag, number_size(d.number) * d.n_dofs));
   // brick schedule for the atomic-free cell loop (mgx_brick.hip); MGX_NO_BRICKS=1 keeps the
   // per-cell kernel (A/B measurements)
-  if (!std::getenv("MGX_NO_BRICKS"))
+  if (!std::getenv("MGX_NO_BRICKS") && (p <= 4 || d.separable))
     {
       BrickHost   bh;
       std::string why;
       const mgx_exchange_desc *ex = desc->exchange;
-      if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour,
-                       ex ? ex->shared : nullptr, ex ? ex->n_shared : 0, bh, why))
+      // A colour launch needs a few hundred bricks to fill 256 CUs; below that the per-cell kernel
+      // (all cells of the level in one launch, atomic scatter) is faster.  Measured cross-over on
+      // MI355X: between 512 and 4096 bricks for p = 4 and p = 8 (tools/vcycle_levels.py).
+      const uint32_t brick_min   = std::getenv("MGX_BRICK_MIN") ? (uint32_t)std::atoi(std::getenv("MGX_BRICK_MIN")) : 2048u;
+      const uint32_t brick_cells = p <= 4 ? 64u : 8u;
+      if (desc->n_cells / brick_cells < brick_min)
+        MGX_TRACE("operator_create: per-cell kernel (%u bricks < %u)", desc->n_cells / brick_cells, brick_min);
+      else if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour,
+                            ex ? ex->shared : nullptr, ex ? ex->n_shared : 0, bh, why))
         {
           BrickData &b = d.bricks;
           b.n_bricks   = bh.n_bricks;

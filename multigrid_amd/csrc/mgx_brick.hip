@@ -25,18 +25,27 @@
 
 namespace mgx
 {
+  // Brick shape: 4x4x4 cells for p <= 4 (64 consecutive Morton cells), 2x2x2 for p >= 5 (the 8
+  // children of one parent), so that the (NB p + 1)^3 fp64 accumulator stays below 55 kB of LDS.
+  // p <= 4: a cell needs (p+1)^2 <= 25 threads, a wave owns two cells of a round, four waves
+  // process the 8 same-parity cells of a round.  p >= 5: the 8 cells of a brick are mutually
+  // adjacent, so a round is one cell on (p+1)^2 threads (one or two waves).
   template <int P>
   struct BCfg
   {
-    static constexpr int NB       = 4;           // cells per direction
-    static constexpr int N        = P + 1;
-    static constexpr int LN       = N | 1;       // odd x-line pitch (bank-conflict free)
-    static constexpr int G        = NB * P + 1;  // points per direction
-    static constexpr int NE1      = 2 * NB + 1;  // mesh entities per direction
-    static constexpr int NE       = NE1 * NE1 * NE1;
-    static constexpr int TPC      = N * N;
-    static constexpr int THREADS  = 256;         // 4 waves x 2 cells per round
-    static constexpr int CELL_LDS = N * N * LN;
+    static constexpr int  NB         = P <= 4 ? 4 : 2; // cells per direction
+    static constexpr int  NCELLS     = NB * NB * NB;
+    static constexpr int  N          = P + 1;
+    static constexpr int  LN         = N | 1;          // odd x-line pitch (bank-conflict free)
+    static constexpr int  G          = NB * P + 1;     // points per direction
+    static constexpr int  NE1        = 2 * NB + 1;     // mesh entities per direction
+    static constexpr int  NE         = NE1 * NE1 * NE1;
+    static constexpr int  TPC        = N * N;
+    static constexpr bool kTwoPerWave = P <= 4;        // two cells per wave, 8 cells per round
+    static constexpr int  ROUND_CELLS = kTwoPerWave ? 8 : 1;
+    static constexpr int  THREADS    = kTwoPerWave ? 256 : ((TPC + 63) / 64) * 64;
+    static constexpr bool kWaveSync  = kTwoPerWave || THREADS == 64; // transposes stay inside one wave
+    static constexpr int  CELL_LDS   = N * N * LN;
   };
 
   template <int N, typename T>
@@ -181,7 +190,7 @@ namespace mgx
     constexpr int G  = C::G;
     constexpr int E1 = C::NE1;
     constexpr int P3 = P * P * P;
-    constexpr int NA = 64 * P3;
+    constexpr int NA = C::NCELLS * P3;
     constexpr bool kFixedLane = (C::THREADS % P3) == 0; // per-thread decode hoisted out of the loops
     constexpr int NBF = G * G * G - (G - 1) * (G - 1) * (G - 1);
     int slot_rel = 0, pnt_rel = 0, k = 0;
@@ -587,9 +596,8 @@ namespace mgx
     constexpr int G  = C::G;
     constexpr int E1 = C::NE1;
     constexpr int H1 = N / 2 + 1;
-    static_assert(C::TPC <= 32 && C::THREADS == 256, "two cells per wave, four waves");
     __shared__ T        acc[G * G * G];
-    __shared__ T        U[8 * C::CELL_LDS];
+    __shared__ T        U[C::ROUND_CELLS * C::CELL_LDS];
     __shared__ uint32_t ebase[C::NE];
     __shared__ uint8_t  eflags[C::NE];
 
@@ -603,10 +611,12 @@ namespace mgx
     for (int i = tid; i < G * G * G; i += C::THREADS)
       acc[i] = T(0);
 
+    // p <= 4: lanes [0,TPC) and [32,32+TPC) of each wave own the two cells of that wave;
+    // p >= 5: the workgroup owns one cell per round
     const int  lane    = tid & 63;
-    const int  t       = lane & 31;
+    const int  t       = C::kTwoPerWave ? (lane & 31) : tid;
     const bool compute = t < C::TPC;
-    const int  lc      = 2 * (tid >> 6) + (lane >> 5);
+    const int  lc      = C::kTwoPerWave ? 2 * (tid >> 6) + (lane >> 5) : 0;
     const int  a       = compute ? t % N : 0;
     const int  b       = compute ? t / N : 0;
     T         *Uc      = U + lc * C::CELL_LDS;
@@ -618,6 +628,14 @@ namespace mgx
     const uint32_t loff = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
     const int hx = 2 * (lc & 1), hy = 2 * ((lc >> 1) & 1), hz = 2 * (lc >> 2);
     const EOMat<T> &M = B->mass, &K = B->lapl;
+    // ordering of the LDS transposes: inside one wave a compiler barrier is enough, a cell spread
+    // over two waves needs the workgroup barrier
+    auto phase_sync = [&]() {
+      if (C::kWaveSync)
+        wave_sync();
+      else
+        lds_barrier();
+    };
     __syncthreads();
 
     // source values are prefetched two rounds ahead (two register sets, statically indexed by
@@ -658,22 +676,22 @@ namespace mgx
             for (int i = 0; i < N; ++i)
               Uc[xl + i] = t1[i];
           }
-        wave_sync();
+        phase_sync();
 #pragma unroll
         for (int i = 0; i < N; ++i)
           t1[i] = Uc[yl + i * LN]; // y-line of M_x u
-        wave_sync();
+        phase_sync();
         if (compute)
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
               Uc[xl + i] = k1[i];
           }
-        wave_sync();
+        phase_sync();
 #pragma unroll
         for (int i = 0; i < N; ++i)
           k1[i] = Uc[yl + i * LN]; // y-line of K_x u
-        wave_sync();
+        phase_sync();
         // y: t2 = M t1 ; s2 = c_x M k1 + c_y K t1
         T t2[N], s2[N];
         eo_split<N, T>(t1, xe, xo);
@@ -690,18 +708,18 @@ namespace mgx
             for (int i = 0; i < N; ++i)
               Uc[yl + i * LN] = t2[i];
           }
-        wave_sync();
+        phase_sync();
 #pragma unroll
         for (int i = 0; i < N; ++i)
           t2[i] = Uc[zl + i * PL]; // z-line of M_y M_x u
-        wave_sync();
+        phase_sync();
         if (compute)
           {
 #pragma unroll
             for (int i = 0; i < N; ++i)
               Uc[yl + i * LN] = s2[i];
           }
-        wave_sync();
+        phase_sync();
 #pragma unroll
         for (int i = 0; i < N; ++i)
           s2[i] = Uc[zl + i * PL];
@@ -765,7 +783,7 @@ namespace mgx
           hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
                              bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
                              (T)op.coef[2], post);
-        else
+        else if constexpr (P <= 4) // the quadrature-point form is built for 4x4x4 bricks only
           hipLaunchKernelGGL((brick_loop_kernel<P, T, (MODE >= kNoStore ? 0 : MODE)>), dim3(count),
                              dim3(C::THREADS), 0, s, src, first, bd.ent_base, bd.ent_flags,
                              (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
@@ -806,6 +824,11 @@ namespace mgx
         MGX_BRICK_CASE(2)
         MGX_BRICK_CASE(3)
         MGX_BRICK_CASE(4)
+        MGX_BRICK_CASE(5)
+        MGX_BRICK_CASE(6)
+        MGX_BRICK_CASE(7)
+        MGX_BRICK_CASE(8)
+        MGX_BRICK_CASE(9)
         default: break;
       }
 #undef MGX_BRICK_CASE

@@ -19,7 +19,6 @@ namespace mgx
     constexpr uint32_t kInvalid    = 0xFFFFFFFFu;
     constexpr int      kMaxColours = 32;
     constexpr uint32_t kUnset      = 0xFFFFFFFEu;
-    constexpr int      E1 = 9, NE = 729;
 
     inline int compact3(int m)
     {
@@ -39,17 +38,20 @@ namespace mgx
                     std::string &why)
   {
     out = BrickHost();
-    if (p < 1 || p > 4)
+    if (p < 1 || p > 9)
       {
-        why = "degree > 4: (4p+1)^3 accumulator does not fit the LDS budget";
+        why = "degree out of range";
         return false;
       }
-    if (n_cells < 64 || n_cells % 64 != 0)
+    // 4x4x4 bricks for p <= 4, 2x2x2 (the children of one parent) for p >= 5
+    const int NBd = p <= 4 ? 4 : 2, CB = NBd * NBd * NBd, E1 = 2 * NBd + 1, NE = E1 * E1 * E1;
+    if (n_cells < (uint32_t)CB || n_cells % CB != 0)
       {
-        why = "fewer than 64 cells or cell count not a multiple of 64";
+        why = "fewer cells than one brick or cell count not a multiple of the brick size";
         return false;
       }
-    const uint32_t nb = n_cells / 64;
+    const uint32_t nb = n_cells / CB;
+    out.n_entities    = NE;
     out.n_bricks      = nb;
     out.ent_base.assign((size_t)nb * NE, kInvalid);
     out.ent_flags.assign((size_t)nb * NE, 0);
@@ -58,14 +60,14 @@ namespace mgx
 #pragma omp parallel for schedule(static)
     for (uint32_t b = 0; b < nb; ++b)
       {
-        uint32_t key[NE];
+        uint32_t key[729];
         for (int i = 0; i < NE; ++i)
           key[i] = kUnset;
         uint32_t *ent = &out.ent_base[(size_t)b * NE];
-        for (int m = 0; m < 64; ++m)
+        for (int m = 0; m < CB; ++m)
           {
             const int      bx = compact3(m), by = compact3(m >> 1), bz = compact3(m >> 2);
-            const uint32_t c  = 64 * b + m;
+            const uint32_t c  = (uint32_t)CB * b + m;
             for (int e = 0; e < 27; ++e)
               {
                 const int cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
@@ -93,7 +95,7 @@ namespace mgx
       }
     if (!structured)
       {
-        why = "cells [64k,64k+64) do not form 4x4x4 bricks in Morton order";
+        why = "consecutive cells do not form bricks in Morton order";
         out = BrickHost();
         return false;
       }

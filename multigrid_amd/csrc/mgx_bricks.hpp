@@ -11,6 +11,7 @@ namespace mgx
   {
     uint32_t              n_bricks  = 0;
     int                   n_colours = 0;
+    int                   n_entities = 729; // entities per brick: 9^3 (4x4x4 cells) or 5^3 (2x2x2 cells)
     std::vector<uint32_t> colour_start; // [n_colours+1] into the colour-sorted brick order
     std::vector<uint32_t> ent_base;     // [n_bricks*729] first DoF per brick entity (constrained: invalid)
     std::vector<uint8_t>  ent_flags;    // [n_bricks*729] bit0 FIRST, bit1 LAST

@@ -272,13 +272,16 @@ namespace
             L.idx27[27 * (size_t)c + e]       = base >= L.n_free ? MGX_INVALID_INDEX : base;
           }
       }
-    if (level >= 2) // 64 consecutive Morton cells = one 4x4x4 brick; 8 colours by brick parity
+    // bricks of the device cell loop: 4x4x4 cells (64 consecutive Morton cells) for p <= 4,
+    // 2x2x2 (the 8 children of a parent) for p >= 5; 8 colours by brick parity
+    const uint32_t nbd = p <= 4 ? 4 : 2, cb = nbd * nbd * nbd;
+    if (level >= (p <= 4 ? 2 : 1))
       {
-        L.brick_colour.resize(nc / 64);
-        for (uint32_t b = 0; b < nc / 64; ++b)
+        L.brick_colour.resize(nc / cb);
+        for (uint32_t b = 0; b < nc / cb; ++b)
           {
-            const uint32_t X = L.coords[3 * (size_t)(64 * b)] / 4, Y = L.coords[3 * (size_t)(64 * b) + 1] / 4,
-                           Z = L.coords[3 * (size_t)(64 * b) + 2] / 4;
+            const uint32_t X = L.coords[3 * (size_t)(cb * b)] / nbd, Y = L.coords[3 * (size_t)(cb * b) + 1] / nbd,
+                           Z = L.coords[3 * (size_t)(cb * b) + 2] / nbd;
             L.brick_colour[b] = (uint8_t)((X & 1) | ((Y & 1) << 1) | ((Z & 1) << 2));
           }
       }

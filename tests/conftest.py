@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# the parity cases are small: let every level that has at least one brick run the brick cell loop
+# (the production default switches to it from 2048 bricks on; test_gpu_parity.py has one case at the
+# default threshold)
+os.environ.setdefault("MGX_BRICK_MIN", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

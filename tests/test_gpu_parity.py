@@ -192,6 +192,25 @@ def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
     orc.close()
 
 
+def test_default_brick_threshold(ctx, monkeypatch):
+    """With the production threshold (bricks from 2048 per level on) small levels use the per-cell
+    kernel and the finest level of a 64^3 mesh (4096 bricks) the brick loop; same results."""
+    monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
+    p, nr = 2, 6
+    cube = mg.Cube(p, 1, nr)
+    orc = Oracle(p, 1, nr, degree=3, n_cycles=1)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    x = cube.seeded_vector(nr, 5)
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    solver.matrix_dp(nr).vmult(dst, src)
+    assert rel(dst.download(), orc.vmult(nr, x)) < 1e-12
+    solver.vmult(dst, src)
+    assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    solver.close()
+    cube.close()
+    orc.close()
+
+
 def test_readme_known_answers_on_gpu(ctx):
     """README.md:143 (512 cells): the GPU path itself reproduces the reference's printed numbers."""
     cube = mg.Cube(4, 1, 3)

@@ -3,11 +3,12 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multigrid_amd as mg
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+deg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ns, nr = cells, 0
 while ns % 2 == 0 and ns > 1:
     ns //= 2; nr += 1
 ctx = mg.Context(0)
-cube = mg.Cube(4, ns, nr)
+cube = mg.Cube(deg, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
 x = ctx.vector(cube.n_dofs(l), data=cube.seeded_vector(l, 42))
