@@ -719,7 +719,9 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       // MI355X: between 512 and 4096 bricks for p = 4 and p = 8 (tools/vcycle_levels.py).
       const uint32_t brick_min   = std::getenv("MGX_BRICK_MIN") ? (uint32_t)std::atoi(std::getenv("MGX_BRICK_MIN")) : 2048u;
       const uint32_t brick_cells = p <= 4 ? 64u : 8u;
-      if (desc->n_cells / brick_cells < brick_min)
+      if (desc->n_dofs >= 0x3FFFFFFFu)
+        MGX_TRACE("operator_create: per-cell kernel (%u DoFs do not fit the 30-bit entity index)", desc->n_dofs);
+      else if (desc->n_cells / brick_cells < brick_min)
         MGX_TRACE("operator_create: per-cell kernel (%u bricks < %u)", desc->n_cells / brick_cells, brick_min);
       else if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour,
                             ex ? ex->shared : nullptr, ex ? ex->n_shared : 0, bh, why))
@@ -729,11 +731,14 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
           b.n_colours  = bh.n_colours;
           for (int c = 0; c <= bh.n_colours; ++c)
             b.colour_start[c] = bh.colour_start[c];
+          // device table word: bits 0..29 first DoF, bit 30 FIRST, bit 31 LAST (mgx_brick.hip)
+          for (size_t i = 0; i < bh.ent_base.size(); ++i)
+            if (bh.ent_base[i] != MGX_INVALID_INDEX)
+              bh.ent_base[i] |= (uint32_t)(bh.ent_flags[i] & 3u) << 30;
           MGX_HIP(hipMalloc((void **)&b.ent_base, sizeof(uint32_t) * bh.ent_base.size()));
           MGX_HIP(hipMemcpy(b.ent_base, bh.ent_base.data(), sizeof(uint32_t) * bh.ent_base.size(),
                             hipMemcpyHostToDevice));
-          MGX_HIP(hipMalloc((void **)&b.ent_flags, bh.ent_flags.size()));
-          MGX_HIP(hipMemcpy(b.ent_flags, bh.ent_flags.data(), bh.ent_flags.size(), hipMemcpyHostToDevice));
+          b.ent_flags = nullptr;
           MGX_TRACE("operator_create: %u bricks, %d colours", b.n_bricks, b.n_colours);
         }
       else

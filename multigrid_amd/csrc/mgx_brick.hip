@@ -111,6 +111,11 @@ namespace mgx
   // global addresses: runs of (p-1)^3, (p-1)^2, (p-1) or 1 values instead of the runs of p-1 a
   // lexicographic sweep over the brick points would give.
   // ------------------------------------------------------------------------------------------
+  // Entity table word: bits 0..29 first DoF of the entity, bit 30 FIRST, bit 31 LAST;
+  // 0xFFFFFFFF = constrained / empty entity (the host refuses levels with >= 2^30 - 1 DoFs)
+  __device__ __forceinline__ uint32_t ent_index(uint32_t w) { return w & 0x3FFFFFFFu; }
+  __device__ __forceinline__ uint32_t ent_flags_of(uint32_t w) { return w >> 30; }
+
   // Pass 1 of the write-out: everything that has to be READ (partial sums of earlier launches and
   // the operands of the fused post-operation) is loaded with unconditional, branch-free loads
   // (masked entries read element 0) and folded into the accumulator value.  Pass 2 then only
@@ -183,8 +188,8 @@ namespace mgx
   }
 
   template <int P, typename T, int MODE>
-  __device__ __forceinline__ void store_brick(int tid, T *acc, const uint32_t *ebase, const uint8_t *eflags,
-                                              const T *__restrict__ src, const BrickPost<T> &post)
+  __device__ __forceinline__ void store_brick(int tid, T *acc, const uint32_t *ebase, const T *__restrict__ src,
+                                              const BrickPost<T> &post)
   {
     using C          = BCfg<P>;
     constexpr int G  = C::G;
@@ -193,13 +198,18 @@ namespace mgx
     constexpr int NA = C::NCELLS * P3;
     constexpr bool kFixedLane = (C::THREADS % P3) == 0; // per-thread decode hoisted out of the loops
     constexpr int NBF = G * G * G - (G - 1) * (G - 1) * (G - 1);
+    constexpr int ITA = (NA + C::THREADS - 1) / C::THREADS;  // iterations of part A
+    constexpr int ITB = (NBF + C::THREADS - 1) / C::THREADS; // iterations of part B
+    // plain / residual forms only read partial sums of earlier launches: whole waves whose
+    // entities are all FIRST skip pass 1
+    constexpr bool kLoadsOnlyPartials = (MODE == kPlain || MODE == kNoCompute);
     int slot_rel = 0, pnt_rel = 0, k = 0;
     if (kFixedLane)
       decode_cell_dof<P>(tid % P3, slot_rel, pnt_rel, k);
 
-    // work item -> (entity slot, accumulator index, offset inside the entity).  With a thread
-    // count that is a multiple of p^3 a thread keeps its position inside the cell block and
-    // iteration `it` only advances the cell by a compile-time constant: the cell index is
+    // Part A: the p^3 DoFs on the high side / in the interior of each cell, cell after cell.  With
+    // a thread count that is a multiple of p^3 a thread keeps its position inside the cell block
+    // and iteration `it` only advances the cell by a compile-time constant: the cell index is
     // m = m_thread + CPI * it with CPI = THREADS / p^3 a power of two, so the Morton bits of the
     // two parts are disjoint and (after full unrolling) the second part folds to immediates.
     constexpr int CPI = kFixedLane ? C::THREADS / P3 : 1;
@@ -229,7 +239,8 @@ namespace mgx
           off = (uint32_t)k;
         }
     };
-    constexpr int ITA = (NA + C::THREADS - 1) / C::THREADS; // iterations of part A
+    // Part B: the low faces of the brick (points with a zero coordinate); their DoFs live in the
+    // cell blocks of neighbouring bricks
     auto item_b = [&](int w, int &e, int &pnt, uint32_t &off) {
       int gx, gy, gz;
       if (w < G * G)
@@ -261,7 +272,10 @@ namespace mgx
       off = (uint32_t)((oz * ny + oy) * nx + ox);
     };
 
-    // ---- pass 1: loads + post-operation, result back into the accumulator (same thread) ----
+    // ---- pass 1: loads + post-operation, result back into the accumulator (same thread).  The
+    // table words (and for part B the decoded positions) stay in registers for pass 2. ----
+    constexpr bool kKeepA = ITA <= 32;
+    uint32_t       wa[kKeepA ? ITA : 1];
 #pragma unroll
     for (int it = 0; it < ITA; ++it)
       {
@@ -270,21 +284,37 @@ namespace mgx
         int      e, pnt;
         uint32_t off;
         item_a(it, e, pnt, off);
-        const uint32_t base = ebase[e];
-        acc[pnt] = post_value<P, T, MODE>(src, post, base != kInvalid, base + off, eflags[e], acc[pnt]);
+        const uint32_t w = ebase[e];
+        if (kKeepA)
+          wa[it] = w;
+        const bool     valid = w != kInvalid;
+        const uint32_t fl    = ent_flags_of(w);
+        if (kLoadsOnlyPartials && !__any(valid && !(fl & 1)))
+          continue;
+        acc[pnt] = post_value<P, T, MODE>(src, post, valid, ent_index(w) + off, (uint8_t)fl, acc[pnt]);
       }
-#pragma unroll 2
-    for (int w = tid; w < NBF; w += C::THREADS)
+    uint32_t wb[ITB], ib[ITB];
+    int      pb[ITB];
+#pragma unroll
+    for (int it = 0; it < ITB; ++it)
       {
-        int      e, pnt;
-        uint32_t off;
-        item_b(w, e, pnt, off);
-        const uint32_t base = ebase[e];
-        acc[pnt] = post_value<P, T, MODE>(src, post, base != kInvalid, base + off, eflags[e], acc[pnt]);
+        wb[it] = kInvalid;
+        ib[it] = 0;
+        pb[it] = 0;
+        const int w_item = tid + it * C::THREADS;
+        if (w_item < NBF)
+          {
+            int      e;
+            uint32_t off;
+            item_b(w_item, e, pb[it], off);
+            const uint32_t w = ebase[e];
+            wb[it]           = w;
+            ib[it]           = ent_index(w) + off;
+            acc[pb[it]] = post_value<P, T, MODE>(src, post, w != kInvalid, ib[it], (uint8_t)ent_flags_of(w), acc[pb[it]]);
+          }
       }
-    // ---- pass 2: stores only.  Part A writes the p^3 DoFs on the high side / in the interior
-    // of each cell; with a first-touch cell-by-cell numbering that is one contiguous block per
-    // cell (one 512-B wave instruction at p = 4).  Part B: the low faces of the brick. ----
+    // ---- pass 2: stores only.  With a first-touch cell-by-cell numbering part A writes one
+    // contiguous block per cell (one 512-B wave instruction at p = 4). ----
 #pragma unroll
     for (int it = 0; it < ITA; ++it)
       {
@@ -293,19 +323,14 @@ namespace mgx
         int      e, pnt;
         uint32_t off;
         item_a(it, e, pnt, off);
-        const uint32_t base = ebase[e];
-        if (base != kInvalid)
-          ((eflags[e] & 2) ? post.out : post.partial)[base + off] = acc[pnt];
+        const uint32_t w = kKeepA ? wa[it] : ebase[e];
+        if (w != kInvalid)
+          ((w >> 31) ? post.out : post.partial)[ent_index(w) + off] = acc[pnt];
       }
-    for (int w = tid; w < NBF; w += C::THREADS)
-      {
-        int      e, pnt;
-        uint32_t off;
-        item_b(w, e, pnt, off);
-        const uint32_t base = ebase[e];
-        if (base != kInvalid)
-          ((eflags[e] & 2) ? post.out : post.partial)[base + off] = acc[pnt];
-      }
+#pragma unroll
+    for (int it = 0; it < ITB; ++it)
+      if (wb[it] != kInvalid)
+        ((wb[it] >> 31) ? post.out : post.partial)[ib[it]] = acc[pb[it]];
   }
 
   // wave-local ordering of LDS traffic: the two cells of a wave exchange data only among the
@@ -341,15 +366,11 @@ namespace mgx
     __shared__ T        acc[G * G * G];
     __shared__ T        U[8 * C::CELL_LDS];
     __shared__ uint32_t ebase[C::NE];
-    __shared__ uint8_t  eflags[C::NE];
 
     const int      tid   = threadIdx.x;
     const uint32_t brick = brick_first + blockIdx.x;
     for (int i = tid; i < C::NE; i += C::THREADS)
-      {
-        ebase[i]  = ent_base[(size_t)brick * C::NE + i];
-        eflags[i] = ent_flags[(size_t)brick * C::NE + i];
-      }
+      ebase[i] = ent_base[(size_t)brick * C::NE + i];
     for (int i = tid; i < G * G * G; i += C::THREADS)
       acc[i] = T(0);
 
@@ -382,12 +403,12 @@ namespace mgx
       const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
       const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
       nvalid = (b0 != kInvalid ? 1u : 0u) | (b1 != kInvalid ? 2u : 0u) | (b2 != kInvalid ? 4u : 0u);
-      r[0] = src[b0 != kInvalid ? b0 + loff : 0u];
-      const uint32_t m1 = b1 != kInvalid ? b1 + loff * (uint32_t)(P - 1) : 0u;
+      r[0] = src[b0 != kInvalid ? ent_index(b0) + loff : 0u];
+      const uint32_t m1 = b1 != kInvalid ? ent_index(b1) + loff * (uint32_t)(P - 1) : 0u;
 #pragma unroll
       for (int i = 0; i < P - 1; ++i)
         r[1 + i] = src[m1 + (uint32_t)i];
-      r[P] = src[b2 != kInvalid ? b2 + loff : 0u];
+      r[P] = src[b2 != kInvalid ? ent_index(b2) + loff : 0u];
     };
 
     // Source values of the next round (prefetched).  The gather runs in uniform control flow
@@ -525,7 +546,7 @@ namespace mgx
       }
     __syncthreads();
 
-    store_brick<P, T, MODE>(tid, acc, ebase, eflags, src, post);
+    store_brick<P, T, MODE>(tid, acc, ebase, src, post);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -599,15 +620,11 @@ namespace mgx
     __shared__ T        acc[G * G * G];
     __shared__ T        U[C::ROUND_CELLS * C::CELL_LDS];
     __shared__ uint32_t ebase[C::NE];
-    __shared__ uint8_t  eflags[C::NE];
 
     const int      tid   = threadIdx.x;
     const uint32_t brick = brick_first + blockIdx.x;
     for (int i = tid; i < C::NE; i += C::THREADS)
-      {
-        ebase[i]  = ent_base[(size_t)brick * C::NE + i];
-        eflags[i] = ent_flags[(size_t)brick * C::NE + i];
-      }
+      ebase[i] = ent_base[(size_t)brick * C::NE + i];
     for (int i = tid; i < G * G * G; i += C::THREADS)
       acc[i] = T(0);
 
@@ -645,12 +662,12 @@ namespace mgx
       const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
       const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
       nvalid = (b0 != kInvalid ? 1u : 0u) | (b1 != kInvalid ? 2u : 0u) | (b2 != kInvalid ? 4u : 0u);
-      r[0] = src[b0 != kInvalid ? b0 + loff : 0u];
-      const uint32_t m1 = b1 != kInvalid ? b1 + loff * (uint32_t)(P - 1) : 0u;
+      r[0] = src[b0 != kInvalid ? ent_index(b0) + loff : 0u];
+      const uint32_t m1 = b1 != kInvalid ? ent_index(b1) + loff * (uint32_t)(P - 1) : 0u;
 #pragma unroll
       for (int i = 0; i < P - 1; ++i)
         r[1 + i] = src[m1 + (uint32_t)i];
-      r[P] = src[b2 != kInvalid ? b2 + loff : 0u];
+      r[P] = src[b2 != kInvalid ? ent_index(b2) + loff : 0u];
     };
     T        rA[N], rB[N];
     uint32_t vA = 0, vB = 0;
@@ -765,7 +782,7 @@ namespace mgx
           post.out[tid] = acc[tid]; // keep the rounds alive
         return;
       }
-    store_brick<P, T, MODE>(tid, acc, ebase, eflags, src, post);
+    store_brick<P, T, MODE>(tid, acc, ebase, src, post);
   }
 
   // ------------------------------------------------------------------------------------------
