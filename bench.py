@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--vcycle-number", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
-    ap.add_argument("--cpu-cells", type=int, default=32, help="finest level of the CPU baseline sample")
+    ap.add_argument("--cpu-cells", type=int, default=64, help="finest level of the CPU baseline sample")
     return ap.parse_args()
 
 
@@ -63,10 +63,10 @@ def cpu_baseline(args):
     orc = Oracle(args.degree, ns, nr, degree=args.smoother_degree, n_cycles=1, vfloat=False)
     n = orc.n_dofs(orc.max_level)
     orc.time_vmult(orc.max_level, 1)  # warm-up
-    n_mv = 10
+    n_mv = 20
     t_mv = orc.time_vmult(orc.max_level, n_mv) / n_mv
     orc.time_vcycle(1)
-    n_vc = 3
+    n_vc = 8
     t_vc = orc.time_vcycle(n_vc) / n_vc
     threads = orc.num_threads()
     orc.close()
