@@ -11,7 +11,8 @@
  *                     refine_global(n_refine)            poisson_cube/program.cc:542,570
  *   cell order        forest/Morton order (p4est), children of cell c are 8c..8c+7
  *   DoF numbering     entity-contiguous, lexicographic inside an entity, Dirichlet DoFs last
- *                     (contract of laplace_operator.h:272-340)
+ *                     (contract of laplace_operator.h:272-340); the order
+ *                     of the entities is the provider's choice, see MGX_CUBE_NUMBERING_* below
  *   problem           u = prod sin(3 pi x_d), f = 27 pi^2 u, coefficient 1, Dirichlet on all
  *                     faces                              poisson_cube/program.cc:98-144,266
  */
@@ -26,7 +27,20 @@ extern "C" {
 
 typedef struct mgx_cube_s *mgx_cube_t;
 
-int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *cube);
+/* Order in which the mesh entities receive their DoF ranges (the compressed index table holds for
+ * any order; deal.II's own choice is MatrixFree's renumbering):
+ *   BRICK  every entity is numbered by the first cell (Morton order) that contains it, and the
+ *          entities numbered by one 4x4x4 (p <= 4) or 2x2x2 (p >= 5) brick of consecutive cells are
+ *          grouped by the brick-level entity they lie on: brick interior, then its faces, edges,
+ *          corners.  DoFs that the device cell loop completes in the same colour launch then form
+ *          long contiguous runs -- no 128-B memory line is shared between launches.
+ *   CELL   plain first-touch order cell by cell (one contiguous block per cell),
+ *          kept so that tests can show that results do not depend on the choice. */
+#define MGX_CUBE_NUMBERING_BRICK 0
+#define MGX_CUBE_NUMBERING_CELL 1
+
+int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *cube); /* BRICK numbering */
+int mgx_cube_create_numbered(int degree, int n_subdiv, int n_refine, int numbering, mgx_cube_t *cube);
 
 /* General form: a box of roots[0] x roots[1] x roots[2] cubic coarse cells of size h0 with lower
  * corner (origin,origin,origin), refined n_refine times, distributed over a procs[0] x procs[1] x
@@ -44,6 +58,7 @@ typedef struct
   double origin, h0;
   int    procs[3];
   int    rank;
+  int    numbering; /* MGX_CUBE_NUMBERING_* */
 } mgx_cube_box_desc;
 int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
 int mgx_cube_rank(mgx_cube_t cube);

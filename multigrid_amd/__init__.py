@@ -227,17 +227,22 @@ class DeviceVector:
 class Cube:
     """Host-side discretisation of poisson_cube (include/mgx_cube.h): what deal.II supplies."""
 
-    def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0):
+    NUMBERING = {"brick": 0, "cell": 1}
+
+    def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0, numbering="brick"):
         """box=None: the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction.
         box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1),
         program.cc:509-529), optionally distributed over the process grid `procs`; this rank owns
-        box[d]/procs[d] coarse cells per direction."""
+        box[d]/procs[d] coarse cells per direction.
+        numbering: "brick" (default, grouped for the device cell loop) or "cell" (the
+        plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h."""
         self.lib = _lib.load()
         h = C.c_void_p()
+        num = self.NUMBERING[numbering]
         if box is None:
-            check(self.lib.mgx_cube_create(degree, n_subdiv, n_refine, C.byref(h)))
+            check(self.lib.mgx_cube_create_numbered(degree, n_subdiv, n_refine, num, C.byref(h)))
         else:
-            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), -1.0, 1.9, (C.c_int * 3)(*procs), rank)
+            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), -1.0, 1.9, (C.c_int * 3)(*procs), rank, num)
             check(self.lib.mgx_cube_create_box(C.byref(d), C.byref(h)))
         self.h = h
         self.rank, self.size = self.lib.mgx_cube_rank(h), self.lib.mgx_cube_size(h)

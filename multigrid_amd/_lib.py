@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+# MGX_LIB_PATH: A/B timing of two builds of the same library (tools/); never a different backend
+LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(_HERE, "libmgx.so")
 
 F32, F64 = 0, 1
 INVALID_INDEX = 0xFFFFFFFF
@@ -37,7 +38,7 @@ class CommDesc(C.Structure):
 
 class CubeBoxDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("n_refine", C.c_int), ("roots", C.c_int * 3), ("origin", C.c_double),
-                ("h0", C.c_double), ("procs", C.c_int * 3), ("rank", C.c_int)]
+                ("h0", C.c_double), ("procs", C.c_int * 3), ("rank", C.c_int), ("numbering", C.c_int)]
 
 
 class OperatorDesc(C.Structure):
@@ -127,6 +128,7 @@ SIGNATURES = {
     "mgx_solver_enable_timings": (C.c_int, [vp, C.c_int]),
     # mgx_cube.h
     "mgx_cube_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "mgx_cube_create_numbered": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "mgx_cube_create_box": (C.c_int, [C.POINTER(CubeBoxDesc), C.POINTER(vp)]),
     "mgx_cube_rank": (C.c_int, [vp]),
     "mgx_cube_size": (C.c_int, [vp]),

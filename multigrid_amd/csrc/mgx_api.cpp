@@ -1699,6 +1699,19 @@ int mgx_solver_vmult(mgx_solver_t S, double *dst, const double *src)
   const int    lmax = S->n_levels - 1;
   const size_t n    = S->matrix[lmax]->d.n_dofs;
   hipStream_t  s    = S->ctx->stream;
+  if (S->vnumber == MGX_F64 && dst != src && lmax > S->graph_level)
+    {
+      // same number type: the two precision-converting copies (:503, :507) are plain copies, so
+      // the cycle runs on the caller's vectors instead (src is only read on the finest level,
+      // every entry of dst is written by the pre-smoother)
+      void *defect = S->defect[lmax], *update = S->solution_update[lmax];
+      S->defect[lmax]          = const_cast<double *>(src);
+      S->solution_update[lmax] = dst;
+      const int status         = v_cycle(S, lmax, 1);
+      S->defect[lmax]          = defect;
+      S->solution_update[lmax] = update;
+      return status;
+    }
   launch_copy_cast(s, S->defect[lmax], S->vnumber, src, MGX_F64, n); // :503
   MGX_TRY(v_cycle(S, lmax, 1));                                       // :505
   launch_copy_cast(s, dst, MGX_F64, S->solution_update[lmax], S->vnumber, n); // :507

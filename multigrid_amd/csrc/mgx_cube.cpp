@@ -187,6 +187,7 @@ struct mgx_cube_s
   int                pcoord[3] = {0, 0, 0}, rank = 0, size = 1;
   int                lroots[3] = {1, 1, 1}, roff[3] = {0, 0, 0}; // this rank's coarse cells and offset
   double             origin = -0.9, h0 = 1.9;
+  bool               brick_numbering = false;
   Basis              basis;
   std::vector<Level> levels;
 };
@@ -226,6 +227,22 @@ namespace
       return (uint32_t)((cx == 1 ? p - 1 : 1) * (cy == 1 ? p - 1 : 1) * (cz == 1 ? p - 1 : 1));
     };
     uint32_t next = 0;
+    // Order of the numbering.  Cells are visited in Morton order and every mesh entity is numbered
+    // by the first cell that contains it.  With `brick_numbering` the entities a brick of
+    // NBd^3 consecutive cells numbers are additionally grouped by the brick-level entity they lie
+    // on (brick interior, then its 2D faces, edges, corners): all DoFs that are complete after the
+    // same set of colour launches of the device cell loop (mgx_brick.hip) then form long
+    // contiguous runs, so no 128-B memory line mixes values that are finalised by different
+    // launches.  The entity-contiguity contract of the compressed index table is untouched.
+    const uint32_t nbd_num = p <= 4 ? 4 : 2, cb_num = nbd_num * nbd_num * nbd_num;
+    const bool     grouped = C.brick_numbering && level >= (p <= 4 ? 2 : 1);
+    struct Pending
+    {
+      uint32_t  key; // (group rank << 16) | visiting order
+      uint32_t *slot;
+      uint32_t  size;
+    };
+    std::vector<Pending> pending;
     for (int pass = 0; pass < 2; ++pass) // unconstrained entities first, Dirichlet boundary last
       {
         for (uint32_t c = 0; c < nc; ++c)
@@ -244,12 +261,34 @@ namespace
                     if ((int)on_boundary != pass)
                       continue;
                     uint32_t &f = first[(ez * Ey + ey) * Ex + ex];
-                    if (f == MGX_INVALID_INDEX)
+                    if (f != MGX_INVALID_INDEX)
+                      continue;
+                    if (!grouped)
                       {
                         f = next;
                         next += esize(cx, cy, cz);
+                        continue;
                       }
+                    f = MGX_INVALID_INDEX - 1; // claimed, numbered when the brick is complete
+                    // which brick surfaces the entity lies on: 0 interior, 1 low, 2 high per direction
+                    const uint32_t E2 = 2 * nbd_num;
+                    const uint32_t sx = ex % E2 == 0 ? ((X % nbd_num == 0 && cx == 0) ? 1 : 2) : 0;
+                    const uint32_t sy = ey % E2 == 0 ? ((Y % nbd_num == 0 && cy == 0) ? 1 : 2) : 0;
+                    const uint32_t sz = ez % E2 == 0 ? ((Z % nbd_num == 0 && cz == 0) ? 1 : 2) : 0;
+                    const uint32_t nsurf = (sx != 0) + (sy != 0) + (sz != 0);
+                    const uint32_t group = nsurf * 27 + sz * 9 + sy * 3 + sx; // interior, faces, edges, corners
+                    pending.push_back({(group << 16) | (uint32_t)pending.size(), &f, esize(cx, cy, cz)});
                   }
+            if (grouped && (c + 1) % cb_num == 0)
+              {
+                std::sort(pending.begin(), pending.end(), [](const Pending &a, const Pending &b) { return a.key < b.key; });
+                for (const Pending &q : pending)
+                  {
+                    *q.slot = next;
+                    next += q.size;
+                  }
+                pending.clear();
+              }
           }
         if (pass == 0)
           L.n_free = next;
@@ -640,6 +679,8 @@ static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
     return MGX_ERR_UNSUPPORTED; // 32-bit (global) DoF indices as in the reference's compressed table
   if (bd.rank < 0 || bd.rank >= size || !(bd.h0 > 0))
     return MGX_ERR_INVALID_ARGUMENT;
+  if (bd.numbering != MGX_CUBE_NUMBERING_BRICK && bd.numbering != MGX_CUBE_NUMBERING_CELL)
+    return MGX_ERR_INVALID_ARGUMENT;
   omp_set_num_threads(effective_threads());
   auto C    = std::make_unique<mgx_cube_s>();
   C->p      = degree;
@@ -657,6 +698,7 @@ static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
       C->lroots[d] = bd.roots[d] / bd.procs[d];
       C->roff[d]   = C->pcoord[d] * C->lroots[d];
     }
+  C->brick_numbering = bd.numbering == MGX_CUBE_NUMBERING_BRICK;
   make_basis(C->basis, degree);
   C->levels.resize(n_refine + 1);
   for (int l = 0; l <= n_refine; ++l)
@@ -672,6 +714,11 @@ static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
 
 int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *out)
 {
+  return mgx_cube_create_numbered(degree, n_subdiv, n_refine, MGX_CUBE_NUMBERING_BRICK, out);
+}
+
+int mgx_cube_create_numbered(int degree, int n_subdiv, int n_refine, int numbering, mgx_cube_t *out)
+{
   // "square" mesh: subdivided_hyper_cube(n_subdiv, -0.9, 1.0) (poisson_cube/program.cc:542)
   if (n_subdiv < 1)
     return MGX_ERR_INVALID_ARGUMENT;
@@ -681,6 +728,7 @@ int mgx_cube_create(int degree, int n_subdiv, int n_refine, mgx_cube_t *out)
   bd.origin   = -0.9;
   bd.h0       = 1.9 / n_subdiv;
   bd.rank     = 0;
+  bd.numbering = numbering;
   for (int d = 0; d < 3; ++d)
     {
       bd.roots[d] = n_subdiv;

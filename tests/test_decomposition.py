@@ -47,7 +47,7 @@ def test_partition_tables(procs, p):
     size = procs[0] * procs[1] * procs[2]
     cubes = [mg.Cube(p, n_refine=nr, box=procs, procs=procs, rank=r) for r in range(size)]
     orc = Oracle(p, n_refine=nr, box=procs)
-    whole = mg.Cube(p, n_refine=nr, box=procs)  # the same mesh on one rank
+    whole = mg.Cube(p, n_refine=nr, box=procs, numbering="cell")  # the same mesh on one rank
     for l in range(nr + 1):
         n_global = orc.n_dofs(l)
         assert whole.n_dofs(l) == n_global
@@ -96,7 +96,7 @@ def test_partition_tables(procs, p):
 
 def test_box_mesh_matches_oracle_single_rank():
     """the doubling-mesh family on one rank (2x1x1 coarse cells) against the oracle"""
-    c = mg.Cube(3, n_refine=2, box=(2, 1, 1))
+    c = mg.Cube(3, n_refine=2, box=(2, 1, 1), numbering="cell")
     o = Oracle(3, n_refine=2, box=(2, 1, 1))
     for l in range(3):
         assert np.array_equal(c.idx27(l), o.idx27(l))

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 mg = pytest.importorskip("multigrid_amd")
 from oracle import Oracle  # noqa: E402
+from oracle_view import oracle_for  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +35,7 @@ CASES = [(1, 2, 1), (1, 1, 3), (2, 1, 2), (2, 1, 3), (3, 1, 2), (3, 3, 2), (4, 1
 @pytest.mark.parametrize("p,ns,nr", CASES)
 def test_vmult_and_residual(ctx, p, ns, nr):
     cube = mg.Cube(p, ns, nr)
-    orc = Oracle(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr)
     for l in range(cube.n_levels):
         op = mg.LaplaceOperator.from_cube(ctx, cube, l)
         x = cube.seeded_vector(l, 1)
@@ -113,7 +114,7 @@ def test_error_paths(ctx):
 @pytest.mark.parametrize("p,ns,nr", [(2, 1, 2), (4, 1, 2), (4, 1, 3), (3, 3, 2), (4, 3, 1), (7, 1, 1)])
 def test_chebyshev(ctx, p, ns, nr):
     cube = mg.Cube(p, ns, nr)
-    orc = Oracle(p, ns, nr, degree=3)
+    orc = oracle_for(cube, p, ns, nr, degree=3)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
     for l in range(cube.n_levels):
         sm = solver.smoother(l)
@@ -136,7 +137,7 @@ def test_chebyshev(ctx, p, ns, nr):
 @pytest.mark.parametrize("p,ns,nr", [(1, 2, 1), (2, 1, 2), (4, 1, 2), (4, 3, 1), (8, 1, 1)])
 def test_transfers(ctx, p, ns, nr):
     cube = mg.Cube(p, ns, nr)
-    orc = Oracle(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr)
     ops = [mg.LaplaceOperator.from_cube(ctx, cube, l) for l in range(cube.n_levels)]
     for l in range(1, cube.n_levels):
         tr = mg.Transfer(ops[l - 1], ops[l], cube.children(l), cube.prolong_1d())
@@ -167,13 +168,14 @@ def test_transfers(ctx, p, ns, nr):
                                                   (3, 1, 3, 2, 2), (1, 1, 4, 3, 1)])
 def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
     cube = mg.Cube(p, ns, nr)
-    orc = Oracle(p, ns, nr, degree=degree, n_cycles=ncyc)
+    orc = oracle_for(cube, p, ns, nr, degree=degree, n_cycles=ncyc)
     solver = mg.MultigridSolver(ctx, cube, degree, degree, ncyc, mg.F64)
     lmax = cube.max_level
     x = cube.seeded_vector(lmax, 5)
-    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
-    solver.vmult(dst, src)  # MultigridSolver::vmult = one V-cycle
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=np.full(x.size, np.nan))
+    solver.vmult(dst, src)  # MultigridSolver::vmult = one V-cycle; every entry of dst is written
     assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    assert np.array_equal(src.download(), x)  # the source is left alone
     rate, trace = solver.solve(True)
     orate, otrace = orc.solve(True)
     if nr > 0:
@@ -198,7 +200,7 @@ def test_default_brick_threshold(ctx, monkeypatch):
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     p, nr = 2, 6
     cube = mg.Cube(p, 1, nr)
-    orc = Oracle(p, 1, nr, degree=3, n_cycles=1)
+    orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
     x = cube.seeded_vector(nr, 5)
     src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
@@ -228,7 +230,7 @@ def test_readme_known_answers_on_gpu(ctx):
 
 def test_mixed_precision_vcycle(ctx):
     cube = mg.Cube(4, 1, 3)
-    orc = Oracle(4, 1, 3, degree=3, n_cycles=1, vfloat=True)
+    orc = oracle_for(cube, 4, 1, 3, degree=3, n_cycles=1, vfloat=True)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32)
     lmax = cube.max_level
     x = cube.seeded_vector(lmax, 5)

@@ -61,7 +61,7 @@ def test_product_does_not_touch_the_oracle():
 @pytest.mark.parametrize("p,ns,nr", [(1, 2, 2), (2, 1, 2), (4, 1, 3), (4, 3, 1), (5, 3, 1), (8, 1, 1), (9, 1, 1)])
 def test_cube_provider_matches_oracle(lib, p, ns, nr):
     import multigrid_amd as mg
-    c = mg.Cube(p, ns, nr)
+    c = mg.Cube(p, ns, nr, numbering="cell")  # the oracle's entity order: tables must be identical
     o = Oracle(p, ns, nr)
     assert c.n_levels == o.n_levels
     for l in range(c.n_levels):
@@ -95,9 +95,55 @@ def test_cube_provider_matches_oracle(lib, p, ns, nr):
     o.close()
 
 
+@pytest.mark.parametrize("p,ns,nr", [(1, 1, 3), (2, 3, 2), (4, 1, 3), (4, 3, 2), (5, 1, 2), (8, 1, 1)])
+def test_brick_numbering_contract(lib, p, ns, nr):
+    """The default (brick-grouped) numbering: same mesh, same data as the cell numbering up to a
+    permutation; entity-contiguous with Dirichlet DoFs last (laplace_operator.h:272-340); and the
+    DoFs numbered by one brick are one contiguous range with the brick interior first."""
+    import multigrid_amd as mg
+    c, r = mg.Cube(p, ns, nr), mg.Cube(p, ns, nr, numbering="cell")
+    nb = 4 if p <= 4 else 2
+    for l in range(c.n_levels):
+        n = c.n_dofs(l)
+        gc, gr = c.dof_grid(l).astype(np.int64), r.dof_grid(l).astype(np.int64)
+        assert np.array_equal(np.sort(gc), np.arange(n))
+        assert c.n_constrained(l) == r.n_constrained(l)
+        assert np.array_equal(c.constrained(l), np.arange(n - c.n_constrained(l), n))
+        assert np.array_equal(np.sort(gc[c.constrained(l)]), np.sort(gr[r.constrained(l)]))
+        for name in ("rhs",):
+            a, b = np.empty(n), np.empty(n)
+            a[gc], b[gr] = getattr(c, name)(l), getattr(r, name)(l)
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)  # cell contributions add in another order
+        # entity contiguity: the DoFs of entity e of cell c are base .. base+size-1 and lie on the
+        # grid points the cell-numbered provider assigns to the same entity
+        idx, ridx = c.idx27_plain(l).reshape(-1, 27), r.idx27_plain(l).reshape(-1, 27)
+        for e in (0, 1, 4, 13, 14, 22, 26):
+            cx, cy, cz = e % 3, (e // 3) % 3, e // 9
+            size = (p - 1 if cx == 1 else 1) * (p - 1 if cy == 1 else 1) * (p - 1 if cz == 1 else 1)
+            for k in range(size):
+                assert np.array_equal(gc[idx[:, e] + k], gr[ridx[:, e] + k])
+        if c.n_cells(l) < nb ** 3 or l < (2 if p <= 4 else 1):
+            assert np.array_equal(gc, gr)  # no bricks on this level: plain first-touch order
+            continue
+        # unconstrained DoFs first numbered by brick b form one range; brick interiors lead
+        n_free = n - c.n_constrained(l)
+        cells = idx.shape[0]
+        first = np.full(n, -1, np.int64)
+        sizes = np.array([(p - 1 if e % 3 == 1 else 1) * (p - 1 if (e // 3) % 3 == 1 else 1) *
+                          (p - 1 if e // 9 == 1 else 1) for e in range(27)])
+        for cell in range(cells - 1, -1, -1):  # reverse order: the first cell wins
+            for e in range(27):
+                if sizes[e]:
+                    first[idx[cell, e]:idx[cell, e] + sizes[e]] = cell // nb ** 3
+        owner = first[:n_free]
+        assert (np.diff(owner) >= 0).all()  # ranges of consecutive bricks, in brick order
+    c.close()
+    r.close()
+
+
 def test_seeded_vector_is_numbering_independent(lib):
     import multigrid_amd as mg
-    c = mg.Cube(3, 1, 2)
+    c = mg.Cube(3, 1, 2, numbering="cell")
     v = c.seeded_vector(2, 42)
     g = c.dof_grid(2)
     assert v.min() >= -1 and v.max() < 1 and abs(v.mean()) < 0.05
