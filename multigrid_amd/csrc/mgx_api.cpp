@@ -1126,13 +1126,13 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 //   out <- cur + f1 (cur - out) + f2 D^-1 (b - A cur);  mode 2 general, 3 without the f1 term,
 //   4 with out == 0 on entry.  sm->tmp carries the partial sums of brick-surface DoFs.
 static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, const void *old, void *out,
-                                const void *b, double f1, double f2)
+                                const void *b, double f1, double f2, double f0 = 0.)
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
   {
     ProfileBracket pb(op, mode);
-    launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old);
+    launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old, f0);
   }
   if (op->plan)
     {
@@ -1140,10 +1140,10 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
       // update there
       MGX_TRY(exchange_add(op, sm->tmp));
       launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
-                              op->plan->n_shared, sm->tmp, old);
+                              op->plan->n_shared, sm->tmp, old, f0);
     }
   launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
-                          op->d.n_constrained, nullptr, old);
+                          op->d.n_constrained, nullptr, old, f0);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }
@@ -1176,6 +1176,26 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
   const bool three_term = I.degree >= 2 && std::fabs(I.delta) >= 1e-40;
   const int  n_loop     = three_term ? I.degree - 1 : 0; // iterations of the three-term recurrence
   void      *X = x, *Y = sm->x_old;
+  if (!is_step && n_loop >= 1 && op->d.separable && !std::getenv("MGX_NO_FUSED_INIT"))
+    {
+      // Zero initial guess: x_1 = (1/theta) D^-1 b is not stored.  The first loop iteration
+      // evaluates it while gathering (mode 5), the second one again as its x_old (mode 6); from the
+      // third on both operands are stored iterates.  Targets alternate so that the last is X.
+      const double f0   = 1. / I.theta;
+      double       rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+      void        *cur = nullptr, *old = nullptr;
+      for (int k = 0; k < n_loop; ++k)
+        {
+          const double rhokp = 1. / (2. * sigma - rhok);
+          const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
+          rhok      = rhokp;
+          void *out = ((n_loop - 1 - k) % 2 == 0) ? X : Y;
+          MGX_TRY(cheb_fused_iteration(sm, k == 0 ? 5 : (k == 1 ? 6 : 2), cur, old, out, b, f1, f2, f0));
+          old = cur;
+          cur = out;
+        }
+      return MGX_OK;
+    }
   if (!is_step)
     {
       // x_1 = (1/theta) D^-1 b goes where an alternation over {X,Y} ends in X

@@ -84,6 +84,11 @@ namespace mgx
     kCheb     = 2, // out = x + f1 (x - out) + f2 b (a - A x)       (PreconditionChebyshev update)
     kChebFirst = 3, // out = x + f2 b (a - A x)                     (first step: no x_old term)
     kChebZeroOld = 4, // out = x + f1 x + f2 b (a - A x)             (x_old known to be zero)
+    // start of PreconditionChebyshev::vmult (zero initial guess): the first iterate x_1 = f0 b a is
+    // never stored -- the first loop iteration computes it while gathering (kChebInit, x_old = 0),
+    // the second one recomputes it as its x_old (kChebOldInit); separable kernel only
+    kChebInit    = 5, // x := f0 b a ; out = x + f1 x + f2 b (a - A x)
+    kChebOldInit = 6, // out = x + f1 (x - f0 b a) + f2 b (a - A x)
     // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
     kNoStore   = 8, // rounds only, no write-out
     kNoCompute = 9, // write-out only, no rounds
@@ -100,7 +105,7 @@ namespace mgx
     const T *old;     // kCheb: previous iterate x_old (may alias out: read before written)
     T       *out;     // result vector
     T       *partial; // carrier of partial sums between colour launches (may alias out)
-    T        f1, f2;
+    T        f1, f2, f0;
   };
 
 
@@ -140,15 +145,21 @@ namespace mgx
       }
     else
       {
-        const T av = post.a[il], bv = post.b[il], xi = src[il];
-        T       ov = T(0);
+        const T av = post.a[il], bv = post.b[il];
+        T       xi = T(0), ov = T(0);
+        if (MODE == kChebInit)
+          xi = post.f0 * bv * av; // the same expression as in the gather: bitwise the same x_1
+        else
+          xi = src[il];
         if (MODE == kCheb)
           ov = post.old[il];
+        else if (MODE == kChebOldInit)
+          ov = post.f0 * bv * av;
         val  = need_partial ? val + pv : val;
         T xn = xi + post.f2 * bv * (av - val);
-        if (MODE == kCheb)
+        if (MODE == kCheb || MODE == kChebOldInit)
           xn += post.f1 * (xi - ov);
-        else if (MODE == kChebZeroOld)
+        else if (MODE == kChebZeroOld || MODE == kChebInit)
           xn += post.f1 * xi;
         return last ? xn : val;
       }
@@ -657,32 +668,50 @@ namespace mgx
 
     // source values are prefetched two rounds ahead (two register sets, statically indexed by
     // unrolling the round loop by two): an HBM miss takes about as long as one round
-    auto gather = [&](int round, T(&r)[N], uint32_t &nvalid) {
+    constexpr int ND = MODE == kChebInit ? N : 1; // kChebInit gathers two operands per value
+    auto gather = [&](int round, T(&r)[N], T(&d)[ND], uint32_t &nvalid) {
       const int       bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
       const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
       const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
       nvalid = (b0 != kInvalid ? 1u : 0u) | (b1 != kInvalid ? 2u : 0u) | (b2 != kInvalid ? 4u : 0u);
-      r[0] = src[b0 != kInvalid ? ent_index(b0) + loff : 0u];
-      const uint32_t m1 = b1 != kInvalid ? ent_index(b1) + loff * (uint32_t)(P - 1) : 0u;
+      const T        *v0 = MODE == kChebInit ? post.a : src;
+      const uint32_t  m0 = b0 != kInvalid ? ent_index(b0) + loff : 0u;
+      const uint32_t  m1 = b1 != kInvalid ? ent_index(b1) + loff * (uint32_t)(P - 1) : 0u;
+      const uint32_t  m2 = b2 != kInvalid ? ent_index(b2) + loff : 0u;
+      r[0] = v0[m0];
 #pragma unroll
       for (int i = 0; i < P - 1; ++i)
-        r[1 + i] = src[m1 + (uint32_t)i];
-      r[P] = src[b2 != kInvalid ? ent_index(b2) + loff : 0u];
+        r[1 + i] = v0[m1 + (uint32_t)i];
+      r[P] = v0[m2];
+      if (MODE == kChebInit)
+        {
+          d[0] = post.b[m0];
+#pragma unroll
+          for (int i = 0; i < P - 1; ++i)
+            d[(1 + i) % ND] = post.b[m1 + (uint32_t)i];
+          d[P % ND] = post.b[m2];
+        }
     };
-    T        rA[N], rB[N];
+    T        rA[N], rB[N], dA[ND], dB[ND];
     uint32_t vA = 0, vB = 0;
-    gather(0, rA, vA);
-    gather(1, rB, vB);
+    gather(0, rA, dA, vA);
+    gather(1, rB, dB, vB);
 
-    auto one_round = [&](int round, T(&rn)[N], uint32_t &nvalid) {
+    auto one_round = [&](int round, T(&rn)[N], T(&dn)[ND], uint32_t &nvalid) {
         T r[N], t1[N], k1[N], xe[H1], xo[H1];
+        if (MODE == kChebInit)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rn[i] = post.f0 * dn[i % ND] * rn[i]; // x_1 = f0 D^-1 b, as in post_value
+          }
         r[0] = (nvalid & 1u) ? rn[0] : T(0);
 #pragma unroll
         for (int i = 1; i < P; ++i)
           r[i] = (nvalid & 2u) ? rn[i] : T(0);
         r[P] = (nvalid & 4u) ? rn[P] : T(0);
         if (round < 6)
-          gather(round + 2, rn, nvalid); // this register set is free again: refill it
+          gather(round + 2, rn, dn, nvalid); // this register set is free again: refill it
         // x: t1 = M u, k1 = K u
         eo_split<N, T>(r, xe, xo);
         eo_apply<N, T>(M, xe, xo, t1);
@@ -770,8 +799,8 @@ namespace mgx
 #pragma unroll 1
         for (int round = 0; round < 8; round += 2)
           {
-            one_round(round, rA, vA);
-            one_round(round + 1, rB, vB);
+            one_round(round, rA, dA, vA);
+            one_round(round + 1, rB, dB, vB);
           }
       }
     __syncthreads();
@@ -800,7 +829,7 @@ namespace mgx
           hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
                              bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
                              (T)op.coef[2], post);
-        else if constexpr (P <= 4) // the quadrature-point form is built for 4x4x4 bricks only
+        else if constexpr (P <= 4 && MODE != kChebInit && MODE != kChebOldInit) // quadrature-point form: 4x4x4 bricks only
           hipLaunchKernelGGL((brick_loop_kernel<P, T, (MODE >= kNoStore ? 0 : MODE)>), dim3(count),
                              dim3(C::THREADS), 0, s, src, first, bd.ent_base, bd.ent_flags,
                              (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
@@ -809,9 +838,10 @@ namespace mgx
 
   template <typename T>
   static void brick_dispatch(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                             const void *b, void *out, void *partial, double f1, double f2, const void *old)
+                             const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0)
   {
     BrickPost<T> post;
+    post.f0      = (T)f0;
     post.a       = (const T *)a;
     post.b       = (const T *)b;
     post.old     = (const T *)old;
@@ -827,6 +857,8 @@ namespace mgx
         case kResidual: brick_launch<PP, T, kResidual>(s, op, (const T *)src, post); break; \
         case kCheb: brick_launch<PP, T, kCheb>(s, op, (const T *)src, post); break; \
         case kChebFirst: brick_launch<PP, T, kChebFirst>(s, op, (const T *)src, post); break; \
+        case kChebInit: brick_launch<PP, T, kChebInit>(s, op, (const T *)src, post); break; \
+        case kChebOldInit: brick_launch<PP, T, kChebOldInit>(s, op, (const T *)src, post); break; \
         case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post); break; \
         case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post); break; \
         case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post); break; \
@@ -852,13 +884,15 @@ namespace mgx
   }
 
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                         const void *b, void *out, void *partial, double f1, double f2, const void *old)
+                         const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0)
   {
     if (!old)
       old = out;
+    if (!src)
+      src = (const void *)a; // kChebInit: never dereferenced, but keep the pointer valid
     if (op.number == 1)
-      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old);
+      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0);
     else
-      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old);
+      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0);
   }
 } // namespace mgx

@@ -89,7 +89,8 @@ namespace mgx
   // `partial` carries partial sums of brick-surface DoFs between the colour launches
   //   old: previous iterate of mode 2 (nullptr: it is `out`, which is then read before written)
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                         const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr);
+                         const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr,
+                         double f0 = 0.);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)
@@ -128,7 +129,7 @@ namespace mgx
   // ax == nullptr: (A x)_c = x_c (constrained rows); otherwise the product is read from ax
   void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
                                const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count,
-                               const void *ax = nullptr, const void *old = nullptr);
+                               const void *ax = nullptr, const void *old = nullptr, double f0 = 0.);
   // interface exchange helpers
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
   void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count);

@@ -123,21 +123,24 @@ namespace mgx
   }
 
   // Chebyshev update on the constrained rows, where (A x)_c = x_c (laplace_operator.h:736-737);
-  // mode as in mgx_brick.hip: 2 general, 3 first step, 4 x_old == 0
+  // mode as in mgx_brick.hip: 2 general, 3 first step, 4 x_old == 0, 5 x = f0 D^-1 b computed
+  // here and x_old == 0, 6 x_old = f0 D^-1 b computed here
   template <typename T>
   __global__ void __launch_bounds__(256)
     k_cheb_constrained(int mode, const T *__restrict__ x, T *__restrict__ out, const T *__restrict__ b,
                        const T *__restrict__ dinv, T f1, T f2, const uint32_t *__restrict__ list, uint32_t count,
-                       const T *__restrict__ ax, const T *old)
+                       const T *__restrict__ ax, const T *old, T f0)
   {
     GRID_STRIDE(i, count)
     {
       const uint32_t c  = list[i];
-      const T        xi = x[c];
+      const T        xi = mode == 5 ? f0 * dinv[c] * b[c] : x[c];
       T              xn = xi + f2 * dinv[c] * (b[c] - (ax ? ax[c] : xi));
       if (mode == 2)
         xn += f1 * (xi - old[c]);
-      else if (mode == 4)
+      else if (mode == 6)
+        xn += f1 * (xi - f0 * dinv[c] * b[c]);
+      else if (mode == 4 || mode == 5)
         xn += f1 * xi;
       out[c] = xn;
     }
@@ -415,15 +418,17 @@ namespace mgx
 
   void launch_cheb_constrained(hipStream_t s, int number, int mode, const void *x, void *out, const void *b,
                                const void *dinv, double f1, double f2, const uint32_t *list, uint32_t count,
-                               const void *ax, const void *old)
+                               const void *ax, const void *old, double f0)
   {
     if (count == 0)
       return;
     if (!old)
       old = out;
+    if (!x)
+      x = b; // mode 5 never reads it
     BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_constrained<T>), stream_grid(count), dim3(256), 0, s, mode,
                                          (const T *)x, (T *)out, (const T *)b, (const T *)dinv, (T)f1, (T)f2, list,
-                                         count, (const T *)ax, (const T *)old));
+                                         count, (const T *)ax, (const T *)old, (T)f0));
   }
 
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count)
