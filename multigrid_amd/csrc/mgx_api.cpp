@@ -1345,6 +1345,61 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
     }
     MGX_HIP(hipMalloc((void **)&tr->d.own27, sizeof(uint32_t) * own.size()));
     MGX_HIP(hipMemcpy(tr->d.own27, own.data(), sizeof(uint32_t) * own.size(), hipMemcpyHostToDevice));
+    // patch table of the pipelined kernels (mgx_transfer.hip): the 5^3 mesh entities of the
+    // children patch of every parent.  Patch entity layer 0..4 along a direction = (child 0:
+    // codes 0,1,2 ; child 1: codes 0,1,2) with child 0's code 2 and child 1's code 0 coinciding.
+    if (fine->d.n_dofs < (1u << 29) && !std::getenv("MGX_TRANSFER_V1"))
+      {
+        std::vector<uint32_t> patch(125 * (size_t)npar);
+        bool                  consistent = true;
+#pragma omp parallel for schedule(static)
+        for (uint32_t pc = 0; pc < npar; ++pc)
+          for (int e = 0; e < 125; ++e)
+            {
+              const int el[3] = {e % 5, (e / 5) % 5, e / 25};
+              int       nopt[3], bit[3][2], code[3][2], cls[3], size = 1;
+              for (int d = 0; d < 3; ++d)
+                {
+                  nopt[d]    = el[d] == 2 ? 2 : 1;
+                  bit[d][0]  = el[d] > 2;
+                  code[d][0] = el[d] - 2 * bit[d][0];
+                  bit[d][1]  = 1; // layer 2 seen from child 1: its code 0
+                  code[d][1] = 0;
+                  cls[d]     = el[d] == 0 ? 0 : (el[d] == 4 ? 2 : 1);
+                  size *= (el[d] % 2 == 1) ? p - 1 : 1;
+                }
+              uint32_t base = 0;
+              bool     owned = false, first = true;
+              for (int oz = 0; oz < nopt[2]; ++oz)
+                for (int oy = 0; oy < nopt[1]; ++oy)
+                  for (int ox = 0; ox < nopt[0]; ++ox)
+                    {
+                      const int      ch = bit[0][ox] | (bit[1][oy] << 1) | (bit[2][oz] << 2);
+                      const int      ce = (code[2][oz] * 3 + code[1][oy]) * 3 + code[0][ox];
+                      const uint32_t fc = desc->children[8 * (size_t)pc + ch];
+                      const uint32_t b  = idxf[27 * (size_t)fc + ce];
+                      if (first)
+                        base = b;
+                      else if (b != base)
+                        consistent = false; // children do not share the entities of the parent's mid planes
+                      first = false;
+                      owned = owned || ((own[fc] >> ce) & 1u);
+                    }
+              const uint32_t sh = shift[27 * (size_t)pc + (cls[2] * 3 + cls[1]) * 3 + cls[0]];
+              patch[125 * (size_t)pc + e] =
+                size == 0 ? 0u : (base | (sh << 29) | ((owned ? 1u : 0u) << 31));
+            }
+        if (consistent)
+          {
+            MGX_HIP(hipMalloc((void **)&tr->d.patch, sizeof(uint32_t) * patch.size()));
+            MGX_HIP(hipMemcpy(tr->d.patch, patch.data(), sizeof(uint32_t) * patch.size(), hipMemcpyHostToDevice));
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, coarse->ctx->device);
+            tr->d.pipe_grid = (uint32_t)(cus * transfer_pipe_blocks_per_cu(p, coarse->d.number));
+          }
+        else
+          MGX_TRACE("transfer_create: children patches inconsistent, first-version kernels used");
+      }
   }
   // 1D prolongation matrix into the coarse operator's basis block
   const size_t np1 = (size_t)(2 * p + 1) * n;
@@ -1371,6 +1426,7 @@ int mgx_transfer_destroy(mgx_transfer_t tr)
   (void)hipFree(tr->d.children);
   (void)hipFree(tr->d.weight_shift);
   (void)hipFree(tr->d.own27);
+  (void)hipFree(tr->d.patch);
   (void)hipFree(tr->scratch);
   delete tr;
   return MGX_OK;

@@ -78,7 +78,18 @@ namespace mgx
     uint8_t            *weight_shift = nullptr; // device [n_coarse_cells*27]: weight = 2^-shift
     uint32_t           *own27 = nullptr;        // device [n_fine_cells]: bit e set iff the fine cell is
                                                 // the first (in cell order) containing its entity e
+    // pipelined transfers (mgx_transfer.hip): 125 words per parent for the 5^3 mesh entities of its
+    // children patch: first fine DoF | log2(multiplicity) << 29 | owned-by-this-parent << 31;
+    // nullptr if the fine level has 2^29 DoFs or more (first-version kernels are used then)
+    uint32_t           *patch = nullptr;
+    uint32_t            pipe_grid = 0;          // persistent grid size
   };
+
+  void launch_prolongate_pipe(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
+                              bool with_constraints);
+  void launch_restrict_add_pipe(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
+                                bool with_constraints);
+  int  transfer_pipe_blocks_per_cu(int p, int number);
 
   // ---- cell loops (mgx_kernels.hip) ----
   // dst += A_cells * src  (MatrixFree::cell_loop(local_apply), laplace_operator.h:527-558)

@@ -579,6 +579,8 @@ namespace mgx
   void launch_prolongate(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
                          bool with_constraints)
   {
+    if (t.patch)
+      return launch_prolongate_pipe(s, t, fine, coarse, add, with_constraints);
     if (t.coarse->number == 1)
       {
         MGX_DISPATCH_P(t.coarse->p, prolongate_t<P, double>(s, t, fine, coarse, add, with_constraints));
@@ -603,6 +605,8 @@ namespace mgx
   void launch_restrict_add(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
                            bool with_constraints)
   {
+    if (t.patch)
+      return launch_restrict_add_pipe(s, t, coarse, fine, with_constraints);
     if (t.coarse->number == 1)
       {
         MGX_DISPATCH_P(t.coarse->p, restrict_t<P, double>(s, t, coarse, fine, with_constraints));
