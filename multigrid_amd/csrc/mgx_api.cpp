@@ -1395,7 +1395,29 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
             MGX_HIP(hipMemcpy(tr->d.patch, patch.data(), sizeof(uint32_t) * patch.size(), hipMemcpyHostToDevice));
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, coarse->ctx->device);
-            tr->d.pipe_grid = (uint32_t)(cus * transfer_pipe_blocks_per_cu(p, coarse->d.number));
+            tr->d.n_cus = (uint32_t)std::max(1, cus);
+            // colouring of the coarse cells by index mod 8 (the parity colouring of a Morton-ordered
+            // mesh): valid if no two cells of one colour share a mesh entity
+            if (npar % 8 == 0 && !std::getenv("MGX_RESTRICT_ATOMIC"))
+              {
+                std::vector<uint32_t> idxc(27 * (size_t)npar);
+                MGX_HIP(hipMemcpy(idxc.data(), coarse->d.idx27_plain, sizeof(uint32_t) * idxc.size(), hipMemcpyDeviceToHost));
+                std::vector<uint8_t> mask(coarse->d.n_dofs, 0);
+                bool                 ok = true;
+                for (uint32_t c = 0; c < npar && ok; ++c)
+                  for (int e = 0; e < 27; ++e)
+                    {
+                      const int size = (e % 3 == 1 ? p - 1 : 1) * ((e / 3) % 3 == 1 ? p - 1 : 1) * (e / 9 == 1 ? p - 1 : 1);
+                      if (size == 0 || e == 13)
+                        continue;
+                      uint8_t      &m   = mask[idxc[27 * (size_t)c + e]];
+                      const uint8_t bit = (uint8_t)(1u << (c & 7u));
+                      if (m & bit)
+                        ok = false;
+                      m |= bit;
+                    }
+                tr->d.coarse_coloured = ok;
+              }
           }
         else
           MGX_TRACE("transfer_create: children patches inconsistent, first-version kernels used");

@@ -82,14 +82,15 @@ namespace mgx
     // children patch: first fine DoF | log2(multiplicity) << 29 | owned-by-this-parent << 31;
     // nullptr if the fine level has 2^29 DoFs or more (first-version kernels are used then)
     uint32_t           *patch = nullptr;
-    uint32_t            pipe_grid = 0;          // persistent grid size
+    mutable uint32_t    pipe_grid[4] = {0, 0, 0, 0}; // persistent grid of prolongate(add), prolongate, restrict x2
+    bool                coarse_coloured = false; // coarse cells c and c' with c % 8 == c' % 8 share no DoF
+    uint32_t            n_cus = 256;
   };
 
   void launch_prolongate_pipe(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
                               bool with_constraints);
   void launch_restrict_add_pipe(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
                                 bool with_constraints);
-  int  transfer_pipe_blocks_per_cu(int p, int number);
 
   // ---- cell loops (mgx_kernels.hip) ----
   // dst += A_cells * src  (MatrixFree::cell_loop(local_apply), laplace_operator.h:527-558)

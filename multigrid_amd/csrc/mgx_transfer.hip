@@ -16,9 +16,17 @@
 //     workgroup rather than by bandwidth.
 //   * every fine point of the patch is loaded once ((2p+1)^3 loads per parent instead of the
 //     8 (p+1)^3 of a child-by-child gather).
+//   * the three 1D sweeps run line-per-thread: a thread reads the 2p+1 (restriction) or p+1
+//     (prolongation) values of one line once, keeps them in registers and forms all outputs of the
+//     line with the entries of P1 as wave-uniform scalar operands.  (Forming one output per thread
+//     with both operands read from LDS made the kernels LDS-bandwidth bound: 2 LDS reads per FMA.)
+//     The z sweep works directly on the registers the patch values were prefetched into (restriction)
+//     or are stored from (prolongation); only the two intermediate arrays live in LDS.
 #include "mgx_internal.hpp"
 
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 namespace mgx
 {
@@ -27,11 +35,8 @@ namespace mgx
   {
     static constexpr int N       = P + 1;
     static constexpr int M       = 2 * P + 1;
-    static constexpr int M3      = M * M * M;
-    static constexpr int N3      = N * N * N;
     static constexpr int THREADS = P <= 2 ? 64 : (P <= 4 ? 128 : 256);
-    static constexpr int NIT     = (M3 + THREADS - 1) / THREADS; // patch points per thread
-    static constexpr int NCT     = (N3 + THREADS - 1) / THREADS; // coarse values per thread
+    static constexpr int NL      = (M * M + THREADS - 1) / THREADS; // z-lines of the patch per thread
   };
 
   // patch table word: bits 0..28 first DoF, bits 29..30 log2(multiplicity), bit 31 owned
@@ -44,189 +49,261 @@ namespace mgx
   template <int P>
   __device__ __forceinline__ void patch_layer(int a, int &layer, int &off, int &size)
   {
-    if (a == 0)
-      {
-        layer = 0;
-        off   = 0;
-        size  = 1;
-      }
-    else if (a < P)
-      {
-        layer = 1;
-        off   = a - 1;
-        size  = P - 1;
-      }
-    else if (a == P)
-      {
-        layer = 2;
-        off   = 0;
-        size  = 1;
-      }
-    else if (a < 2 * P)
-      {
-        layer = 3;
-        off   = a - P - 1;
-        size  = P - 1;
-      }
-    else
-      {
-        layer = 4;
-        off   = 0;
-        size  = 1;
-      }
+    layer = a == 0 ? 0 : (a < P ? 1 : (a == P ? 2 : (a < 2 * P ? 3 : 4)));
+    off   = layer == 1 ? a - 1 : (layer == 3 ? a - P - 1 : 0);
+    size  = (layer & 1) ? P - 1 : 1;
   }
 
-  // patch point q (lexicographic in the (2p+1)^3 patch) -> table slot | offset << 8; ~0 beyond
-  template <int P>
-  __device__ __forceinline__ uint32_t patch_code_of(int q)
+  // the z-line (a, b) of the patch: slot and offset of its point c are
+  // slot = 25 ez(c) + sxy, offset = oz(c) nxy + oxy
+  struct PatchLine
   {
-    constexpr int M = 2 * P + 1;
-    if (q >= M * M * M)
-      return 0xFFFFFFFFu;
-    const int x = q % M, y = (q / M) % M, z = q / (M * M);
-    int       ex, ey, ez, ox, oy, oz, nx, ny, nz;
-    patch_layer<P>(x, ex, ox, nx);
-    patch_layer<P>(y, ey, oy, ny);
-    patch_layer<P>(z, ez, oz, nz);
-    (void)nz;
-    return (uint32_t)((ez * 5 + ey) * 5 + ex) | ((uint32_t)((oz * ny + oy) * nx + ox) << 8);
+    int sxy, oxy, nxy;
+  };
+  template <int P>
+  __device__ __forceinline__ PatchLine patch_line(int a, int b)
+  {
+    int ex, ey, ox, oy, nx, ny;
+    patch_layer<P>(a, ex, ox, nx);
+    patch_layer<P>(b, ey, oy, ny);
+    return {ey * 5 + ex, oy * nx + ox, ny * nx};
   }
 
-  // coarse value c (lexicographic in the (p+1)^3 cell) -> slot in the 27-entry row | offset << 8
+  // x-line (j, k) of a coarse cell through its 27-entry row: entities 3 (3 cz + cy) + {0,1,2}
   template <int P>
-  __device__ __forceinline__ uint32_t cell_code_of(int c)
+  __device__ __forceinline__ void coarse_line(int j, int k, int &row, uint32_t &off)
   {
-    constexpr int N = P + 1;
-    if (c >= N * N * N)
-      return 0xFFFFFFFFu;
-    const int i = c % N, j = (c / N) % N, k = c / (N * N);
-    const int cx = i == 0 ? 0 : (i == P ? 2 : 1), cy = j == 0 ? 0 : (j == P ? 2 : 1), cz = k == 0 ? 0 : (k == P ? 2 : 1);
-    const int ox = cx == 1 ? i - 1 : 0, oy = cy == 1 ? j - 1 : 0, oz = cz == 1 ? k - 1 : 0;
-    const int nx = cx == 1 ? P - 1 : 1, ny = cy == 1 ? P - 1 : 1;
-    return (uint32_t)((cz * 3 + cy) * 3 + cx) | ((uint32_t)((oz * ny + oy) * nx + ox) << 8);
+    const int cy = j == 0 ? 0 : (j == P ? 2 : 1), cz = k == 0 ? 0 : (k == P ? 2 : 1);
+    const int oy = cy == 1 ? j - 1 : 0, oz = cz == 1 ? k - 1 : 0;
+    row = 3 * (3 * cz + cy);
+    off = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
   }
+
+  // persistent-workgroup plumbing shared by both kernels: double-buffered table rows in LDS
+  template <int TH>
+  struct TableStage
+  {
+    uint32_t wreg = 0, wreg2 = 0, creg = kInvalid;
+    __device__ __forceinline__ void fetch(const uint32_t *__restrict__ patch, const uint32_t *__restrict__ idx_c,
+                                          uint32_t parent, uint32_t n_parents, int tid, uint32_t stride = 1u)
+    {
+      const bool   ok  = parent < n_parents;
+      const size_t row = (size_t)parent * stride;
+      wreg             = (ok && tid < 125) ? patch[125u * row + tid] : 0u;
+      if (TH < 125)
+        wreg2 = (ok && tid + 64 < 125) ? patch[125u * row + tid + 64] : 0u;
+      creg = (ok && tid < 27) ? idx_c[27u * row + tid] : kInvalid;
+    }
+    __device__ __forceinline__ void publish(uint32_t *tbl, uint32_t *ctb, int tid) const
+    {
+      if (tid < 125)
+        tbl[tid] = wreg;
+      if (TH < 125 && tid + 64 < 125)
+        tbl[tid + 64] = wreg2;
+      if (tid < 27)
+        ctb[tid] = creg;
+    }
+  };
 
   // ------------------------------------------------------------------------------------------
   // restrict_and_add: coarse += P^T (w .* fine), w = 1/multiplicity of the fine DoF among the
   // parent patches.  Shared coarse DoFs receive the parents' contributions by atomic adds.
   // ------------------------------------------------------------------------------------------
-  template <int P, typename T>
+  // COLOURED: the launch covers the parents 8 m + colour only.  Parents of one colour share no
+  // coarse DoF (the host has verified it), so their sums are added with plain read-modify-writes
+  // whose reads are prefetched with the patch data -- deterministic, and not limited by the
+  // memory-side atomic units (scattered fp64 atomics run at a few % of the store rate).
+  template <int P, typename T, bool COLOURED>
   __global__ void __launch_bounds__(TPCfg<P>::THREADS)
-    restrict_pipe_kernel(T *__restrict__ coarse, const T *__restrict__ fine, const uint32_t *__restrict__ patch,
-                         const uint32_t *__restrict__ idx_c, uint32_t n_parents, const Basis1D<T> *__restrict__ B)
+    restrict_pipe_kernel(T *__restrict__ coarse, const T *__restrict__ fine, const uint32_t *__restrict__ patch_,
+                         const uint32_t *__restrict__ idx_c_, uint32_t n_parents_, const Basis1D<T> *__restrict__ B,
+                         uint32_t colour)
   {
+    // a coloured launch sees the table rows of its parents as a strided array
+    const uint32_t  n_parents = COLOURED ? n_parents_ / 8u : n_parents_;
+    const uint32_t  pstride   = COLOURED ? 8u : 1u;
+    const uint32_t *patch = patch_ + (COLOURED ? 125u * (size_t)colour : 0u);
+    const uint32_t *idx_c = idx_c_ + (COLOURED ? 27u * (size_t)colour : 0u);
     using C          = TPCfg<P>;
-    constexpr int N = C::N, M = C::M, M3 = C::M3, TH = C::THREADS, NIT = C::NIT, NCT = C::NCT;
+    constexpr int N = C::N, M = C::M, TH = C::THREADS, NL = C::NL;
     __shared__ uint32_t tbl[2][128];
     __shared__ uint32_t ctb[2][32];
-    __shared__ T        p1[M * N];
-    __shared__ T        out[M3];
-    __shared__ T        t2[N * M * M];
-    __shared__ T        t1[N * N * M];
+    __shared__ T        t2[N * M * M]; // [k][b][a]
+    __shared__ T        t1[N * N * M]; // [k][j][a]
     const int      tid = threadIdx.x;
     const uint32_t G   = gridDim.x;
-    for (int i = tid; i < M * N; i += TH)
-      p1[i] = B->P1[i];
-    uint32_t code[NIT], ccode[NCT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      code[it] = patch_code_of<P>(tid + it * TH);
-#pragma unroll
-    for (int it = 0; it < NCT; ++it)
-      ccode[it] = cell_code_of<P>(tid + it * TH);
+    const T       *p1  = B->P1; // p1[a * N + i], wave-uniform
 
-    uint32_t pc = blockIdx.x;
-    // table rows of a parent: threads 0..124 the patch row (two words per thread with 64
-    // threads), threads 0..26 the coarse row
-    uint32_t wreg = 0, wreg2 = 0, creg = 0;
-    auto     fetch_tables = [&](uint32_t parent) {
-      const bool ok = parent < n_parents;
-      wreg          = (ok && tid < 125) ? patch[125u * (size_t)parent + tid] : 0u;
-      if (TH < 125)
-        wreg2 = (ok && tid + 64 < 125) ? patch[125u * (size_t)parent + tid + 64] : 0u;
-      creg = (ok && tid < 27) ? idx_c[27u * (size_t)parent + tid] : kInvalid;
-    };
-    auto publish = [&](int b) {
-      if (tid < 125)
-        tbl[b][tid] = wreg;
-      if (TH < 125 && tid + 64 < 125)
-        tbl[b][tid + 64] = wreg2;
-      if (tid < 27)
-        ctb[b][tid] = creg;
-    };
-    T        v[NIT];
-    uint64_t shifts = 0;
-    auto     issue  = [&](int b) {
-      shifts = 0;
+    PatchLine line[NL];
+    bool      has[NL];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)
+    for (int it = 0; it < NL; ++it)
+      {
+        const int l = tid + it * TH;
+        has[it]     = l < M * M;
+        line[it]    = patch_line<P>(has[it] ? l % M : 0, has[it] ? l / M : 0);
+      }
+    // layer / offset of point c along z: compile-time after unrolling
+    auto zslot = [](int c) {
+      int e, o, n;
+      patch_layer<P>(c, e, o, n);
+      return e;
+    };
+    auto zoff = [](int c) {
+      int e, o, n;
+      patch_layer<P>(c, e, o, n);
+      return o;
+    };
+
+    static_assert(N * N <= TH, "one coarse x-line per thread");
+    const bool cl   = tid < N * N;
+    int        crow = 0;
+    uint32_t   coff = 0;
+    coarse_line<P>(cl ? tid % N : 0, cl ? tid / N : 0, crow, coff);
+
+    uint32_t        pc = blockIdx.x;
+    TableStage<TH>  ts;
+    T               v[NL][M];
+    T               co[COLOURED ? N : 1]; // coloured: current coarse values of this thread's x-line
+    uint32_t        sh[NL][5]; // shift of the five z-layers of the line
+    auto            issue = [&](int b) {
+      if (COLOURED)
         {
-          const uint32_t cd = code[it];
-          const uint32_t w  = tbl[b][cd == 0xFFFFFFFFu ? 0 : (cd & 0xFF)];
-          const uint32_t a  = cd == 0xFFFFFFFFu ? 0u : pw_index(w) + (cd >> 8);
-          v[it]             = fine[a];
-          shifts |= (uint64_t)pw_shift(w) << (2 * it);
+          const uint32_t b0 = ctb[b][crow], b1 = ctb[b][crow + 1], b2 = ctb[b][crow + 2];
+          co[0]             = coarse[(cl && b0 != kInvalid) ? b0 + coff : 0u];
+#pragma unroll
+          for (int i = 1; i < P; ++i)
+            co[COLOURED ? i : 0] = coarse[(cl && b1 != kInvalid) ? b1 + coff * (uint32_t)(P - 1) + (uint32_t)(i - 1) : 0u];
+          co[COLOURED ? P : 0] = coarse[(cl && b2 != kInvalid) ? b2 + coff : 0u];
+        }
+#pragma unroll
+      for (int it = 0; it < NL; ++it)
+        {
+          uint32_t w[5];
+#pragma unroll
+          for (int e = 0; e < 5; ++e)
+            {
+              w[e]      = tbl[b][has[it] ? 25 * e + line[it].sxy : 0];
+              sh[it][e] = pw_shift(w[e]);
+            }
+#pragma unroll
+          for (int c = 0; c < M; ++c)
+            v[it][c] = fine[has[it] ? pw_index(w[zslot(c)]) + (uint32_t)(zoff(c) * line[it].nxy + line[it].oxy) : 0u];
         }
     };
 
-    fetch_tables(pc);
-    publish(0);
+    ts.fetch(patch, idx_c, pc, n_parents, tid, pstride);
+    ts.publish(tbl[0], ctb[0], tid);
     __syncthreads();
     issue(0);
-    fetch_tables(pc + G);
+    ts.fetch(patch, idx_c, pc + G, n_parents, tid, pstride);
     int buf = 0;
     for (; pc < n_parents; pc += G)
       {
-        publish(buf ^ 1);
-        // weighted fine values of this parent (loaded during the previous iteration)
+        ts.publish(tbl[buf ^ 1], ctb[buf ^ 1], tid);
+        T cur[COLOURED ? N : 1];
+        if (COLOURED)
+          {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (code[it] != 0xFFFFFFFFu)
-            {
-              const uint32_t sh = (uint32_t)(shifts >> (2 * it)) & 3u;
-              out[tid + it * TH] = v[it] * (T(1) / T(1u << sh));
-            }
+            for (int i = 0; i < N; ++i)
+              cur[COLOURED ? i : 0] = co[COLOURED ? i : 0];
+          }
+        // z^T on the prefetched registers: t2[k][b][a] = sum_c P1[c][k] w v[c]
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+          {
+            T r[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+              r[k] = T(0);
+#pragma unroll
+            for (int c = 0; c < M; ++c)
+              {
+                const T x = v[it][c] * (T(1) / T(1u << sh[it][zslot(c)]));
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                  r[k] = fma(p1[c * N + k], x, r[k]);
+              }
+            if (has[it])
+              {
+                const int l = tid + it * TH;
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                  t2[k * M * M + l] = r[k];
+              }
+          }
         __syncthreads();
         if (pc + G < n_parents)
           issue(buf ^ 1);
-        fetch_tables(pc + 2 * G);
-        for (int o = tid; o < N * M * M; o += TH) // z^T: [k][b][a]
+        ts.fetch(patch, idx_c, pc + 2 * G, n_parents, tid, pstride);
+        // y^T: line (k, a)
+        for (int l = tid; l < N * M; l += TH)
           {
-            const int ba = o % (M * M), k = o / (M * M);
-            T         s  = 0;
-#pragma unroll
-            for (int c = 0; c < M; ++c)
-              s = fma(p1[c * N + k], out[c * M * M + ba], s);
-            t2[o] = s;
-          }
-        __syncthreads();
-        for (int o = tid; o < N * N * M; o += TH) // y^T: [k][j][a]
-          {
-            const int a = o % M, j = (o / M) % N, k = o / (M * N);
-            T         s = 0;
+            const int a = l % M, k = l / M;
+            T         x[M], r[N];
 #pragma unroll
             for (int b = 0; b < M; ++b)
-              s = fma(p1[b * N + j], t2[(k * M + b) * M + a], s);
-            t1[o] = s;
+              x[b] = t2[(k * M + b) * M + a];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              {
+                T s = p1[j] * x[0];
+#pragma unroll
+                for (int b = 1; b < M; ++b)
+                  s = fma(p1[b * N + j], x[b], s);
+                r[j] = s;
+              }
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              t1[(k * N + j) * M + a] = r[j];
           }
         __syncthreads();
-        // x^T and scatter: thread c owns coarse value (i, j, k)
-#pragma unroll
-        for (int it = 0; it < NCT; ++it)
+        // x^T and scatter: line (j, k) of the coarse cell
+        if (cl)
           {
-            const uint32_t cd = ccode[it];
-            if (cd == 0xFFFFFFFFu)
-              continue;
-            const int c = tid + it * TH, i = c % N, kj = c / N;
-            T         s = 0;
+            const int l = tid;
+            T         x[M], r[N];
 #pragma unroll
             for (int a = 0; a < M; ++a)
-              s = fma(p1[a * N + i], t1[kj * M + a], s);
-            const uint32_t w = ctb[buf][cd & 0xFF];
-            if (w != kInvalid)
-              unsafeAtomicAdd(&coarse[w + (cd >> 8)], s);
+              x[a] = t1[l * M + a];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              {
+                T s = p1[i] * x[0];
+#pragma unroll
+                for (int a = 1; a < M; ++a)
+                  s = fma(p1[a * N + i], x[a], s);
+                r[i] = s;
+              }
+            const uint32_t b0 = ctb[buf][crow], b1 = ctb[buf][crow + 1], b2 = ctb[buf][crow + 2];
+            if (COLOURED)
+              {
+                if (b0 != kInvalid)
+                  coarse[b0 + coff] = cur[0] + r[0];
+                if (b1 != kInvalid)
+                  {
+#pragma unroll
+                    for (int i = 1; i < P; ++i)
+                      coarse[b1 + coff * (uint32_t)(P - 1) + (uint32_t)(i - 1)] = cur[COLOURED ? i : 0] + r[i];
+                  }
+                if (b2 != kInvalid)
+                  coarse[b2 + coff] = cur[COLOURED ? P : 0] + r[P];
+              }
+            else
+              {
+                if (b0 != kInvalid)
+                  unsafeAtomicAdd(&coarse[b0 + coff], r[0]);
+                if (b1 != kInvalid)
+                  {
+#pragma unroll
+                    for (int i = 1; i < P; ++i)
+                      unsafeAtomicAdd(&coarse[b1 + coff * (uint32_t)(P - 1) + (uint32_t)(i - 1)], r[i]);
+                  }
+                if (b2 != kInvalid)
+                  unsafeAtomicAdd(&coarse[b2 + coff], r[P]);
+              }
           }
-        __syncthreads(); // tables of `buf` and the sweep buffers are free again
+        __syncthreads(); // tables of `buf`, t1 and t2 are free again
         buf ^= 1;
       }
   }
@@ -242,131 +319,175 @@ namespace mgx
                            const uint32_t *__restrict__ idx_c, uint32_t n_parents, const Basis1D<T> *__restrict__ B)
   {
     using C          = TPCfg<P>;
-    constexpr int N = C::N, M = C::M, N3 = C::N3, TH = C::THREADS, NIT = C::NIT, NCT = C::NCT;
+    constexpr int N = C::N, M = C::M, TH = C::THREADS, NL = C::NL;
+    constexpr int NA = ADD ? M : 1;
+    static_assert(N * N <= TH, "one coarse x-line per thread");
     __shared__ uint32_t tbl[2][128];
     __shared__ uint32_t ctb[2][32];
-    __shared__ T        p1[M * N];
-    __shared__ T        in[N3];
-    __shared__ T        t1[N * N * M];
-    __shared__ T        t2[N * M * M];
+    __shared__ T        t1[N * N * M]; // [k][j][a]
+    __shared__ T        t2[N * M * M]; // [k][b][a]
     const int      tid = threadIdx.x;
     const uint32_t G   = gridDim.x;
-    for (int i = tid; i < M * N; i += TH)
-      p1[i] = B->P1[i];
-    uint32_t code[NIT], ccode[NCT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      code[it] = patch_code_of<P>(tid + it * TH);
-#pragma unroll
-    for (int it = 0; it < NCT; ++it)
-      ccode[it] = cell_code_of<P>(tid + it * TH);
+    const T       *p1  = B->P1;
 
-    uint32_t pc = blockIdx.x;
-    uint32_t wreg = 0, wreg2 = 0, creg = 0;
-    auto     fetch_tables = [&](uint32_t parent) {
-      const bool ok = parent < n_parents;
-      wreg          = (ok && tid < 125) ? patch[125u * (size_t)parent + tid] : 0u;
-      if (TH < 125)
-        wreg2 = (ok && tid + 64 < 125) ? patch[125u * (size_t)parent + tid + 64] : 0u;
-      creg = (ok && tid < 27) ? idx_c[27u * (size_t)parent + tid] : kInvalid;
-    };
-    auto publish = [&](int b) {
-      if (tid < 125)
-        tbl[b][tid] = wreg;
-      if (TH < 125 && tid + 64 < 125)
-        tbl[b][tid + 64] = wreg2;
-      if (tid < 27)
-        ctb[b][tid] = creg;
-    };
-    T    cv[NCT], fo[ADD ? NIT : 1];
-    auto issue = [&](int b) {
+    PatchLine line[NL];
+    bool      has[NL];
 #pragma unroll
-      for (int it = 0; it < NCT; ++it)
-        {
-          const uint32_t cd    = ccode[it];
-          const uint32_t w     = ctb[b][cd == 0xFFFFFFFFu ? 0 : (cd & 0xFF)];
-          const bool     valid = cd != 0xFFFFFFFFu && w != kInvalid;
-          const T        x     = coarse[valid ? w + (cd >> 8) : 0u];
-          cv[it]               = valid ? x : T(0);
-        }
+    for (int it = 0; it < NL; ++it)
+      {
+        const int l = tid + it * TH;
+        has[it]     = l < M * M;
+        line[it]    = patch_line<P>(has[it] ? l % M : 0, has[it] ? l / M : 0);
+      }
+    auto zslot = [](int c) {
+      int e, o, n;
+      patch_layer<P>(c, e, o, n);
+      return e;
+    };
+    auto zoff = [](int c) {
+      int e, o, n;
+      patch_layer<P>(c, e, o, n);
+      return o;
+    };
+    // coarse x-line (j, k) of this thread
+    const bool cl  = tid < N * N;
+    int        crow = 0;
+    uint32_t   coff = 0;
+    coarse_line<P>(cl ? tid % N : 0, cl ? tid / N : 0, crow, coff);
+
+    uint32_t       pc = blockIdx.x;
+    TableStage<TH> ts;
+    T              cv[N], fo[NL][NA];
+    auto           issue = [&](int b) {
+      const uint32_t b0 = ctb[b][crow], b1 = ctb[b][crow + 1], b2 = ctb[b][crow + 2];
+      const bool     v0 = cl && b0 != kInvalid, v1 = cl && b1 != kInvalid, v2 = cl && b2 != kInvalid;
+      cv[0]             = coarse[v0 ? b0 + coff : 0u];
+#pragma unroll
+      for (int i = 1; i < P; ++i)
+        cv[i] = coarse[v1 ? b1 + coff * (uint32_t)(P - 1) + (uint32_t)(i - 1) : 0u];
+      cv[P] = coarse[v2 ? b2 + coff : 0u];
+      if (!v0)
+        cv[0] = T(0);
+#pragma unroll
+      for (int i = 1; i < P; ++i)
+        if (!v1)
+          cv[i] = T(0);
+      if (!v2)
+        cv[P] = T(0);
       if (ADD)
         {
 #pragma unroll
-          for (int it = 0; it < NIT; ++it)
+          for (int it = 0; it < NL; ++it)
             {
-              const uint32_t cd = code[it];
-              const uint32_t w  = tbl[b][cd == 0xFFFFFFFFu ? 0 : (cd & 0xFF)];
-              const bool     mine = cd != 0xFFFFFFFFu && pw_owned(w);
-              fo[ADD ? it : 0]  = fine[mine ? pw_index(w) + (cd >> 8) : 0u];
+              uint32_t w[5];
+#pragma unroll
+              for (int e = 0; e < 5; ++e)
+                w[e] = tbl[b][has[it] ? 25 * e + line[it].sxy : 0];
+#pragma unroll
+              for (int c = 0; c < M; ++c)
+                {
+                  const uint32_t ww = w[zslot(c)];
+                  fo[it][c % NA]    = fine[(has[it] && pw_owned(ww))
+                                          ? pw_index(ww) + (uint32_t)(zoff(c) * line[it].nxy + line[it].oxy)
+                                          : 0u];
+                }
             }
         }
     };
 
-    fetch_tables(pc);
-    publish(0);
+    ts.fetch(patch, idx_c, pc, n_parents, tid);
+    ts.publish(tbl[0], ctb[0], tid);
     __syncthreads();
     issue(0);
-    fetch_tables(pc + G);
+    ts.fetch(patch, idx_c, pc + G, n_parents, tid);
     int buf = 0;
     for (; pc < n_parents; pc += G)
       {
-        publish(buf ^ 1);
+        ts.publish(tbl[buf ^ 1], ctb[buf ^ 1], tid);
+        // x on the prefetched coarse line: t1[k][j][a] = sum_i P1[a][i] u[i]
+        if (cl)
+          {
 #pragma unroll
-        for (int it = 0; it < NCT; ++it)
-          if (ccode[it] != 0xFFFFFFFFu)
-            in[tid + it * TH] = cv[it];
-        // the old fine values of this parent stay in registers until the z sweep; move them out of
-        // the way of the next parent's prefetch
-        T fcur[ADD ? NIT : 1];
+            for (int a = 0; a < M; ++a)
+              {
+                T s = p1[a * N] * cv[0];
+#pragma unroll
+                for (int i = 1; i < N; ++i)
+                  s = fma(p1[a * N + i], cv[i], s);
+                t1[tid * M + a] = s;
+              }
+          }
+        T fcur[NL][NA];
         if (ADD)
           {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
-              fcur[ADD ? it : 0] = fo[ADD ? it : 0];
+            for (int it = 0; it < NL; ++it)
+#pragma unroll
+              for (int c = 0; c < NA; ++c)
+                fcur[it][c] = fo[it][c];
           }
         __syncthreads();
         if (pc + G < n_parents)
           issue(buf ^ 1);
-        fetch_tables(pc + 2 * G);
-        for (int o = tid; o < N * N * M; o += TH) // x: [k][j][a]
+        ts.fetch(patch, idx_c, pc + 2 * G, n_parents, tid);
+        // y: line (k, a)
+        for (int l = tid; l < N * M; l += TH)
           {
-            const int a = o % M, kj = o / M;
-            T         s = 0;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              s = fma(p1[a * N + i], in[kj * N + i], s);
-            t1[o] = s;
-          }
-        __syncthreads();
-        for (int o = tid; o < N * M * M; o += TH) // y: [k][b][a]
-          {
-            const int a = o % M, b = (o / M) % M, k = o / (M * M);
-            T         s = 0;
+            const int a = l % M, k = l / M;
+            T         x[N];
 #pragma unroll
             for (int j = 0; j < N; ++j)
-              s = fma(p1[b * N + j], t1[(k * N + j) * M + a], s);
-            t2[o] = s;
+              x[j] = t1[(k * N + j) * M + a];
+#pragma unroll
+            for (int b = 0; b < M; ++b)
+              {
+                T s = p1[b * N] * x[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j)
+                  s = fma(p1[b * N + j], x[j], s);
+                t2[(k * M + b) * M + a] = s;
+              }
           }
         __syncthreads();
-        // z sweep into registers, owner writes
+        // z into registers, owner writes
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
+        for (int it = 0; it < NL; ++it)
           {
-            const uint32_t cd = code[it];
-            if (cd == 0xFFFFFFFFu)
+            if (!has[it])
               continue;
-            const int o = tid + it * TH, ba = o % (M * M), c = o / (M * M);
-            T         s = 0;
+            const int l = tid + it * TH;
+            T         x[N];
 #pragma unroll
             for (int k = 0; k < N; ++k)
-              s = fma(p1[c * N + k], t2[k * M * M + ba], s);
-            const uint32_t w = tbl[buf][cd & 0xFF];
-            if (pw_owned(w))
-              fine[pw_index(w) + (cd >> 8)] = ADD ? fcur[ADD ? it : 0] + s : s;
+              x[k] = t2[k * M * M + l];
+            uint32_t w[5];
+#pragma unroll
+            for (int e = 0; e < 5; ++e)
+              w[e] = tbl[buf][25 * e + line[it].sxy];
+#pragma unroll
+            for (int c = 0; c < M; ++c)
+              {
+                T s = p1[c * N] * x[0];
+#pragma unroll
+                for (int k = 1; k < N; ++k)
+                  s = fma(p1[c * N + k], x[k], s);
+                const uint32_t ww = w[zslot(c)];
+                if (pw_owned(ww))
+                  fine[pw_index(ww) + (uint32_t)(zoff(c) * line[it].nxy + line[it].oxy)] =
+                    ADD ? fcur[it][c % NA] + s : s;
+              }
           }
         __syncthreads();
         buf ^= 1;
       }
+  }
+
+  // smallest coarse level restricted colour by colour (8 launches); below it one launch with
+  // atomics is cheaper.  MGX_RESTRICT_COLOUR_MIN overrides (the tests set 8).
+  static uint32_t coloured_min_cells()
+  {
+    const char *e = std::getenv("MGX_RESTRICT_COLOUR_MIN");
+    return e ? (uint32_t)std::atol(e) : 16384u;
   }
 
   // ------------------------------------------------------------------------------------------
@@ -377,19 +498,43 @@ namespace mgx
     using C               = TPCfg<P>;
     const OperatorData &c = *t.coarse;
     const uint32_t     *idx_c = with_constraints ? c.idx27 : c.idx27_plain;
-    const uint32_t      grid  = std::min<uint32_t>(c.n_cells, t.pipe_grid);
+    // persistent grid: as many workgroups as the device holds at once (queried per kernel)
+    auto grid_of = [&](int slot, const void *kernel) {
+      if (t.pipe_grid[slot] == 0)
+        {
+          int per_cu = 1;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, C::THREADS, 0) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+          t.pipe_grid[slot] = (uint32_t)per_cu * t.n_cus;
+        }
+      return std::min<uint32_t>(c.n_cells, t.pipe_grid[slot]);
+    };
     if (what == 0)
       {
         if (add)
-          hipLaunchKernelGGL((prolongate_pipe_kernel<P, T, true>), dim3(grid), dim3(C::THREADS), 0, s, (T *)fine,
-                             (const T *)coarse_in, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis);
+          hipLaunchKernelGGL((prolongate_pipe_kernel<P, T, true>),
+                             dim3(grid_of(0, (const void *)prolongate_pipe_kernel<P, T, true>)), dim3(C::THREADS), 0,
+                             s, (T *)fine, (const T *)coarse_in, t.patch, idx_c, c.n_cells,
+                             (const Basis1D<T> *)c.basis);
         else
-          hipLaunchKernelGGL((prolongate_pipe_kernel<P, T, false>), dim3(grid), dim3(C::THREADS), 0, s, (T *)fine,
-                             (const T *)coarse_in, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis);
+          hipLaunchKernelGGL((prolongate_pipe_kernel<P, T, false>),
+                             dim3(grid_of(1, (const void *)prolongate_pipe_kernel<P, T, false>)), dim3(C::THREADS),
+                             0, s, (T *)fine, (const T *)coarse_in, t.patch, idx_c, c.n_cells,
+                             (const Basis1D<T> *)c.basis);
+      }
+    else if (t.coarse_coloured && c.n_cells >= coloured_min_cells())
+      {
+        // 8 launches, one per colour (parent index mod 8): atomic-free and deterministic
+        const uint32_t g = std::min<uint32_t>(c.n_cells / 8u, grid_of(3, (const void *)restrict_pipe_kernel<P, T, true>));
+        for (uint32_t colour = 0; colour < 8; ++colour)
+          hipLaunchKernelGGL((restrict_pipe_kernel<P, T, true>), dim3(g), dim3(C::THREADS), 0, s, (T *)coarse_out,
+                             (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis, colour);
       }
     else
-      hipLaunchKernelGGL((restrict_pipe_kernel<P, T>), dim3(grid), dim3(C::THREADS), 0, s, (T *)coarse_out,
-                         (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis);
+      hipLaunchKernelGGL((restrict_pipe_kernel<P, T, false>),
+                         dim3(grid_of(2, (const void *)restrict_pipe_kernel<P, T, false>)), dim3(C::THREADS), 0, s,
+                         (T *)coarse_out, (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis,
+                         0u);
   }
 
 #define MGX_TP_DISPATCH(p, ...)                            \
@@ -433,15 +578,4 @@ namespace mgx
       }
   }
 
-  // workgroups per CU the kernels can hold (LDS bound), for the persistent grid
-  int transfer_pipe_blocks_per_cu(int p, int number)
-  {
-    const size_t ts = number == 1 ? 8 : 4;
-    const size_t N = p + 1, M = 2 * p + 1;
-    const size_t lds = 4 * (2 * 128 + 2 * 32) + ts * (M * N + M * M * M + N * M * M + N * N * M);
-    const int    th  = p <= 2 ? 64 : (p <= 4 ? 128 : 256);
-    const int    by_lds = (int)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
-    const int    by_waves = 32 / (th / 64);
-    return std::min(by_lds, by_waves);
-  }
 } // namespace mgx

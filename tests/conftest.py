@@ -7,6 +7,8 @@ import pytest
 # (the production default switches to it from 2048 bricks on; test_gpu_parity.py has one case at the
 # default threshold)
 os.environ.setdefault("MGX_BRICK_MIN", "1")
+# likewise the colour-by-colour (atomic-free) restriction, production default from 16384 coarse cells on
+os.environ.setdefault("MGX_RESTRICT_COLOUR_MIN", "8")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

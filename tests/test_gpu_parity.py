@@ -198,6 +198,7 @@ def test_default_brick_threshold(ctx, monkeypatch):
     """With the production threshold (bricks from 2048 per level on) small levels use the per-cell
     kernel and the finest level of a 64^3 mesh (4096 bricks) the brick loop; same results."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
+    monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
     p, nr = 2, 6
     cube = mg.Cube(p, 1, nr)
     orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1)
