@@ -157,7 +157,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {form: ctx.profile_read(form) for form in range(5)}
+    prof = {form: ctx.profile_read(form) for form in range(7)}
     ctx.profile_enable(False)
     if dist is not None:
         import torch
@@ -180,13 +180,16 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     total_dofs = global_dofs
-    # Roofline of the dominant kernel.  Of the 7 finest-level cell loops of one step, 3 are the
-    # fused Chebyshev iteration (form 2: x, x_old, b, D^-1 read + x_new written = 5 accesses =
-    # 40 B/DoF algorithmic, the reference's own 5-access model, matvec_dg_cheby/program.cc:178);
-    # the plain matvec (form 0) moves 16 B/DoF algorithmic.  One application =
-    # n_colours launches, each over n_dofs / n_colours DoFs.
-    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0}
-    NAMES = {0: "kPlain", 1: "kResidual", 2: "kCheb", 3: "kChebFirst", 4: "kChebZeroOld"}
+    # Roofline of the dominant kernel.  A step runs 7 finest-level cell loops: the plain matvec
+    # (form 0, 16 B/DoF algorithmic), the residual (form 1), and 5 Chebyshev
+    # iterations -- post-smoothing: first step (form 3) + 2 full iterations (form 2: x, x_old, b,
+    # D^-1 read + x_new written = 5 accesses = 40 B/DoF, the reference's own 5-access model,
+    # matvec_dg_cheby/program.cc:178); pre-smoothing from a zero guess: forms 5 and 6, which
+    # recompute x_1 = D^-1 b / theta instead of storing it.  Form 2 has the most launches and the
+    # most traffic.  One application = n_colours launches, each over n_dofs / n_colours DoFs.
+    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0, 5: 24.0, 6: 32.0}
+    NAMES = {0: "kPlain", 1: "kResidual", 2: "kCheb", 3: "kChebFirst", 4: "kChebZeroOld", 5: "kChebInit",
+             6: "kChebOldInit"}
 
     def roof(form):
         launches, ms = prof[form]
@@ -198,7 +201,7 @@ def main():
         # cannot run inside this timed process) and committed under profiles/; it is reported here
         # for the configuration it was measured on
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01e_pmc_traffic_128cube_p4.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01f_pmc_traffic_128cube_p4.json")
         if args.degree == 4 and args.cells == 128 and vnum == mg.F64 and os.path.exists(pmc_file):
             k = json.load(open(pmc_file))["kernels"].get(NAMES[form])
             if k:
@@ -208,7 +211,7 @@ def main():
         return {"bound": "hbm", "kernel": "mgx::brick_sep_kernel<%d,double,%s> (finest level, per colour launch)"
                 % (args.degree, NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01e_pmc_traffic_128cube_p4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                "traffic_source": "profiles/r01f_pmc_traffic_128cube_p4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                   "separate passes, FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
                 "launches": launches, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_bytes_per_dof": ALG[form]}

@@ -1,0 +1,59 @@
+"""profiles/*_pmc_traffic_*.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+tools/matvec_loop.py <cells> <n> cheb.  usage: make_traffic_json.py fetch.csv write.csv cells out.json
+
+Streaming kernels of the same run with known byte counts calibrate the counters (gfx950:
+FETCH_SIZE reports 1/2 for 8-B-per-lane reads, WRITE_SIZE is exact)."""
+import csv, json, sys, collections
+
+
+def load(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            blocks = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+            acc[r["Kernel_Name"].split("(")[0]][blocks].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fe, wr, cells, out = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    p = 4
+    n = (cells * p + 1) ** 3
+    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 tools/matvec_loop.py %d 3 cheb"
+                      "   (and a second pass with --pmc WRITE_SIZE)" % cells,
+           "workload": "poisson_cube FE_Q(4) %d^3 cells, %d DoFs, fp64, finest level, per colour launch" % (cells, n),
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
+                    "(gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md 'HBM')",
+           "calibration": {}, "kernels": {}}
+    known = {"void mgx::k_copy_cast<double, double>": (8 * n, 8 * n), "void mgx::k_xpby<double>": (16 * n, 8 * n),
+             "void mgx::k_dot_partial<double>": (16 * n, 0)}
+    for k, (rb, wb) in known.items():
+        if k in fe and k in wr:
+            big = max(fe[k].keys())
+            f = sum(fe[k][big]) / len(fe[k][big])
+            w = sum(wr[k][big]) / len(wr[k][big])
+            res["calibration"][k.replace("void mgx::", "")] = {
+                "known_read_bytes": rb, "FETCH_SIZE_KiB": f, "reported/known": f * 1024 / rb,
+                "known_write_bytes": wb, "WRITE_SIZE_KiB": w, "write reported/known": (w * 1024 / wb) if wb else None}
+    names = {0: ("kPlain", 16), 1: ("kResidual", 24), 2: ("kCheb", 40), 3: ("kChebFirst", 32), 4: ("kChebZeroOld", 32),
+             5: ("kChebInit", 24), 6: ("kChebOldInit", 32)}
+    for mode, (nm, alg) in names.items():
+        k = "void mgx::brick_sep_kernel<4, double, %d>" % mode
+        if k not in fe or k not in wr:
+            continue
+        big = max(fe[k].keys())
+        f = sum(fe[k][big]) / len(fe[k][big])
+        w = sum(wr[k][big]) / len(wr[k][big])
+        traffic = (2 * f + w) * 1024
+        res["kernels"][nm] = {"kernel": k.replace("void ", ""), "blocks_per_launch": big,
+                              "launches_sampled": [len(fe[k][big]), len(wr[k][big])],
+                              "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": traffic,
+                              "algorithmic_bytes_per_launch": alg * n / 8.0,
+                              "traffic/algorithmic": traffic / (alg * n / 8.0)}
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res["kernels"].items():
+        print(k, "%.1f MB" % (v["traffic_bytes_per_launch"] / 1e6), "x%.3f" % v["traffic/algorithmic"])
+
+
+if __name__ == "__main__":
+    main()

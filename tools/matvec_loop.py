@@ -20,6 +20,7 @@ if mode == "vmult":
 else:
     sm = mg.Chebyshev(op, 20., 3, 15)
     for _ in range(n):
-        sm.step(y, x)
+        sm.step(y, x)   # forms 3, 2, 2
+        sm.vmult(y, x)  # forms 5, 6 (zero initial guess)
 ctx.sync()
 print("done", cube.n_dofs(l))
