@@ -63,10 +63,10 @@ def cpu_baseline(args):
     orc = Oracle(args.degree, ns, nr, degree=args.smoother_degree, n_cycles=1, vfloat=False)
     n = orc.n_dofs(orc.max_level)
     orc.time_vmult(orc.max_level, 1)  # warm-up
-    n_mv = 20
+    n_mv = 40
     t_mv = orc.time_vmult(orc.max_level, n_mv) / n_mv
     orc.time_vcycle(1)
-    n_vc = 8
+    n_vc = 16
     t_vc = orc.time_vcycle(n_vc) / n_vc
     threads = orc.num_threads()
     orc.close()
