@@ -106,6 +106,7 @@ def main():
     t_setup = time.time()
     vnum = mg.F64 if args.vcycle_number == "f64" else mg.F32
     decomposed = world > 1 and not args.replicas
+    native = False
     if decomposed:
         if ns != 1:
             raise SystemExit("--cells must be a power of two for N > 1 (one coarse cube per rank)")
@@ -113,6 +114,9 @@ def main():
         comm = mg.Communicator(ctx, dist)
         cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
         solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, comm=comm)
+        # RCCL send/recv issued by the library on its own stream (no host round trip per exchange),
+        # switched on only after one exchange + one reduction agree bitwise with the torch transport
+        native = comm.verify_and_enable_native(solver.matrix_dp(cube.max_level), cube.n_dofs(cube.max_level))
         global_dofs = 1
         for d in range(3):
             global_dofs *= procs[d] * args.cells * args.degree + 1
@@ -228,8 +232,9 @@ def main():
                    "cells_per_dim": args.cells, "degree": args.degree, "n_dofs_per_gpu": n_dofs,
                    "global_dofs": total_dofs,
                    "parallelism": "1 GPU" if world == 1 else
-                   ("domain decomposition %dx%dx%d, one %d^3-cell cube per GPU, interface exchange over RCCL" %
-                    (procs + (args.cells,)) if decomposed else "%d independent replicas" % world)},
+                   ("domain decomposition %dx%dx%d, one %d^3-cell cube per GPU, interface exchange over RCCL (%s)" %
+                    (procs + (args.cells, "ncclSend/Recv on the solver stream" if native else
+                              "torch.distributed P2P batches")) if decomposed else "%d independent replicas" % world)},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
         "roofline": roof(2) if vnum == mg.F64 else roof(0),

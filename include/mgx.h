@@ -87,6 +87,19 @@ typedef struct
 } mgx_comm_desc;
 int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm);
 
+/* Native transport: the exchange becomes one group of ncclSend/ncclRecv and the reductions
+ * ncclAllReduce, issued by the library on the context's stream -- ordered with the pack/unpack
+ * kernels by the stream, no host synchronisation per exchange (one process per GPU, RCCL over
+ * xGMI).  librccl is bound at run time.  Rank 0 obtains an id and the caller distributes its
+ * MGX_RCCL_ID_BYTES bytes to all ranks (MPI_Bcast, torch.distributed.broadcast, ...); then every
+ * rank calls mgx_context_set_rccl (collective).  mgx_context_use_rccl switches between the native
+ * transport and the callbacks of mgx_context_set_comm (if both are set), e.g. to cross-check one
+ * against the other. */
+#define MGX_RCCL_ID_BYTES 128
+int mgx_rccl_unique_id(void *id_out);
+int mgx_context_set_rccl(mgx_context_t ctx, int rank, int size, const void *id);
+int mgx_context_use_rccl(mgx_context_t ctx, int enable);
+
 /* exchange plan of one level vector layout (host lists, copied) */
 typedef struct
 {

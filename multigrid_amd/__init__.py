@@ -10,6 +10,7 @@ for the poisson_cube path on top of the C ABI in include/mgx.h:
 All numerical work runs in hand-written HIP kernels inside libmgx.so; nothing here computes.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -42,10 +43,18 @@ class Communicator:
     with one batch of point-to-point operations (at most 7 neighbours in a 2x2x2 process grid,
     each a direct xGMI peer)."""
 
-    def __init__(self, ctx, dist, device_transport=None):
+    def __init__(self, ctx, dist, device_transport=None, native=None):
+        """native: also create an RCCL communicator inside the library (mgx_context_set_rccl; the
+        unique id travels over `dist`).  It stays switched off until verify_and_enable_native() has
+        compared one exchange and one reduction with the callback transport on every rank.
+        Default: on for the nccl backend unless MGX_NATIVE_RCCL=0."""
         self.ctx, self.dist = ctx, dist
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         self.device_transport = (dist.get_backend() == "nccl") if device_transport is None else device_transport
+        self.native_ready = False
+        self.native_enabled = False
+        self._native_wanted = (self.device_transport and os.environ.get("MGX_NATIVE_RCCL", "1") != "0") \
+            if native is None else native
         self._tensors = {}   # device pointer -> torch CUDA tensor backing an exchange buffer
         self._p2p = {}       # plan_id -> cached P2POp list
         self._ex = _lib.EXCHANGE_FN(self._exchange)
@@ -54,6 +63,69 @@ class Communicator:
         self.desc = _lib.CommDesc(self.rank, self.size, None, self._ex, self._ar, self._al)
         check(ctx.lib.mgx_context_set_comm(ctx.h, C.byref(self.desc)))
         ctx._comm = self  # keep the callbacks alive
+        if self._native_wanted:
+            self._setup_native()
+
+    def _setup_native(self):
+        """collective: every rank must arrive here; a failure on any rank disables it on all"""
+        import sys
+        import torch
+        lib, h = self.ctx.lib, self.ctx.h
+        buf = (C.c_uint8 * 128)()
+        ok = 1
+        if self.rank == 0 and lib.mgx_rccl_unique_id(buf) != 0:
+            ok = 0
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(list(buf) + [ok], dtype=torch.uint8, device=dev)
+        self.dist.broadcast(t, 0)
+        vals = t.cpu().tolist()
+        if vals[128] == 0:
+            print("mgx Communicator: librccl unavailable, callback transport stays", file=sys.stderr, flush=True)
+            return
+        idb = (C.c_uint8 * 128)(*vals[:128])
+        rc = lib.mgx_context_set_rccl(h, self.rank, self.size, idb)
+        if rc == 0:
+            rc = lib.mgx_context_use_rccl(h, 0)  # off until verified
+        flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        self.native_ready = int(flag.item()) == 1
+        if not self.native_ready:
+            print("mgx Communicator: RCCL communicator not created on every rank (%s), callback transport stays"
+                  % lib.mgx_last_error().decode(), file=sys.stderr, flush=True)
+
+    def verify_and_enable_native(self, op, n_dofs, number=F64):
+        """One interface exchange and one dot product of a test vector through both transports;
+        the native one is switched on only if every rank finds them bitwise identical."""
+        if not self.native_ready:
+            return False
+        import sys
+        import torch
+        lib, h = self.ctx.lib, self.ctx.h
+        rng = np.random.default_rng(1234 + self.rank)
+        v = rng.uniform(-1, 1, n_dofs).astype(_DT[number])
+        a, b = self.ctx.vector(n_dofs, number, v), self.ctx.vector(n_dofs, number, v)
+        good = True
+        try:
+            check(lib.mgx_exchange_add(op.h, a.ptr))        # callbacks
+            da = self.ctx.dot(a, a)
+            check(lib.mgx_context_use_rccl(h, 1))
+            check(lib.mgx_exchange_add(op.h, b.ptr))        # native
+            db = self.ctx.dot(b, b)
+            good = np.array_equal(a.download(), b.download()) and abs(da - db) <= 1e-12 * abs(da)
+        except Exception as e:  # noqa: BLE001
+            print("mgx Communicator: native RCCL check failed:", repr(e), file=sys.stderr, flush=True)
+            good = False
+        lib.mgx_context_use_rccl(h, 0)
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        self.native_enabled = int(flag.item()) == 1
+        if self.native_enabled:
+            check(lib.mgx_context_use_rccl(h, 1))
+        elif self.rank == 0:
+            print("mgx Communicator: native RCCL transport disagrees with the callback transport, not used",
+                  file=sys.stderr, flush=True)
+        return self.native_enabled
 
     def _alloc(self, user, nbytes):
         """exchange buffers as torch CUDA tensors: RCCL sends from / receives into them directly"""

@@ -80,6 +80,9 @@ SIGNATURES = {
     "mgx_sync": (C.c_int, [vp]),
     "mgx_context_stream": (vp, [vp]),
     "mgx_context_set_comm": (C.c_int, [vp, C.POINTER(CommDesc)]),
+    "mgx_rccl_unique_id": (C.c_int, [vp]),
+    "mgx_context_set_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "mgx_context_use_rccl": (C.c_int, [vp, C.c_int]),
     "mgx_copy_device": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "mgx_operator_exchange_buffers": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(C.c_int)]),
     "mgx_exchange_add": (C.c_int, [vp, vp]),

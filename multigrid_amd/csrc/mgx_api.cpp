@@ -7,6 +7,9 @@
 #include "mgx_internal.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: the library is bound at run time (dlopen), single-GPU users need no RCCL
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -93,6 +96,60 @@ struct ExchangePlan
   void                  *own_buf = nullptr;
 };
 
+// RCCL entry points, bound lazily.  The process may already hold an RCCL (torch bundles one): that
+// instance is reused so that only one RCCL runtime is active.
+struct RcclApi
+{
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId)    GetUniqueId    = nullptr;
+  decltype(&ncclCommInitRank)   CommInitRank   = nullptr;
+  decltype(&ncclCommDestroy)    CommDestroy    = nullptr;
+  decltype(&ncclGroupStart)     GroupStart     = nullptr;
+  decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
+  decltype(&ncclSend)           Send           = nullptr;
+  decltype(&ncclRecv)           Recv           = nullptr;
+  decltype(&ncclAllReduce)      AllReduce      = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool load()
+  {
+    if (lib)
+      return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+      if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)))
+        break;
+    if (!lib)
+      for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+          break;
+    if (!lib)
+      return false;
+#define MGX_RCCL_SYM(name)                                        \
+  name = reinterpret_cast<decltype(name)>(dlsym(lib, "nccl" #name)); \
+  if (!name)                                                      \
+    {                                                             \
+      lib = nullptr;                                              \
+      return false;                                               \
+    }
+    MGX_RCCL_SYM(GetUniqueId)
+    MGX_RCCL_SYM(CommInitRank)
+    MGX_RCCL_SYM(CommDestroy)
+    MGX_RCCL_SYM(GroupStart)
+    MGX_RCCL_SYM(GroupEnd)
+    MGX_RCCL_SYM(Send)
+    MGX_RCCL_SYM(Recv)
+    MGX_RCCL_SYM(AllReduce)
+    MGX_RCCL_SYM(GetErrorString)
+#undef MGX_RCCL_SYM
+    return true;
+  }
+};
+static RcclApi &rccl_api()
+{
+  static RcclApi api;
+  return api;
+}
+
 struct mgx_context_s
 {
   int         device = 0;
@@ -111,6 +168,11 @@ struct mgx_context_s
   // domain decomposition
   bool                                      has_comm = false;
   mgx_comm_desc                             comm{};
+  // native transport: RCCL send/recv and allreduce on `stream`, no host synchronisation
+  ncclComm_t                                nccl = nullptr;
+  bool                                      use_rccl = false;
+  int                                       rccl_rank = 0, rccl_size = 1;
+  double                                   *ar_dev = nullptr; // allreduce scratch (8 doubles)
   std::vector<std::pair<size_t, struct ExchangePlan *>> plans; // (vector length, plan) for dot products
 };
 
@@ -174,6 +236,28 @@ namespace
     return MGX_OK;
   }
 
+  // in-place sum of a few host doubles over the ranks
+  int comm_allreduce(mgx_context_t ctx, double *values, int count)
+  {
+    if (!ctx->has_comm)
+      return MGX_OK;
+    if (ctx->use_rccl)
+      {
+        if (count > 8)
+          return fail(MGX_ERR_INVALID_ARGUMENT, "comm_allreduce: more than 8 values");
+        RcclApi &R = rccl_api();
+        MGX_HIP(hipMemcpyAsync(ctx->ar_dev, values, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+        if (R.AllReduce(ctx->ar_dev, ctx->ar_dev, (size_t)count, ncclDouble, ncclSum, ctx->nccl, ctx->stream) != ncclSuccess)
+          return fail(MGX_ERR_HIP, "ncclAllReduce failed");
+        MGX_HIP(hipMemcpyAsync(values, ctx->ar_dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+        MGX_HIP(hipStreamSynchronize(ctx->stream));
+        return MGX_OK;
+      }
+    if (!ctx->comm.allreduce_sum || ctx->comm.allreduce_sum(ctx->comm.user, values, count) != 0)
+      return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+    return MGX_OK;
+  }
+
   // x.y over the DoFs this rank owns, summed over the ranks (Vector::operator* / l2_norm with
   // MPI_Allreduce in the reference).  The exchange plan is looked up by the vector length.
   int dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *out)
@@ -192,9 +276,7 @@ namespace
           *out -= dup;
           break;
         }
-    if (ctx->comm.allreduce_sum(ctx->comm.user, out, 1) != 0)
-      return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
-    return MGX_OK;
+    return comm_allreduce(ctx, out, 1);
   }
 
   // Vector::compress(add) for duplicated interface DoFs: every rank ends up with the sum of all
@@ -211,10 +293,30 @@ namespace
       launch_pack(s, num, P->send[k], vec, P->index_dev[k], P->count[k]);
     launch_pack(s, num, P->own_buf, vec, P->shared_dev, P->n_shared);
     launch_constrained_set(s, num, vec, 0.0, P->shared_dev, P->n_shared);
-    MGX_HIP(hipStreamSynchronize(s));
-    if (ctx->comm.exchange(ctx->comm.user, P->plan_id, num, (int)P->rank.size(), P->rank.data(), P->count.data(),
-                           P->send.data(), P->recv.data()) != 0)
-      return fail(MGX_ERR_HIP, "exchange callback failed");
+    if (ctx->use_rccl)
+      {
+        // one group of point-to-point operations on the context's stream: ordered after the pack
+        // kernels and before the unpack kernels by the stream itself, the host does not wait
+        RcclApi             &R  = rccl_api();
+        const ncclDataType_t dt = num == MGX_F64 ? ncclDouble : ncclFloat;
+        bool                 ok = R.GroupStart() == ncclSuccess;
+        for (size_t k = 0; ok && k < P->rank.size(); ++k)
+          {
+            ok = ok && R.Send(P->send[k], P->count[k], dt, P->rank[k], ctx->nccl, s) == ncclSuccess;
+            ok = ok && R.Recv(P->recv[k], P->count[k], dt, P->rank[k], ctx->nccl, s) == ncclSuccess;
+          }
+        ok = (R.GroupEnd() == ncclSuccess) && ok;
+        if (!ok)
+          return fail(MGX_ERR_HIP, "RCCL exchange failed");
+      }
+    else
+      {
+        MGX_HIP(hipStreamSynchronize(s));
+        if (!ctx->comm.exchange ||
+            ctx->comm.exchange(ctx->comm.user, P->plan_id, num, (int)P->rank.size(), P->rank.data(),
+                               P->count.data(), P->send.data(), P->recv.data()) != 0)
+          return fail(MGX_ERR_HIP, "exchange callback failed");
+      }
     for (size_t k = 0; k <= P->rank.size(); ++k)
       {
         if ((int)k == P->self_pos)
@@ -389,6 +491,9 @@ int mgx_context_destroy(mgx_context_t ctx)
   (void)hipFree(ctx->partial_dev);
   (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
+  (void)hipFree(ctx->ar_dev);
+  if (ctx->nccl)
+    (void)rccl_api().CommDestroy(ctx->nccl);
   for (auto *pool : {&ctx->ev_pool, &ctx->ev_used})
     for (auto &ev : *pool)
       {
@@ -416,6 +521,56 @@ int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm)
               "mgx_context_set_comm: bad communicator");
   ctx->comm     = *comm;
   ctx->has_comm = comm->size > 1;
+  return MGX_OK;
+}
+
+int mgx_rccl_unique_id(void *id128)
+{
+  MGX_REQUIRE(id128, "mgx_rccl_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == MGX_RCCL_ID_BYTES, "ncclUniqueId size");
+  RcclApi &R = rccl_api();
+  if (!R.load())
+    return fail(MGX_ERR_UNSUPPORTED, "mgx_rccl_unique_id: librccl not found");
+  ncclUniqueId id;
+  if (R.GetUniqueId(&id) != ncclSuccess)
+    return fail(MGX_ERR_HIP, "ncclGetUniqueId failed");
+  std::memcpy(id128, &id, sizeof(id));
+  return MGX_OK;
+}
+
+int mgx_context_set_rccl(mgx_context_t ctx, int rank, int size, const void *id128)
+{
+  MGX_REQUIRE(ctx && id128 && size >= 1 && rank >= 0 && rank < size, "mgx_context_set_rccl: bad argument");
+  MGX_REQUIRE(!ctx->nccl, "mgx_context_set_rccl: communicator already set");
+  RcclApi &R = rccl_api();
+  if (!R.load())
+    return fail(MGX_ERR_UNSUPPORTED, "mgx_context_set_rccl: librccl not found");
+  MGX_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  const ncclResult_t r = R.CommInitRank(&ctx->nccl, size, id, rank);
+  if (r != ncclSuccess)
+    {
+      ctx->nccl = nullptr;
+      return fail(MGX_ERR_HIP, std::string("ncclCommInitRank failed: ") + R.GetErrorString(r));
+    }
+  MGX_HIP(hipMalloc((void **)&ctx->ar_dev, 8 * sizeof(double)));
+  ctx->rccl_rank = rank;
+  ctx->rccl_size = size;
+  ctx->has_comm  = size > 1 || std::getenv("MGX_RCCL_SELFTEST") != nullptr;
+  ctx->use_rccl  = true;
+  return MGX_OK;
+}
+
+int mgx_context_use_rccl(mgx_context_t ctx, int enable)
+{
+  MGX_REQUIRE(ctx, "mgx_context_use_rccl: null context");
+  if (enable)
+    MGX_REQUIRE(ctx->nccl, "mgx_context_use_rccl: no RCCL communicator on this context");
+  else
+    MGX_REQUIRE(ctx->comm.exchange && ctx->comm.allreduce_sum, "mgx_context_use_rccl: no callback transport to fall back to");
+  MGX_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->use_rccl = enable != 0;
   return MGX_OK;
 }
 
@@ -776,14 +931,18 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       P->plan_id = e.plan_id;
       P->number  = d.number;
       const size_t es = number_size(d.number);
+      const int    my_rank = (ctx->nccl && !ctx->comm.exchange) ? ctx->rccl_rank : ctx->comm.rank;
+      // MGX_RCCL_SELFTEST: a one-rank communicator may name itself as neighbour (tools/rccl_selftest.py)
+      const bool   selftest = std::getenv("MGX_RCCL_SELFTEST") != nullptr;
       for (int k = 0; k < e.n_neighbors; ++k)
         {
-          MGX_REQUIRE(e.neighbor_rank[k] != ctx->comm.rank && (k == 0 || e.neighbor_rank[k] > e.neighbor_rank[k - 1]),
+          MGX_REQUIRE(selftest ||
+                        (e.neighbor_rank[k] != my_rank && (k == 0 || e.neighbor_rank[k] > e.neighbor_rank[k - 1])),
                       "mgx_operator_create: neighbour ranks must be ascending and differ from the own rank");
           for (uint32_t i = 0; i < e.count[k]; ++i)
             if (e.index[k][i] >= desc->n_dofs)
               return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: exchange index out of range");
-          if (e.neighbor_rank[k] < ctx->comm.rank)
+          if (e.neighbor_rank[k] < my_rank)
             P->self_pos = k + 1;
           P->rank.push_back(e.neighbor_rank[k]);
           P->count.push_back(e.count[k]);
@@ -1002,8 +1161,7 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
   {
     // deal.II: v_i = (global index of i) mod 11 minus the global mean
     double sc[2] = {op->start_sum, op->start_count};
-    if (ctx->has_comm && ctx->comm.allreduce_sum(ctx->comm.user, sc, 2) != 0)
-      return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+    MGX_TRY(comm_allreduce(ctx, sc, 2));
     launch_index_mod11(s, num, r, op->global_index_dev, sc[0] / sc[1], n);
   }
   MGX_HIP(hipMemsetAsync(x, 0, bytes, s));

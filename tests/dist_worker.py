@@ -5,6 +5,9 @@ mode "host": gloo, CPU only -- exercises the decomposition tables and the exchan
              arrays (the interface sum a rank performs is emulated in numpy).
 mode "gpu" : gloo transport, every rank computes on the (same, single) GPU through the C ABI;
              results are compared with the single-domain CPU oracle on the same global mesh.
+mode "nccl": one rank, backend nccl (= RCCL): the torch transport and the library's own RCCL
+             communicator (mgx_context_set_rccl) live in one process; the native transport is
+             cross-checked and enabled as bench.py does, then the same comparisons as "gpu".
 """
 import os
 import sys
@@ -25,8 +28,12 @@ def main():
     mode, p, nr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     import torch
+    if mode == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import multigrid_amd as mg
     from oracle import Oracle
@@ -78,6 +85,9 @@ def main():
         ctx = mg.Context(0)
         comm = mg.Communicator(ctx, dist)
         solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64, comm=comm)
+        if mode == "nccl":
+            assert comm.native_ready, "library-side RCCL communicator was not created"
+            assert comm.verify_and_enable_native(solver.matrix_dp(l), cube.n_dofs(l))
         # matvec / residual on every level against the oracle on the global mesh
         for lev in range(cube.n_levels):
             g = cube.dof_grid(lev)
@@ -125,7 +135,8 @@ def main():
         assert its == oits, (its, oits)
         l2 = solver.compute_l2_error()
         assert abs(l2 - orc.l2_error()) < 1e-8 * l2
-        print("rank %d gpu ok: FMG L2 %.6e, cg its %d" % (rank, l2, its), flush=True)
+        print("rank %d gpu ok: FMG L2 %.6e, cg its %d%s" % (rank, l2, its, ", native RCCL" if comm.native_enabled else ""),
+              flush=True)
         solver.close()
         ctx.close()
     dist.barrier()
