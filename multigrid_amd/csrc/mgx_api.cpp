@@ -94,6 +94,12 @@ struct ExchangePlan
   uint32_t              *shared_dev = nullptr, *not_owned_dev = nullptr;
   uint32_t               n_shared = 0, n_not_owned = 0;
   void                  *own_buf = nullptr;
+  // fused form: one pack launch over the concatenated lists, one ordered unpack launch over the
+  // interface DoFs (CSR of their contributions in ascending rank order, 255 = the rank's own sum)
+  std::vector<uint32_t>  start;              // [n_neighbors + 1] offsets into the concatenation
+  uint32_t              *all_index_dev = nullptr, *csr_start_dev = nullptr, *csr_pos_dev = nullptr;
+  uint8_t               *all_seg_dev = nullptr, *csr_k_dev = nullptr;
+  bool                   fused = false;
 };
 
 // RCCL entry points, bound lazily.  The process may already hold an RCCL (torch bundles one): that
@@ -289,10 +295,16 @@ namespace
     mgx_context_t ctx = op->ctx;
     hipStream_t   s   = ctx->stream;
     const int     num = op->d.number;
-    for (size_t k = 0; k < P->rank.size(); ++k)
-      launch_pack(s, num, P->send[k], vec, P->index_dev[k], P->count[k]);
-    launch_pack(s, num, P->own_buf, vec, P->shared_dev, P->n_shared);
-    launch_constrained_set(s, num, vec, 0.0, P->shared_dev, P->n_shared);
+    if (P->fused)
+      launch_pack_all(s, num, P->send.data(), P->start.data(), (int)P->rank.size(), vec, P->all_index_dev,
+                      P->all_seg_dev, P->start.back());
+    else
+      {
+        for (size_t k = 0; k < P->rank.size(); ++k)
+          launch_pack(s, num, P->send[k], vec, P->index_dev[k], P->count[k]);
+        launch_pack(s, num, P->own_buf, vec, P->shared_dev, P->n_shared);
+        launch_constrained_set(s, num, vec, 0.0, P->shared_dev, P->n_shared);
+      }
     if (ctx->use_rccl)
       {
         // one group of point-to-point operations on the context's stream: ordered after the pack
@@ -317,13 +329,17 @@ namespace
                                P->count.data(), P->send.data(), P->recv.data()) != 0)
           return fail(MGX_ERR_HIP, "exchange callback failed");
       }
-    for (size_t k = 0; k <= P->rank.size(); ++k)
-      {
-        if ((int)k == P->self_pos)
-          launch_unpack_add(s, num, vec, P->own_buf, P->shared_dev, P->n_shared);
-        if (k < P->rank.size())
-          launch_unpack_add(s, num, vec, P->recv[k], P->index_dev[k], P->count[k]);
-      }
+    if (P->fused)
+      launch_unpack_ordered(s, num, P->recv.data(), (int)P->rank.size(), vec, P->shared_dev, P->csr_start_dev,
+                            P->csr_k_dev, P->csr_pos_dev, P->n_shared);
+    else
+      for (size_t k = 0; k <= P->rank.size(); ++k)
+        {
+          if ((int)k == P->self_pos)
+            launch_unpack_add(s, num, vec, P->own_buf, P->shared_dev, P->n_shared);
+          if (k < P->rank.size())
+            launch_unpack_add(s, num, vec, P->recv[k], P->index_dev[k], P->count[k]);
+        }
     MGX_HIP(hipGetLastError());
     return MGX_OK;
   }
@@ -980,6 +996,71 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
         MGX_HIP(hipMemcpy(P->shared_dev, e.shared, sizeof(uint32_t) * e.n_shared, hipMemcpyHostToDevice));
       if (e.n_not_owned)
         MGX_HIP(hipMemcpy(P->not_owned_dev, e.not_owned, sizeof(uint32_t) * e.n_not_owned, hipMemcpyHostToDevice));
+      // fused pack / ordered unpack tables
+      if (e.n_neighbors <= 32 && e.n_neighbors < 255 && !std::getenv("MGX_EXCHANGE_UNFUSED"))
+        {
+          P->start.assign(e.n_neighbors + 1, 0);
+          for (int k = 0; k < e.n_neighbors; ++k)
+            P->start[k + 1] = P->start[k] + e.count[k];
+          const uint32_t        total = P->start.back();
+          std::vector<uint32_t> all_index(total + 1, 0);
+          std::vector<uint8_t>  all_seg(total + 1, 0);
+          for (int k = 0; k < e.n_neighbors; ++k)
+            for (uint32_t i = 0; i < e.count[k]; ++i)
+              {
+                all_index[P->start[k] + i] = e.index[k][i];
+                all_seg[P->start[k] + i]   = (uint8_t)k;
+              }
+          // contributions per interface DoF in ascending rank order, own sum at self_pos
+          std::vector<uint32_t> slot(desc->n_dofs, MGX_INVALID_INDEX);
+          for (uint32_t j = 0; j < e.n_shared; ++j)
+            slot[e.shared[j]] = j;
+          std::vector<uint32_t> cnt(e.n_shared + 1, 0);
+          bool                  ok = true;
+          for (int k = 0; k < e.n_neighbors && ok; ++k)
+            for (uint32_t i = 0; i < e.count[k]; ++i)
+              {
+                const uint32_t j = slot[e.index[k][i]];
+                if (j == MGX_INVALID_INDEX)
+                  {
+                    ok = false; // an exchanged DoF that is not in the shared list: keep the plain form
+                    break;
+                  }
+                cnt[j]++;
+              }
+          if (ok)
+            {
+              std::vector<uint32_t> cs(e.n_shared + 1, 0);
+              for (uint32_t j = 0; j < e.n_shared; ++j)
+                cs[j + 1] = cs[j] + cnt[j] + 1;
+              std::vector<uint8_t>  ck(cs.back() + 1, 0);
+              std::vector<uint32_t> cp(cs.back() + 1, 0), fill(cs.begin(), cs.end() - 1);
+              for (int k = 0; k <= e.n_neighbors; ++k)
+                {
+                  if (k == P->self_pos)
+                    for (uint32_t j = 0; j < e.n_shared; ++j)
+                      ck[fill[j]++] = 255;
+                  if (k < e.n_neighbors)
+                    for (uint32_t i = 0; i < e.count[k]; ++i)
+                      {
+                        const uint32_t j = slot[e.index[k][i]];
+                        ck[fill[j]]   = (uint8_t)k;
+                        cp[fill[j]++] = i;
+                      }
+                }
+              MGX_HIP(hipMalloc((void **)&P->all_index_dev, sizeof(uint32_t) * all_index.size()));
+              MGX_HIP(hipMalloc((void **)&P->all_seg_dev, all_seg.size()));
+              MGX_HIP(hipMalloc((void **)&P->csr_start_dev, sizeof(uint32_t) * cs.size()));
+              MGX_HIP(hipMalloc((void **)&P->csr_k_dev, ck.size()));
+              MGX_HIP(hipMalloc((void **)&P->csr_pos_dev, sizeof(uint32_t) * cp.size()));
+              MGX_HIP(hipMemcpy(P->all_index_dev, all_index.data(), sizeof(uint32_t) * all_index.size(), hipMemcpyHostToDevice));
+              MGX_HIP(hipMemcpy(P->all_seg_dev, all_seg.data(), all_seg.size(), hipMemcpyHostToDevice));
+              MGX_HIP(hipMemcpy(P->csr_start_dev, cs.data(), sizeof(uint32_t) * cs.size(), hipMemcpyHostToDevice));
+              MGX_HIP(hipMemcpy(P->csr_k_dev, ck.data(), ck.size(), hipMemcpyHostToDevice));
+              MGX_HIP(hipMemcpy(P->csr_pos_dev, cp.data(), sizeof(uint32_t) * cp.size(), hipMemcpyHostToDevice));
+              P->fused = true;
+            }
+        }
       ctx->plans.push_back({(size_t)desc->n_dofs, P.get()});
       op->plan = std::move(P);
     }
@@ -1038,6 +1119,11 @@ int mgx_operator_destroy(mgx_operator_t op)
       (void)hipFree(P->shared_dev);
       (void)hipFree(P->not_owned_dev);
       (void)hipFree(P->own_buf);
+      (void)hipFree(P->all_index_dev);
+      (void)hipFree(P->all_seg_dev);
+      (void)hipFree(P->csr_start_dev);
+      (void)hipFree(P->csr_k_dev);
+      (void)hipFree(P->csr_pos_dev);
     }
   delete op;
   return MGX_OK;

@@ -144,6 +144,11 @@ namespace mgx
                                const void *ax = nullptr, const void *old = nullptr, double f0 = 0.);
   // interface exchange helpers
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
+  void launch_pack_all(hipStream_t s, int number, void *const *send, const uint32_t *start, int n_neighbors,
+                       const void *v, const uint32_t *index, const uint8_t *seg, uint32_t total);
+  void launch_unpack_ordered(hipStream_t s, int number, void *const *recv, int n_neighbors, void *v,
+                             const uint32_t *shared, const uint32_t *csr_start, const uint8_t *csr_k,
+                             const uint32_t *csr_pos, uint32_t n_shared);
   void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count);
   void launch_list_residual(hipStream_t s, int number, void *res, const void *rhs, const uint32_t *list,
                             uint32_t count); // res[i] = rhs[i] - res[i]

@@ -154,6 +154,44 @@ namespace mgx
     GRID_STRIDE(i, count) buf[i] = v[list[i]];
   }
 
+  // all neighbours in one launch: entry e of the concatenated lists goes to send buffer seg[e]
+  struct ExchangePtrs
+  {
+    void    *buf[32];
+    uint32_t start[33];
+  };
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_pack_all(ExchangePtrs p, const T *__restrict__ v, const uint32_t *__restrict__ index,
+               const uint8_t *__restrict__ seg, uint32_t total)
+  {
+    GRID_STRIDE(e, total)
+    {
+      const uint32_t k                 = seg[e];
+      ((T *)p.buf[k])[e - p.start[k]] = v[index[e]];
+    }
+  }
+  // one thread per interface DoF: its own partial sum and the neighbours' contributions are added
+  // in ascending rank order (identical on every rank that holds the DoF => bitwise equal copies)
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_unpack_ordered(ExchangePtrs p, T *__restrict__ v, const uint32_t *__restrict__ shared,
+                     const uint32_t *__restrict__ csr_start, const uint8_t *__restrict__ csr_k,
+                     const uint32_t *__restrict__ csr_pos, uint32_t n_shared)
+  {
+    GRID_STRIDE(j, n_shared)
+    {
+      const uint32_t dof = shared[j];
+      T              sum = T(0);
+      for (uint32_t c = csr_start[j]; c < csr_start[j + 1]; ++c)
+        {
+          const uint32_t k = csr_k[c];
+          sum += k == 255u ? v[dof] : ((const T *)p.buf[k])[csr_pos[c]];
+        }
+      v[dof] = sum;
+    }
+  }
+
   template <typename T>
   __global__ void __launch_bounds__(256)
     k_unpack_add(T *__restrict__ v, const T *__restrict__ buf, const uint32_t *__restrict__ list, uint32_t count)
@@ -437,6 +475,34 @@ namespace mgx
       return;
     BY_NUMBER(number, hipLaunchKernelGGL((k_pack<T>), stream_grid(count), dim3(256), 0, s, (T *)buf, (const T *)v,
                                          list, count));
+  }
+
+  void launch_pack_all(hipStream_t s, int number, void *const *send, const uint32_t *start, int n_neighbors,
+                       const void *v, const uint32_t *index, const uint8_t *seg, uint32_t total)
+  {
+    if (total == 0)
+      return;
+    ExchangePtrs p{};
+    for (int k = 0; k < n_neighbors; ++k)
+      {
+        p.buf[k]   = send[k];
+        p.start[k] = start[k];
+      }
+    BY_NUMBER(number, hipLaunchKernelGGL((k_pack_all<T>), stream_grid(total), dim3(256), 0, s, p, (const T *)v, index,
+                                         seg, total));
+  }
+
+  void launch_unpack_ordered(hipStream_t s, int number, void *const *recv, int n_neighbors, void *v,
+                             const uint32_t *shared, const uint32_t *csr_start, const uint8_t *csr_k,
+                             const uint32_t *csr_pos, uint32_t n_shared)
+  {
+    if (n_shared == 0)
+      return;
+    ExchangePtrs p{};
+    for (int k = 0; k < n_neighbors; ++k)
+      p.buf[k] = recv[k];
+    BY_NUMBER(number, hipLaunchKernelGGL((k_unpack_ordered<T>), stream_grid(n_shared), dim3(256), 0, s, p, (T *)v,
+                                         shared, csr_start, csr_k, csr_pos, n_shared));
   }
 
   void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count)
