@@ -29,7 +29,8 @@ namespace mgx
   // children of one parent), so that the (NB p + 1)^3 fp64 accumulator stays below 55 kB of LDS.
   // p <= 4: a cell needs (p+1)^2 <= 25 threads, a wave owns two cells of a round, four waves
   // process the 8 same-parity cells of a round.  p >= 5: the 8 cells of a brick are mutually
-  // adjacent, so a round is one cell on (p+1)^2 threads (one or two waves).
+  // adjacent; two of them are integrated side by side on (p+1)^2 threads each (one or two waves
+  // per cell) and added to the accumulator one after the other (fixed order: deterministic).
   template <int P>
   struct BCfg
   {
@@ -42,9 +43,11 @@ namespace mgx
     static constexpr int  NE         = NE1 * NE1 * NE1;
     static constexpr int  TPC        = N * N;
     static constexpr bool kTwoPerWave = P <= 4;        // two cells per wave, 8 cells per round
-    static constexpr int  ROUND_CELLS = kTwoPerWave ? 8 : 1;
-    static constexpr int  THREADS    = kTwoPerWave ? 256 : ((TPC + 63) / 64) * 64;
-    static constexpr bool kWaveSync  = kTwoPerWave || THREADS == 64; // transposes stay inside one wave
+    static constexpr int  TPW        = kTwoPerWave ? 32 : ((TPC + 63) / 64) * 64; // threads reserved per cell
+    static constexpr int  ROUND_CELLS = kTwoPerWave ? 8 : 2;
+    static constexpr int  ROUNDS     = NCELLS / ROUND_CELLS;
+    static constexpr int  THREADS    = kTwoPerWave ? 256 : 2 * TPW;
+    static constexpr bool kWaveSync  = kTwoPerWave || TPW == 64; // transposes stay inside one wave
     static constexpr int  CELL_LDS   = N * N * LN;
   };
 
@@ -640,11 +643,11 @@ namespace mgx
       acc[i] = T(0);
 
     // p <= 4: lanes [0,TPC) and [32,32+TPC) of each wave own the two cells of that wave;
-    // p >= 5: the workgroup owns one cell per round
+    // p >= 5: each half of the workgroup owns one cell per round
     const int  lane    = tid & 63;
-    const int  t       = C::kTwoPerWave ? (lane & 31) : tid;
+    const int  t       = C::kTwoPerWave ? (lane & 31) : tid % C::TPW;
     const bool compute = t < C::TPC;
-    const int  lc      = C::kTwoPerWave ? 2 * (tid >> 6) + (lane >> 5) : 0;
+    const int  lc      = C::kTwoPerWave ? 2 * (tid >> 6) + (lane >> 5) : tid / C::TPW;
     const int  a       = compute ? t % N : 0;
     const int  b       = compute ? t / N : 0;
     T         *Uc      = U + lc * C::CELL_LDS;
@@ -656,6 +659,23 @@ namespace mgx
     const uint32_t loff = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
     const int hx = 2 * (lc & 1), hy = 2 * ((lc >> 1) & 1), hz = 2 * (lc >> 2);
     const EOMat<T> &M = B->mass, &K = B->lapl;
+    // cell of this thread in a round: p <= 4 the same-parity cell of its 2x2x2 octant, p >= 5 cell
+    // 2 round + lc of the 2x2x2 brick
+    auto cell_of = [&](int round, int &bx, int &by, int &bz) {
+      if (C::kTwoPerWave)
+        {
+          bx = hx + (round & 1);
+          by = hy + ((round >> 1) & 1);
+          bz = hz + (round >> 2);
+        }
+      else
+        {
+          const int m = 2 * round + lc;
+          bx          = m & 1;
+          by          = (m >> 1) & 1;
+          bz          = m >> 2;
+        }
+    };
     // ordering of the LDS transposes: inside one wave a compiler barrier is enough, a cell spread
     // over two waves needs the workgroup barrier
     auto phase_sync = [&]() {
@@ -670,7 +690,8 @@ namespace mgx
     // unrolling the round loop by two): an HBM miss takes about as long as one round
     constexpr int ND = MODE == kChebInit ? N : 1; // kChebInit gathers two operands per value
     auto gather = [&](int round, T(&r)[N], T(&d)[ND], uint32_t &nvalid) {
-      const int       bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
+      int bx, by, bz;
+      cell_of(round, bx, by, bz);
       const uint32_t *eb = ebase + ((2 * bz + cz) * E1 + (2 * by + cy)) * E1 + 2 * bx;
       const uint32_t  b0 = eb[0], b1 = eb[1], b2 = eb[2];
       nvalid = (b0 != kInvalid ? 1u : 0u) | (b1 != kInvalid ? 2u : 0u) | (b2 != kInvalid ? 4u : 0u);
@@ -710,7 +731,7 @@ namespace mgx
         for (int i = 1; i < P; ++i)
           r[i] = (nvalid & 2u) ? rn[i] : T(0);
         r[P] = (nvalid & 4u) ? rn[P] : T(0);
-        if (round < 6)
+        if (round + 2 < C::ROUNDS)
           gather(round + 2, rn, dn, nvalid); // this register set is free again: refill it
         // x: t1 = M u, k1 = K u
         eo_split<N, T>(r, xe, xo);
@@ -784,20 +805,35 @@ namespace mgx
             if (r[0] == T(12345.678))
               acc[tid] = r[1]; // keep the sweeps alive
           }
-        else if (compute)
+        else
           {
-            // thread (i = a, j = b) owns the z-line: accumulate the column of the brick array
-            const int bx = hx + (round & 1), by = hy + ((round >> 1) & 1), bz = hz + (round >> 2);
-            T        *col = acc + ((bz * P) * G + (by * P + b)) * G + bx * P + a;
+            // thread (i = a, j = b) owns the z-line: accumulate the column of the brick array.
+            // p >= 5: the two cells of the round touch, the second half adds after the first
+            int bx, by, bz;
+            cell_of(round, bx, by, bz);
+            T *col = acc + ((bz * P) * G + (by * P + b)) * G + bx * P + a;
+            if (compute && (C::kTwoPerWave || lc == 0))
+              {
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-              col[i * G * G] += r[i];
+                for (int i = 0; i < N; ++i)
+                  col[i * G * G] += r[i];
+              }
+            if (!C::kTwoPerWave)
+              {
+                lds_barrier();
+                if (compute && lc == 1)
+                  {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                      col[i * G * G] += r[i];
+                  }
+              }
           }
     };
     if (MODE != kNoCompute && MODE != kInitOnly)
       {
 #pragma unroll 1
-        for (int round = 0; round < 8; round += 2)
+        for (int round = 0; round < C::ROUNDS; round += 2)
           {
             one_round(round, rA, dA, vA);
             one_round(round + 1, rB, dB, vB);
