@@ -161,7 +161,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {form: ctx.profile_read(form) for form in range(7)}
+    prof = {form: ctx.profile_read(form) for form in range(8)}
     ctx.profile_enable(False)
     if dist is not None:
         import torch
@@ -185,15 +185,16 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     total_dofs = global_dofs
     # Roofline of the dominant kernel.  A step runs 7 finest-level cell loops: the plain matvec
-    # (form 0, 16 B/DoF algorithmic), the residual (form 1), and 5 Chebyshev
+    # (form 0, 16 B/DoF algorithmic), the residual fused with the restriction (form 7:
+    # x, b read, coarse sums read+written = 16 + 2 B/DoF; form 1 is the plain residual), and 5 Chebyshev
     # iterations -- post-smoothing: first step (form 3) + 2 full iterations (form 2: x, x_old, b,
     # D^-1 read + x_new written = 5 accesses = 40 B/DoF, the reference's own 5-access model,
     # matvec_dg_cheby/program.cc:178); pre-smoothing from a zero guess: forms 5 and 6, which
     # recompute x_1 = D^-1 b / theta instead of storing it.  Form 2 has the most launches and the
     # most traffic.  One application = n_colours launches, each over n_dofs / n_colours DoFs.
-    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0, 5: 24.0, 6: 32.0}
+    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0, 5: 24.0, 6: 32.0, 7: 18.0}
     NAMES = {0: "kPlain", 1: "kResidual", 2: "kCheb", 3: "kChebFirst", 4: "kChebZeroOld", 5: "kChebInit",
-             6: "kChebOldInit"}
+             6: "kChebOldInit", 7: "kResidualRestrict"}
 
     def roof(form):
         launches, ms = prof[form]

@@ -129,7 +129,8 @@ int mgx_profile_enable(mgx_context_t ctx, int enable);
  * (40 B/DoF: x, x_old, b, D^-1 read, x_new written), 3 first Chebyshev step (32 B/DoF),
  * 4 Chebyshev iteration with zero x_old (32 B/DoF), 5 first iteration after a zero guess with
  * x_1 = D^-1 b / theta formed on the fly (24 B/DoF), 6 second such iteration, x_old = x_1 formed
- * on the fly (32 B/DoF).  One bracket spans the colour launches of
+ * on the fly (32 B/DoF), 7 V-cycle residual fused with the restriction to the next coarser level
+ * (18 B/DoF).  One bracket spans the colour launches of
  * one application (8 on a structured mesh); `launches` counts the individual kernel launches. */
 int mgx_profile_read(mgx_context_t ctx, int form, uint64_t *launches, double *total_ms);
 

@@ -900,6 +900,7 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
           BrickData &b = d.bricks;
           b.n_bricks   = bh.n_bricks;
           b.n_colours  = bh.n_colours;
+          b.order      = bh.order;
           for (int c = 0; c <= bh.n_colours; ++c)
             b.colour_start[c] = bh.colour_start[c];
           // device table word: bits 0..29 first DoF, bit 30 FIRST, bit 31 LAST (mgx_brick.hip)
@@ -1667,18 +1668,86 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
           MGX_TRACE("transfer_create: children patches inconsistent, first-version kernels used");
       }
   }
-  // 1D prolongation matrix into the coarse operator's basis block
+  // 1D prolongation matrix into the basis blocks of both operators (the transfer kernels read the
+  // coarse one, the fused residual + restriction of the fine level's cell loop the fine one)
   const size_t np1 = (size_t)(2 * p + 1) * n;
-  if (coarse->d.number == MGX_F64)
+  for (mgx_operator_t o : {coarse, fine})
     {
-      MGX_HIP(hipMemcpy((char *)coarse->d.basis + offsetof(Basis1D<double>, P1), desc->prolong_1d,
-                        sizeof(double) * np1, hipMemcpyHostToDevice));
+      if (o->d.number == MGX_F64)
+        {
+          MGX_HIP(hipMemcpy((char *)o->d.basis + offsetof(Basis1D<double>, P1), desc->prolong_1d,
+                            sizeof(double) * np1, hipMemcpyHostToDevice));
+        }
+      else
+        {
+          std::vector<float> pf(desc->prolong_1d, desc->prolong_1d + np1);
+          MGX_HIP(hipMemcpy((char *)o->d.basis + offsetof(Basis1D<float>, P1), pf.data(), sizeof(float) * np1,
+                            hipMemcpyHostToDevice));
+        }
     }
-  else
+  // Fused residual + restriction (mgx_brick.hip, mode 7): needs the fine level on the brick
+  // schedule in its separable form, children in forest order (cell c is child c % 8 of parent
+  // c / 8, so that a brick's cells are the children of PB^3 sibling parents) and a single rank.
+  if (fine->d.bricks.available() && fine->d.separable && !fine->plan && !coarse->plan &&
+      !std::getenv("MGX_NO_FUSED_RESTRICT"))
     {
-      std::vector<float> pf(desc->prolong_1d, desc->prolong_1d + np1);
-      MGX_HIP(hipMemcpy((char *)coarse->d.basis + offsetof(Basis1D<float>, P1), pf.data(), sizeof(float) * np1,
-                        hipMemcpyHostToDevice));
+      bool forest = true;
+      for (size_t i = 0; i < 8 * (size_t)npar && forest; ++i)
+        forest = desc->children[i] == (uint32_t)i;
+      const int      PB = p <= 4 ? 2 : 1, CE1 = 2 * PB + 1, CE3 = CE1 * CE1 * CE1;
+      const uint32_t nb = fine->d.bricks.n_bricks, ppb = PB * PB * PB; // parents per brick
+      if (forest && (uint64_t)nb * ppb == npar && fine->d.bricks.order.size() == nb)
+        {
+          std::vector<uint32_t> idxc(27 * (size_t)npar);
+          MGX_HIP(hipMemcpy(idxc.data(), coarse->d.idx27, sizeof(uint32_t) * idxc.size(), hipMemcpyDeviceToHost));
+          std::vector<uint32_t> idxp(27 * (size_t)npar);
+          MGX_HIP(hipMemcpy(idxp.data(), coarse->d.idx27_plain, sizeof(uint32_t) * idxp.size(), hipMemcpyDeviceToHost));
+          std::vector<uint32_t> tab((size_t)nb * CE3);
+          bool                  consistent = true;
+          for (uint32_t sb = 0; sb < nb; ++sb)
+            {
+              const uint32_t b = fine->d.bricks.order[sb]; // brick in cell order: parents ppb*b ...
+              for (int e = 0; e < CE3; ++e)
+                {
+                  const int el[3] = {e % CE1, (e / CE1) % CE1, e / (CE1 * CE1)};
+                  int       nopt[3], bit[3][2], code[3][2];
+                  for (int d = 0; d < 3; ++d)
+                    {
+                      // entity layer el of PB parents in a row: parent el/2 (last layer: the previous
+                      // parent's high side); the layer between two parents is seen from both
+                      nopt[d]    = (PB == 2 && el[d] == 2) ? 2 : 1;
+                      bit[d][0]  = (PB == 2 && el[d] > 2) ? 1 : 0;
+                      code[d][0] = el[d] - 2 * bit[d][0];
+                      bit[d][1]  = 1;
+                      code[d][1] = 0;
+                    }
+                  uint32_t word = 0, key = 0;
+                  bool     first = true;
+                  for (int oz = 0; oz < nopt[2]; ++oz)
+                    for (int oy = 0; oy < nopt[1]; ++oy)
+                      for (int ox = 0; ox < nopt[0]; ++ox)
+                        {
+                          const int      q  = bit[0][ox] | (bit[1][oy] << 1) | (bit[2][oz] << 2);
+                          const int      ce = (code[2][oz] * 3 + code[1][oy]) * 3 + code[0][ox];
+                          const uint32_t pc = ppb * b + (uint32_t)q;
+                          if (first)
+                            {
+                              word = idxc[27 * (size_t)pc + ce];
+                              key  = idxp[27 * (size_t)pc + ce];
+                            }
+                          else if (idxp[27 * (size_t)pc + ce] != key)
+                            consistent = false;
+                          first = false;
+                        }
+                  tab[(size_t)sb * CE3 + e] = word;
+                }
+            }
+          if (consistent)
+            {
+              MGX_HIP(hipMalloc((void **)&tr->d.coarse_blocks, sizeof(uint32_t) * tab.size()));
+              MGX_HIP(hipMemcpy(tr->d.coarse_blocks, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
+            }
+        }
     }
   *out = tr.release();
   return MGX_OK;
@@ -1693,6 +1762,7 @@ int mgx_transfer_destroy(mgx_transfer_t tr)
   (void)hipFree(tr->d.weight_shift);
   (void)hipFree(tr->d.own27);
   (void)hipFree(tr->d.patch);
+  (void)hipFree(tr->d.coarse_blocks);
   (void)hipFree(tr->scratch);
   delete tr;
   return MGX_OK;
@@ -1947,15 +2017,29 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
         else
           MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true));
       }
-      {
-        Stopwatch sw(S, level, 0);
-        MGX_TRY(mgx_vmult_residual(S->matrix[level], S->defect[level], S->solution_update[level], S->t[level])); // :663
-      }
-      {
-        Stopwatch sw(S, level, 1);
-        MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s));         // :667
-        MGX_TRY(mgx_restrict_and_add(S->transfer[level], S->defect[level - 1], S->t[level], 1)); // :668
-      }
+      if (S->transfer[level]->d.coarse_blocks)
+        {
+          // residual and restriction in one pass of the cell loop: t only carries the partial sums
+          // of brick-surface DoFs between the colour launches, the residual is never stored
+          Stopwatch      sw(S, level, 0);
+          mgx_operator_t A = S->matrix[level];
+          MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s)); // :667
+          ProfileBracket pb(A, 7);
+          launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level],
+                            0., 0., nullptr, 0., S->defect[level - 1], S->transfer[level]->d.coarse_blocks);
+        }
+      else
+        {
+          {
+            Stopwatch sw(S, level, 0);
+            MGX_TRY(mgx_vmult_residual(S->matrix[level], S->defect[level], S->solution_update[level], S->t[level])); // :663
+          }
+          {
+            Stopwatch sw(S, level, 1);
+            MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s));         // :667
+            MGX_TRY(mgx_restrict_and_add(S->transfer[level], S->defect[level - 1], S->t[level], 1)); // :668
+          }
+        }
       MGX_TRY(v_cycle(S, level - 1, 1)); // :671
       {
         Stopwatch sw(S, level, 2);

@@ -92,6 +92,11 @@ namespace mgx
     // the second one recomputes it as its x_old (kChebOldInit); separable kernel only
     kChebInit    = 5, // x := f0 b a ; out = x + f1 x + f2 b (a - A x)
     kChebOldInit = 6, // out = x + f1 (x - f0 b a) + f2 b (a - A x)
+    // V-cycle: the residual a - A x is only needed restricted to the next coarser level
+    // (multigrid_solver.h:663-668).  Every brick restricts the residual values it completes (its
+    // LAST points, everything else masked to zero) with the transposed embedding and adds the
+    // (PB p + 1)^3 coarse values to the coarse vector; the residual itself is never stored.
+    kResidualRestrict = 7,
     // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
     kNoStore   = 8, // rounds only, no write-out
     kNoCompute = 9, // write-out only, no rounds
@@ -109,6 +114,8 @@ namespace mgx
     T       *out;     // result vector
     T       *partial; // carrier of partial sums between colour launches (may alias out)
     T        f1, f2, f0;
+    T              *coarse;        // kResidualRestrict: coarse-level vector the restriction adds to
+    const uint32_t *coarse_blocks; // kResidualRestrict: coarse entity table of the brick's parents
   };
 
 
@@ -140,7 +147,7 @@ namespace mgx
     const T        pv           = post.partial[ip];
     if (MODE == kPlain || MODE == kNoCompute)
       return need_partial ? val + pv : val;
-    else if (MODE == kResidual)
+    else if (MODE == kResidual || MODE == kResidualRestrict)
       {
         const T av = post.a[il];
         val        = need_partial ? val + pv : val;
@@ -338,14 +345,151 @@ namespace mgx
         uint32_t off;
         item_a(it, e, pnt, off);
         const uint32_t w = kKeepA ? wa[it] : ebase[e];
-        if (w != kInvalid)
+        if (MODE == kResidualRestrict)
+          {
+            // completed residuals stay in the accumulator for the restriction; partial sums go to
+            // the carrier; everything that is not a completed residual becomes zero
+            if (w == kInvalid)
+              acc[pnt] = T(0);
+            else if (!(w >> 31))
+              {
+                post.partial[ent_index(w) + off] = acc[pnt];
+                acc[pnt]                         = T(0);
+              }
+          }
+        else if (w != kInvalid)
           ((w >> 31) ? post.out : post.partial)[ent_index(w) + off] = acc[pnt];
       }
 #pragma unroll
     for (int it = 0; it < ITB; ++it)
-      if (wb[it] != kInvalid)
-        ((wb[it] >> 31) ? post.out : post.partial)[ib[it]] = acc[pb[it]];
+      {
+        if (MODE == kResidualRestrict)
+          {
+            if (tid + it * C::THREADS < NBF)
+              {
+                if (wb[it] == kInvalid)
+                  acc[pb[it]] = T(0);
+                else if (!(wb[it] >> 31))
+                  {
+                    post.partial[ib[it]] = acc[pb[it]];
+                    acc[pb[it]]          = T(0);
+                  }
+              }
+          }
+        else if (wb[it] != kInvalid)
+          ((wb[it] >> 31) ? post.out : post.partial)[ib[it]] = acc[pb[it]];
+      }
   }
+
+  // ------------------------------------------------------------------------------------------
+  // Restriction of the brick array in place (kResidualRestrict).  acc holds the G^3 fine values of
+  // the brick (G = NB p + 1) whose cells are the children of PB^3 parents (PB = NB / 2): three 1D
+  // sweeps with the transposed embedding P1 (one line per thread, values in registers, outputs
+  // written over the head of the line), then the (PB p + 1)^3 coarse values are added to the
+  // coarse vector through the coarse entity table of the brick.  Bricks of one colour launch are
+  // not adjacent, so their parents share no coarse DoF: plain read-modify-write.
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T>
+  __device__ __forceinline__ void restrict_line(const T *__restrict__ p1, const T (&r)[BCfg<P>::G],
+                                                T (&out)[(BCfg<P>::NB / 2) * P + 1])
+  {
+    constexpr int N = P + 1, M = 2 * P + 1, PB = BCfg<P>::NB / 2;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+      {
+        T o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          {
+            T s = p1[j] * r[pb * 2 * P];
+#pragma unroll
+            for (int a = 1; a < M; ++a)
+              s = fma(p1[a * N + j], r[pb * 2 * P + a], s);
+            o[j] = s;
+          }
+        if (pb == 0)
+          {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              out[j] = o[j];
+          }
+        else
+          {
+            // the node shared by the two parents was counted by both (unit weight in each)
+            out[pb * P] += o[0] - r[pb * 2 * P];
+#pragma unroll
+            for (int j = 1; j < N; ++j)
+              out[pb * P + j] = o[j];
+          }
+      }
+  }
+
+  template <int P, typename T>
+  __device__ __forceinline__ void restrict_brick(int tid, T *acc, const T *__restrict__ p1, T *__restrict__ coarse,
+                                                 const uint32_t *__restrict__ ctab)
+  {
+    using C           = BCfg<P>;
+    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1;
+    // x: lines (y, z)
+    for (int l = tid; l < G * G; l += C::THREADS)
+      {
+        T r[G], o[CN];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          r[i] = acc[l * G + i];
+        restrict_line<P, T>(p1, r, o);
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          acc[l * G + j] = o[j];
+      }
+    __syncthreads();
+    // y: lines (x < CN, z)
+    for (int l = tid; l < CN * G; l += C::THREADS)
+      {
+        const int x = l % CN, z = l / CN;
+        T         r[G], o[CN];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          r[i] = acc[(z * G + i) * G + x];
+        restrict_line<P, T>(p1, r, o);
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          acc[(z * G + j) * G + x] = o[j];
+      }
+    __syncthreads();
+    // z: lines (x, y) with x, y < CN; the results go to the coarse vector
+    auto layer = [](int a, int &e, int &o, int &n) {
+      const int q = a / P, rr = a - q * P;
+      e           = 2 * q + (rr != 0);
+      o           = rr ? rr - 1 : 0;
+      n           = rr ? P - 1 : 1;
+    };
+    for (int l = tid; l < CN * CN; l += C::THREADS)
+      {
+        const int x = l % CN, y = l / CN;
+        T         r[G], o[CN];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          r[i] = acc[(i * G + y) * G + x];
+        restrict_line<P, T>(p1, r, o);
+        int ex, ey, ox, oy, nx, ny;
+        layer(x, ex, ox, nx);
+        layer(y, ey, oy, ny);
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          {
+            int ez, oz, nz;
+            layer(j, ez, oz, nz);
+            const uint32_t w = ctab[(ez * CE1 + ey) * CE1 + ex];
+            if (w != kInvalid)
+              {
+                T *c = coarse + w + (uint32_t)((oz * ny + oy) * nx + ox);
+                *c += o[j];
+              }
+          }
+      }
+  }
+
 
   // wave-local ordering of LDS traffic: the two cells of a wave exchange data only among the
   // lanes of that wave, which execute in lockstep; the LDS services one wave's operations in
@@ -848,6 +992,12 @@ namespace mgx
         return;
       }
     store_brick<P, T, MODE>(tid, acc, ebase, src, post);
+    if (MODE == kResidualRestrict)
+      {
+        constexpr int CE1 = C::NB + 1; // 2 PB + 1
+        __syncthreads();
+        restrict_brick<P, T>(tid, acc, B->P1, post.coarse, post.coarse_blocks + (size_t)brick * (CE1 * CE1 * CE1));
+      }
   }
 
   // ------------------------------------------------------------------------------------------
@@ -865,7 +1015,7 @@ namespace mgx
           hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
                              bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
                              (T)op.coef[2], post);
-        else if constexpr (P <= 4 && MODE != kChebInit && MODE != kChebOldInit) // quadrature-point form: 4x4x4 bricks only
+        else if constexpr (P <= 4 && MODE != kChebInit && MODE != kChebOldInit && MODE != kResidualRestrict) // quadrature-point form: 4x4x4 bricks only
           hipLaunchKernelGGL((brick_loop_kernel<P, T, (MODE >= kNoStore ? 0 : MODE)>), dim3(count),
                              dim3(C::THREADS), 0, s, src, first, bd.ent_base, bd.ent_flags,
                              (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
@@ -874,10 +1024,13 @@ namespace mgx
 
   template <typename T>
   static void brick_dispatch(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                             const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0)
+                             const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0,
+                             void *coarse, const uint32_t *coarse_blocks)
   {
     BrickPost<T> post;
     post.f0      = (T)f0;
+    post.coarse  = (T *)coarse;
+    post.coarse_blocks = coarse_blocks;
     post.a       = (const T *)a;
     post.b       = (const T *)b;
     post.old     = (const T *)old;
@@ -895,6 +1048,7 @@ namespace mgx
         case kChebFirst: brick_launch<PP, T, kChebFirst>(s, op, (const T *)src, post); break; \
         case kChebInit: brick_launch<PP, T, kChebInit>(s, op, (const T *)src, post); break; \
         case kChebOldInit: brick_launch<PP, T, kChebOldInit>(s, op, (const T *)src, post); break; \
+        case kResidualRestrict: brick_launch<PP, T, kResidualRestrict>(s, op, (const T *)src, post); break; \
         case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post); break; \
         case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post); break; \
         case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post); break; \
@@ -920,15 +1074,16 @@ namespace mgx
   }
 
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                         const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0)
+                         const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0,
+                         void *coarse, const uint32_t *coarse_blocks)
   {
     if (!old)
       old = out;
     if (!src)
       src = (const void *)a; // kChebInit: never dereferenced, but keep the pointer valid
     if (op.number == 1)
-      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0);
+      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
     else
-      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0);
+      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
   }
 } // namespace mgx

@@ -240,6 +240,7 @@ namespace mgx
       }
     out.ent_base.swap(base2);
     out.ent_flags.swap(flags2);
+    out.order = order;
     out.n_colours = n_colours;
     (void)n_dofs;
     return true;

@@ -15,6 +15,7 @@ namespace mgx
     std::vector<uint32_t> colour_start; // [n_colours+1] into the colour-sorted brick order
     std::vector<uint32_t> ent_base;     // [n_bricks*729] first DoF per brick entity (constrained: invalid)
     std::vector<uint8_t>  ent_flags;    // [n_bricks*729] bit0 FIRST, bit1 LAST
+    std::vector<uint32_t> order;        // [n_bricks] colour-sorted position -> brick index in cell order
   };
 
   // false (with a reason) if the level cannot be scheduled as 4x4x4 bricks

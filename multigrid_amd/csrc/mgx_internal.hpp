@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace mgx
 {
@@ -48,6 +49,7 @@ namespace mgx
     uint32_t  colour_start[33] = {0};
     uint32_t *ent_base  = nullptr; // device [n_bricks * 729]
     uint8_t  *ent_flags = nullptr; // device [n_bricks * 729]  bit0 FIRST, bit1 LAST
+    std::vector<uint32_t> order; // host: colour-sorted position -> brick index in cell order
     bool      available() const { return n_bricks > 0; }
   };
   constexpr int kBrickEntities = 729;
@@ -82,6 +84,10 @@ namespace mgx
     // children patch: first fine DoF | log2(multiplicity) << 29 | owned-by-this-parent << 31;
     // nullptr if the fine level has 2^29 DoFs or more (first-version kernels are used then)
     uint32_t           *patch = nullptr;
+    // fused residual + restriction (mgx_brick.hip, mode 7): per fine brick, in the fine level's
+    // colour-sorted brick order, the first coarse DoF (constrained: invalid) of the (2 PB + 1)^3 mesh
+    // entities of the PB^3 parents the brick's cells belong to (PB = 2 for p <= 4, 1 for p >= 5)
+    uint32_t           *coarse_blocks = nullptr;
     mutable uint32_t    pipe_grid[4] = {0, 0, 0, 0}; // persistent grid of prolongate(add), prolongate, restrict x2
     bool                coarse_coloured = false; // coarse cells c and c' with c % 8 == c' % 8 share no DoF
     uint32_t            n_cus = 256;
@@ -102,7 +108,7 @@ namespace mgx
   //   old: previous iterate of mode 2 (nullptr: it is `out`, which is then read before written)
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr,
-                         double f0 = 0.);
+                         double f0 = 0., void *coarse = nullptr, const uint32_t *coarse_blocks = nullptr);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)

@@ -36,7 +36,7 @@ def main():
                 "known_read_bytes": rb, "FETCH_SIZE_KiB": f, "reported/known": f * 1024 / rb,
                 "known_write_bytes": wb, "WRITE_SIZE_KiB": w, "write reported/known": (w * 1024 / wb) if wb else None}
     names = {0: ("kPlain", 16), 1: ("kResidual", 24), 2: ("kCheb", 40), 3: ("kChebFirst", 32), 4: ("kChebZeroOld", 32),
-             5: ("kChebInit", 24), 6: ("kChebOldInit", 32)}
+             5: ("kChebInit", 24), 6: ("kChebOldInit", 32), 7: ("kResidualRestrict", 18)}
     for mode, (nm, alg) in names.items():
         k = "void mgx::brick_sep_kernel<4, double, %d>" % mode
         if k not in fe or k not in wr:
