@@ -23,6 +23,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace mgx
 {
   // Brick shape: 4x4x4 cells for p <= 4 (64 consecutive Morton cells), 2x2x2 for p >= 5 (the 8
@@ -31,7 +33,7 @@ namespace mgx
   // process the 8 same-parity cells of a round.  p >= 5: the 8 cells of a brick are mutually
   // adjacent; two of them are integrated side by side on (p+1)^2 threads each (one or two waves
   // per cell) and added to the accumulator one after the other (fixed order: deterministic).
-  template <int P>
+  template <int P, bool WIDE = false>
   struct BCfg
   {
     static constexpr int  NB         = P <= 4 ? 4 : 2; // cells per direction
@@ -44,9 +46,13 @@ namespace mgx
     static constexpr int  TPC        = N * N;
     static constexpr bool kTwoPerWave = P <= 4;        // two cells per wave, 8 cells per round
     static constexpr int  TPW        = kTwoPerWave ? 32 : ((TPC + 63) / 64) * 64; // threads reserved per cell
-    static constexpr int  ROUND_CELLS = kTwoPerWave ? 8 : 2;
+    // WIDE (p <= 4 only): two parity classes of 8 cells side by side on 512 threads, added to the
+    // accumulator one after the other.  Halves the number of sequential rounds of a workgroup: used
+    // for launches with too few bricks to fill the chip, whose duration is one workgroup's latency.
+    static constexpr bool kWide      = WIDE && kTwoPerWave;
+    static constexpr int  ROUND_CELLS = kTwoPerWave ? (kWide ? 16 : 8) : 2;
     static constexpr int  ROUNDS     = NCELLS / ROUND_CELLS;
-    static constexpr int  THREADS    = kTwoPerWave ? 256 : 2 * TPW;
+    static constexpr int  THREADS    = kTwoPerWave ? (kWide ? 512 : 256) : 2 * TPW;
     static constexpr bool kWaveSync  = kTwoPerWave || TPW == 64; // transposes stay inside one wave
     static constexpr int  CELL_LDS   = N * N * LN;
   };
@@ -208,7 +214,7 @@ namespace mgx
       }
   }
 
-  template <int P, typename T, int MODE>
+  template <int P, typename T, int MODE, int NT>
   __device__ __forceinline__ void store_brick(int tid, T *acc, const uint32_t *ebase, const T *__restrict__ src,
                                               const BrickPost<T> &post)
   {
@@ -217,10 +223,10 @@ namespace mgx
     constexpr int E1 = C::NE1;
     constexpr int P3 = P * P * P;
     constexpr int NA = C::NCELLS * P3;
-    constexpr bool kFixedLane = (C::THREADS % P3) == 0; // per-thread decode hoisted out of the loops
+    constexpr bool kFixedLane = (NT % P3) == 0; // per-thread decode hoisted out of the loops
     constexpr int NBF = G * G * G - (G - 1) * (G - 1) * (G - 1);
-    constexpr int ITA = (NA + C::THREADS - 1) / C::THREADS;  // iterations of part A
-    constexpr int ITB = (NBF + C::THREADS - 1) / C::THREADS; // iterations of part B
+    constexpr int ITA = (NA + NT - 1) / NT;  // iterations of part A
+    constexpr int ITB = (NBF + NT - 1) / NT; // iterations of part B
     // plain / residual forms only read partial sums of earlier launches: whole waves whose
     // entities are all FIRST skip pass 1
     constexpr bool kLoadsOnlyPartials = (MODE == kPlain || MODE == kNoCompute);
@@ -233,7 +239,7 @@ namespace mgx
     // and iteration `it` only advances the cell by a compile-time constant: the cell index is
     // m = m_thread + CPI * it with CPI = THREADS / p^3 a power of two, so the Morton bits of the
     // two parts are disjoint and (after full unrolling) the second part folds to immediates.
-    constexpr int CPI = kFixedLane ? C::THREADS / P3 : 1;
+    constexpr int CPI = kFixedLane ? NT / P3 : 1;
     auto cell_slot = [](int m) {
       const int bx = (m & 1) | ((m >> 2) & 2), by = ((m >> 1) & 1) | ((m >> 3) & 2), bz = ((m >> 2) & 1) | ((m >> 4) & 2);
       return ((2 * bz) * E1 + 2 * by) * E1 + 2 * bx;
@@ -253,7 +259,7 @@ namespace mgx
         }
       else
         {
-          const int w = tid + it * C::THREADS, m = w / P3;
+          const int w = tid + it * NT, m = w / P3;
           decode_cell_dof<P>(w - m * P3, slot_rel, pnt_rel, k);
           e   = slot_rel + cell_slot(m);
           pnt = pnt_rel + cell_pnt(m);
@@ -300,7 +306,7 @@ namespace mgx
 #pragma unroll
     for (int it = 0; it < ITA; ++it)
       {
-        if (tid + it * C::THREADS >= NA)
+        if (tid + it * NT >= NA)
           break;
         int      e, pnt;
         uint32_t off;
@@ -322,7 +328,7 @@ namespace mgx
         wb[it] = kInvalid;
         ib[it] = 0;
         pb[it] = 0;
-        const int w_item = tid + it * C::THREADS;
+        const int w_item = tid + it * NT;
         if (w_item < NBF)
           {
             int      e;
@@ -339,7 +345,7 @@ namespace mgx
 #pragma unroll
     for (int it = 0; it < ITA; ++it)
       {
-        if (tid + it * C::THREADS >= NA)
+        if (tid + it * NT >= NA)
           break;
         int      e, pnt;
         uint32_t off;
@@ -365,7 +371,7 @@ namespace mgx
       {
         if (MODE == kResidualRestrict)
           {
-            if (tid + it * C::THREADS < NBF)
+            if (tid + it * NT < NBF)
               {
                 if (wb[it] == kInvalid)
                   acc[pb[it]] = T(0);
@@ -424,14 +430,14 @@ namespace mgx
       }
   }
 
-  template <int P, typename T>
+  template <int P, typename T, int NT>
   __device__ __forceinline__ void restrict_brick(int tid, T *acc, const T *__restrict__ p1, T *__restrict__ coarse,
                                                  const uint32_t *__restrict__ ctab)
   {
     using C           = BCfg<P>;
     constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1;
     // x: lines (y, z)
-    for (int l = tid; l < G * G; l += C::THREADS)
+    for (int l = tid; l < G * G; l += NT)
       {
         T r[G], o[CN];
 #pragma unroll
@@ -444,7 +450,7 @@ namespace mgx
       }
     __syncthreads();
     // y: lines (x < CN, z)
-    for (int l = tid; l < CN * G; l += C::THREADS)
+    for (int l = tid; l < CN * G; l += NT)
       {
         const int x = l % CN, z = l / CN;
         T         r[G], o[CN];
@@ -464,7 +470,7 @@ namespace mgx
       o           = rr ? rr - 1 : 0;
       n           = rr ? P - 1 : 1;
     };
-    for (int l = tid; l < CN * CN; l += C::THREADS)
+    for (int l = tid; l < CN * CN; l += NT)
       {
         const int x = l % CN, y = l / CN;
         T         r[G], o[CN];
@@ -704,7 +710,7 @@ namespace mgx
       }
     __syncthreads();
 
-    store_brick<P, T, MODE>(tid, acc, ebase, src, post);
+    store_brick<P, T, MODE, C::THREADS>(tid, acc, ebase, src, post);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -762,13 +768,13 @@ namespace mgx
       }
   }
 
-  template <int P, typename T, int MODE>
-  __global__ void __launch_bounds__(BCfg<P>::THREADS)
+  template <int P, typename T, int MODE, bool WIDE>
+  __global__ void __launch_bounds__((BCfg<P, WIDE>::THREADS))
     brick_sep_kernel(const T *__restrict__ src, uint32_t brick_first, const uint32_t *__restrict__ ent_base,
                      const uint8_t *__restrict__ ent_flags, const Basis1D<T> *__restrict__ B, T c0, T c1, T c2,
                      BrickPost<T> post)
   {
-    using C          = BCfg<P>;
+    using C          = BCfg<P, WIDE>;
     constexpr int N  = C::N;
     constexpr int LN = C::LN;
     constexpr int PL = N * LN;
@@ -801,16 +807,18 @@ namespace mgx
     const int cy = (a == 0) ? 0 : (a == P ? 2 : 1), oy = (cy == 1) ? a - 1 : 0;
     const int cz = (b == 0) ? 0 : (b == P ? 2 : 1), oz = (cz == 1) ? b - 1 : 0;
     const uint32_t loff = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
-    const int hx = 2 * (lc & 1), hy = 2 * ((lc >> 1) & 1), hz = 2 * (lc >> 2);
+    const int hx = 2 * (lc & 1), hy = 2 * ((lc >> 1) & 1), hz = 2 * ((lc >> 2) & 1);
+    const int half = C::kTwoPerWave ? (lc >> 3) : lc; // which of the two cell sets of a round (if two)
     const EOMat<T> &M = B->mass, &K = B->lapl;
     // cell of this thread in a round: p <= 4 the same-parity cell of its 2x2x2 octant, p >= 5 cell
     // 2 round + lc of the 2x2x2 brick
     auto cell_of = [&](int round, int &bx, int &by, int &bz) {
       if (C::kTwoPerWave)
         {
-          bx = hx + (round & 1);
-          by = hy + ((round >> 1) & 1);
-          bz = hz + (round >> 2);
+          const int r = C::kWide ? 2 * round + half : round; // parity class
+          bx          = hx + (r & 1);
+          by          = hy + ((r >> 1) & 1);
+          bz          = hz + (r >> 2);
         }
       else
         {
@@ -956,16 +964,17 @@ namespace mgx
             int bx, by, bz;
             cell_of(round, bx, by, bz);
             T *col = acc + ((bz * P) * G + (by * P + b)) * G + bx * P + a;
-            if (compute && (C::kTwoPerWave || lc == 0))
+            constexpr bool kTwoSets = !C::kTwoPerWave || C::kWide;
+            if (compute && (!kTwoSets || half == 0))
               {
 #pragma unroll
                 for (int i = 0; i < N; ++i)
                   col[i * G * G] += r[i];
               }
-            if (!C::kTwoPerWave)
+            if (kTwoSets)
               {
                 lds_barrier();
-                if (compute && lc == 1)
+                if (compute && half == 1)
                   {
 #pragma unroll
                     for (int i = 0; i < N; ++i)
@@ -991,16 +1000,22 @@ namespace mgx
           post.out[tid] = acc[tid]; // keep the rounds alive
         return;
       }
-    store_brick<P, T, MODE>(tid, acc, ebase, src, post);
+    store_brick<P, T, MODE, C::THREADS>(tid, acc, ebase, src, post);
     if (MODE == kResidualRestrict)
       {
         constexpr int CE1 = C::NB + 1; // 2 PB + 1
         __syncthreads();
-        restrict_brick<P, T>(tid, acc, B->P1, post.coarse, post.coarse_blocks + (size_t)brick * (CE1 * CE1 * CE1));
+        restrict_brick<P, T, C::THREADS>(tid, acc, B->P1, post.coarse, post.coarse_blocks + (size_t)brick * (CE1 * CE1 * CE1));
       }
   }
 
   // ------------------------------------------------------------------------------------------
+  static uint32_t wide_max_bricks()
+  {
+    const char *e = std::getenv("MGX_BRICK_WIDE_MAX");
+    return e ? (uint32_t)std::atol(e) : 1024u;
+  }
+
   template <int P, typename T, int MODE>
   static void brick_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post)
   {
@@ -1012,9 +1027,18 @@ namespace mgx
         if (count == 0)
           continue;
         if (op.separable || MODE >= kNoStore)
-          hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE>), dim3(count), dim3(C::THREADS), 0, s, src, first,
-                             bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
-                             (T)op.coef[2], post);
+          {
+            // few bricks per launch (< 4 per CU): the launch lasts one workgroup's latency, which the
+            // 512-thread form roughly halves; with the chip full the 256-thread form is faster
+            if (P <= 4 && count < wide_max_bricks())
+              hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE, true>), dim3(count), dim3(BCfg<P, true>::THREADS), 0,
+                                 s, src, first, bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis,
+                                 (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
+            else
+              hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE, false>), dim3(count), dim3(C::THREADS), 0, s, src,
+                                 first, bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis, (T)op.coef[0],
+                                 (T)op.coef[1], (T)op.coef[2], post);
+          }
         else if constexpr (P <= 4 && MODE != kChebInit && MODE != kChebOldInit && MODE != kResidualRestrict) // quadrature-point form: 4x4x4 bricks only
           hipLaunchKernelGGL((brick_loop_kernel<P, T, (MODE >= kNoStore ? 0 : MODE)>), dim3(count),
                              dim3(C::THREADS), 0, s, src, first, bd.ent_base, bd.ent_flags,

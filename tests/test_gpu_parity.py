@@ -52,6 +52,35 @@ def test_vmult_and_residual(ctx, p, ns, nr):
     orc.close()
 
 
+@pytest.mark.parametrize("p,ns,nr", [(4, 1, 3), (2, 1, 3), (3, 3, 2)])
+def test_narrow_brick_kernel(ctx, monkeypatch, p, ns, nr):
+    """Launches with few bricks use the 512-thread form of the brick kernel (all small cases above);
+    MGX_BRICK_WIDE_MAX=0 forces the 256-thread form the full-size levels run."""
+    monkeypatch.setenv("MGX_BRICK_WIDE_MAX", "0")
+    cube = mg.Cube(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr, degree=3)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    l = cube.max_level
+    x, b = cube.seeded_vector(l, 1), cube.seeded_vector(l, 2)
+    src, rhs, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=b), ctx.vector(x.size)
+    A = solver.matrix_dp(l)
+    A.vmult(dst, src)
+    assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+    A.vmult_residual(rhs, src, dst)
+    assert rel(dst.download(), orc.vmult_residual(l, b, x)) < 1e-12
+    sm = solver.smoother(l)
+    sm.vmult(dst, rhs)
+    x_ref = orc.cheb_vmult(l, b)
+    assert rel(dst.download(), x_ref) < 1e-10
+    sm.step(dst, rhs)
+    assert rel(dst.download(), orc.cheb_step(l, x_ref, b)) < 1e-10
+    solver.vmult(dst, src)
+    assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    solver.close()
+    cube.close()
+    orc.close()
+
+
 @pytest.mark.parametrize("p,nr", [(4, 2), (4, 3), (2, 4)])
 def test_operator_from_foreign_tables(ctx, p, nr):
     """Drop-in scenario: tables come from the caller (here: the oracle's own arrays), not from
