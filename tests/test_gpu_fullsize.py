@@ -95,3 +95,47 @@ def test_c2_full_solve_reaches_the_readme_accuracy(big):
     assert its == 8                                # README.md:159
     assert red == pytest.approx(6.8e-2, rel=0.1)   # README.md:159: 6.799e-02
     assert solver.compute_l2_error() == pytest.approx(4.2068e-10, rel=0.02)  # README.md:128
+
+
+FALLBACKS = {"MGX_NO_FUSED_RESTRICT": "1", "MGX_NO_FUSED_INIT": "1", "MGX_TRANSFER_V1": "1",
+             "MGX_RESTRICT_ATOMIC": "1", "MGX_BRICK_WIDE_MAX": "0", "MGX_NO_GRAPH": "1"}
+
+
+@pytest.mark.parametrize("p,ns,nr", [(4, 3, 5), (2, 1, 7), (3, 1, 6), (5, 1, 5), (8, 1, 5), (1, 1, 7)])
+def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
+    """Meshes the oracle cannot run in seconds (4 - 17 M DoFs; production thresholds, i.e. without
+    the test overrides of conftest.py): the default V-cycle -- fused residual + restriction, first
+    Chebyshev iterate formed on the fly, pipelined colour-by-colour transfers, 512-thread bricks on
+    small launches, graph replay -- against the same solver built with every one of those switched
+    off (first-version transfer kernels, separate residual and restriction, stored first iterate).
+    The two differ in summation order only."""
+    monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
+    monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
+    ctx = mg.Context(0)
+    cube = mg.Cube(p, ns, nr)
+    l = cube.max_level
+    n = cube.n_dofs(l)
+    x = ctx.vector(n, data=cube.seeded_vector(l, 11))
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    a = ctx.vector(n)
+    solver.vmult(a, x)
+    solver.vmult(a, x)  # second call: coarse levels replayed from the graph
+    for k, v in FALLBACKS.items():
+        monkeypatch.setenv(k, v)
+    plain = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    b = ctx.vector(n)
+    plain.vmult(b, x)
+    nb = ctx.l2_norm(b)
+    mg.check(ctx.lib.mgx_sadd(ctx.h, mg.F64, b.ptr, 1.0, -1.0, a.ptr, n))
+    assert ctx.l2_norm(b) < 1e-11 * nb
+    # and the full solve converges as it should (rate of the README table: 0.11 - 0.16)
+    for k in FALLBACKS:
+        monkeypatch.delenv(k)
+    rate, trace = solver.solve(True)
+    assert rate < 0.3 and (trace[1:, 1] < trace[1:, 0]).all()
+    for v in (x, a, b):
+        v.free()
+    plain.close()
+    solver.close()
+    cube.close()
+    ctx.close()
