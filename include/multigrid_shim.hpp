@@ -75,6 +75,24 @@ namespace multigrid
   {
   public:
     CubeDiscretization(int degree, int n_subdiv, int n_refine) { check(mgx_cube_create(degree, n_subdiv, n_refine, &h_)); }
+    // the "doubling" mesh family (poisson_cube/program.cc:509-529): subdivisions[d] in {1, 2} coarse
+    // cubes of size 1.9 from (-1,-1,-1), refined n_refine times
+    CubeDiscretization(int degree, const int (&subdivisions)[3], int n_refine)
+    {
+      mgx_cube_box_desc bd{};
+      bd.degree   = degree;
+      bd.n_refine = n_refine;
+      bd.origin   = -1.;
+      bd.h0       = 1.9;
+      bd.rank     = 0;
+      bd.numbering = MGX_CUBE_NUMBERING_BRICK;
+      for (int d = 0; d < 3; ++d)
+        {
+          bd.roots[d] = subdivisions[d];
+          bd.procs[d] = 1;
+        }
+      check(mgx_cube_create_box(&bd, &h_));
+    }
     ~CubeDiscretization() { mgx_cube_destroy(h_); }
     CubeDiscretization(const CubeDiscretization &) = delete;
     CubeDiscretization &operator=(const CubeDiscretization &) = delete;

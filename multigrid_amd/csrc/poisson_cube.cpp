@@ -7,9 +7,8 @@
 // same output lines and final table (:360-362, :382-388, :580-606) -- written against the
 // classes of multigrid_shim.hpp instead of deal.II.
 //
-// Differences: only the "square" mesh family is available (the doubling meshes of
-// program.cc:509-529 are boxes, which the structured-cube provider does not generate), the
-// V-cycle number type is a run-time choice (8th argument: f32 = reference default, f64), and the
+// Differences: the V-cycle number type is a run-time choice (8th argument: f32 = reference
+// default, f64), and the
 // per-level L2 errors of the analysed solve are not printed (they would need a device-to-host
 // copy per level).
 #include "../../include/multigrid_shim.hpp"
@@ -21,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -110,7 +110,7 @@ namespace
 
   template <int degree, typename vcycle_number>
   void run(std::size_t min_size, std::size_t max_size, unsigned int n_mg_cycles, unsigned int n_pre,
-           unsigned int n_post)
+           unsigned int n_post, bool use_doubling_mesh)
   {
     std::cout << "Testing FE_Q<3>(" << degree << ")" << std::endl;
     multigrid::Context ctx(0);
@@ -122,14 +122,27 @@ namespace
       {
         std::cout << "Cycle " << cycle << std::endl;
         unsigned int n_refine = 0, n_subdiv = sizes[cycle]; // :532-539
-        if (n_subdiv > 1)
-          while (n_subdiv % 2 == 0)
-            {
-              n_refine += 1;
-              n_subdiv /= 2;
-            }
-        const std::size_t n1 = (std::size_t)(1u << n_refine) * n_subdiv * degree + 1;
-        const std::size_t projected_size = n1 * n1 * n1; // :544-545
+        int          subdivisions[3] = {1, 1, 1};
+        std::size_t  projected_size  = 1;
+        if (use_doubling_mesh) // :509-529
+          {
+            n_refine = cycle / 3;
+            for (unsigned int d = 0; d < cycle % 3; ++d)
+              subdivisions[d] = 2;
+            for (unsigned int d = 0; d < 3; ++d)
+              projected_size *= (std::size_t)(1u << n_refine) * subdivisions[d] * degree + 1;
+          }
+        else
+          {
+            if (n_subdiv > 1)
+              while (n_subdiv % 2 == 0)
+                {
+                  n_refine += 1;
+                  n_subdiv /= 2;
+                }
+            const std::size_t n1 = (std::size_t)(1u << n_refine) * n_subdiv * degree + 1;
+            projected_size       = n1 * n1 * n1; // :544-545
+          }
         if (projected_size < min_size)
           continue;
         if (projected_size > max_size)
@@ -139,9 +152,18 @@ namespace
             break;
           }
         auto t0 = clock_type::now();
-        multigrid::CubeDiscretization disc(degree, (int)n_subdiv, (int)n_refine);
-        std::cout << "Number of degrees of freedom: " << disc.n_dofs() << " = (" << sizes[cycle] << " x " << degree
-                  << " + 1)^3" << std::endl; // :218-220
+        if (n_refine > 9)
+          {
+            std::cout << "More than 9 refinements are not supported, terminating." << std::endl << std::endl;
+            break;
+          }
+        std::unique_ptr<multigrid::CubeDiscretization> disc_ptr;
+        if (use_doubling_mesh)
+          disc_ptr = std::make_unique<multigrid::CubeDiscretization>(degree, subdivisions, (int)n_refine);
+        else
+          disc_ptr = std::make_unique<multigrid::CubeDiscretization>(degree, (int)n_subdiv, (int)n_refine);
+        const multigrid::CubeDiscretization &disc = *disc_ptr;
+        std::cout << "Number of degrees of freedom: " << disc.n_dofs() << std::endl; // :218-220
         std::cout << "DoF setup time:        " << seconds_since(t0) << "s" << std::endl;
         solve<degree, vcycle_number>(ctx, disc, n_mg_cycles, n_pre, n_post, table);
         std::cout << std::endl;
@@ -169,19 +191,19 @@ namespace
 
   template <typename vcycle_number>
   void dispatch(unsigned int degree, std::size_t minsize, std::size_t maxsize, unsigned int c, unsigned int pre,
-                unsigned int post)
+                unsigned int post, bool dbl)
   {
     switch (degree) // LaplaceRunTime<dim,1,9> (program.cc:614-643)
       {
-        case 1: run<1, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 2: run<2, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 3: run<3, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 4: run<4, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 5: run<5, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 6: run<6, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 7: run<7, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 8: run<8, vcycle_number>(minsize, maxsize, c, pre, post); break;
-        case 9: run<9, vcycle_number>(minsize, maxsize, c, pre, post); break;
+        case 1: run<1, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 2: run<2, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 3: run<3, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 4: run<4, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 5: run<5, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 6: run<6, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 7: run<7, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 8: run<8, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
+        case 9: run<9, vcycle_number>(minsize, maxsize, c, pre, post, dbl); break;
         default: break; // degrees outside [1,9] do no work (program.cc:65-66)
       }
   }
@@ -193,7 +215,7 @@ int main(int argc, char *argv[])
     {
       unsigned int degree = 0, n_mg_cycles = 1, n_pre_smooth = 3, n_post_smooth = 3; // program.cc:666-672
       std::size_t  maxsize = static_cast<std::size_t>(-1), minsize = 1;
-      bool         use_doubling_mesh = true, vcycle_f64 = false;
+      bool         use_doubling_mesh = true, vcycle_f64 = false; // program.cc:672
       if (argc == 1)
         {
           std::cout << "Expected at least one argument." << std::endl
@@ -231,16 +253,10 @@ int main(int argc, char *argv[])
                 << "Use doubling mesh:              " << use_doubling_mesh << std::endl
                 << "V-cycle number type:            " << (vcycle_f64 ? "double" : "float") << std::endl
                 << std::endl;
-      if (use_doubling_mesh)
-        {
-          std::cout << "The doubling (box) mesh family is not available in this build; pass 's' as 7th argument."
-                    << std::endl;
-          return 1;
-        }
       if (vcycle_f64)
-        dispatch<double>(degree, minsize, maxsize, n_mg_cycles, n_pre_smooth, n_post_smooth);
+        dispatch<double>(degree, minsize, maxsize, n_mg_cycles, n_pre_smooth, n_post_smooth, use_doubling_mesh);
       else
-        dispatch<float>(degree, minsize, maxsize, n_mg_cycles, n_pre_smooth, n_post_smooth);
+        dispatch<float>(degree, minsize, maxsize, n_mg_cycles, n_pre_smooth, n_post_smooth, use_doubling_mesh);
     }
   catch (std::exception &exc) // program.cc:717-727
     {
