@@ -1934,9 +1934,13 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
       S->smooth.push_back(sm);
     }
   if (!std::getenv("MGX_NO_GRAPH"))
-    for (int l = 0; l < nl; ++l)
-      if (S->matrix[l]->d.n_dofs <= 600000u)
-        S->graph_level = l;
+    {
+      const char    *e = std::getenv("MGX_GRAPH_MAX_DOFS");
+      const uint32_t graph_max = e ? (uint32_t)std::atol(e) : 600000u;
+      for (int l = 0; l < nl; ++l)
+        if (S->matrix[l]->d.n_dofs <= graph_max)
+          S->graph_level = l;
+    }
   const size_t nmax = S->matrix[nl - 1]->d.n_dofs;
   MGX_HIP(hipMalloc((void **)&S->cg_r, 8 * nmax));
   MGX_HIP(hipMalloc((void **)&S->cg_z, 8 * nmax));
