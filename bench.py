@@ -206,7 +206,7 @@ def main():
         # cannot run inside this timed process) and committed under profiles/; it is reported here
         # for the configuration it was measured on
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01f_pmc_traffic_128cube_p4.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01g_pmc_traffic_128cube_p4.json")
         if args.degree == 4 and args.cells == 128 and vnum == mg.F64 and os.path.exists(pmc_file):
             k = json.load(open(pmc_file))["kernels"].get(NAMES[form])
             if k:
@@ -216,7 +216,7 @@ def main():
         return {"bound": "hbm", "kernel": "mgx::brick_sep_kernel<%d,double,%s> (finest level, per colour launch)"
                 % (args.degree, NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01f_pmc_traffic_128cube_p4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                "traffic_source": "profiles/r01g_pmc_traffic_128cube_p4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                   "separate passes, FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
                 "launches": launches, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_bytes_per_dof": ALG[form]}
