@@ -25,6 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (datasheet); tools/microbench.hip sustains 60.5
+FLOP_PER_DOF_P4 = 105.0   # executed by the separable brick kernel at p = 4 (dense 12-sweep form: 270)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
 
 
@@ -219,7 +221,14 @@ def main():
                 "traffic_source": "profiles/r01g_pmc_traffic_128cube_p4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                   "separate passes, FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
                 "launches": launches, "avg_launch_ms": avg,
-                "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_bytes_per_dof": ALG[form]}
+                "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_bytes_per_dof": ALG[form],
+                # co-limiter asked for by SURVEY.md 8d: fp64 vector throughput of the cell loop.  Executed
+                # flops of the separable even-odd form at p = 4 (ISA count of the round loop: 159 fp64
+                # VALU instructions per lane and round, ~110 of them FMA, 25 active lanes per cell)
+                "fp64_valu": ({"flop_per_dof": FLOP_PER_DOF_P4, "achieved_tflops": FLOP_PER_DOF_P4 * (n_dofs / n_col)
+                               / (avg * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
+                               "frac": FLOP_PER_DOF_P4 * (n_dofs / n_col) / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+                              if args.degree == 4 else None)}
     out = {
         "metric": "DoFs/s for Laplace matvec + V-cycle, poisson_cube p=%d fp64" % args.degree,
         "value": total_dofs / (elapsed / args.steps),

@@ -17,8 +17,16 @@
 //     are FIRST|LAST: they are written exactly once.  Surface entities carry their partial sum
 //     through global memory between launches: (8 + 16(k-1)) B for an entity shared by k bricks.
 //
-// HBM traffic per brick at p=4 (fp64): 39.3 kB gathered source + 45.8 kB result/partials +
-// 3.6 kB entity table = 1.39 kB per cell against the algorithmic 1.0 kB (64 DoFs x 16 B).
+//   * fused post-operations (BrickMode): residual, the Chebyshev updates of the smoother (incl. the
+//     two forms that never store the first iterate of a zero-start sweep) and the V-cycle's
+//     residual + restriction to the next coarser level in one pass (restrict_brick below).
+//   * launches that do not fill the chip use a 512-thread form (two parity classes side by side);
+//     p >= 5 works on 2x2x2 bricks with two cells side by side.
+//
+// HBM traffic per brick at p=4 (fp64, plain form, measured 374 MB per colour launch of 4096
+// bricks = 91 kB per brick): 41 kB gathered source (17^3 points for 16^3 owned, brick-grouped
+// numbering), 46 kB result + partial sums written/re-read on the brick surface, 2.9 kB entity
+// table -- against the algorithmic 66 kB (4096 DoFs x 16 B).  DESIGN.md 4.1 has the time budget.
 #include "mgx_internal.hpp"
 
 #include <hip/hip_runtime.h>

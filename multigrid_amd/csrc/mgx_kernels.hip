@@ -1,5 +1,7 @@
-// mgx_kernels.hip -- hand-written gfx950 kernels of the matrix-free Laplace cell loop and the
-// multigrid transfers.
+// mgx_kernels.hip -- first-generation gfx950 kernels: the per-cell Laplace cell loop with atomic
+// scatter (used on levels too small for the brick schedule of mgx_brick.hip and for cell orders
+// that do not form bricks), the diagonal, and the one-workgroup-per-parent transfers (fallback of
+// the pipelined kernels in mgx_transfer.hip for levels with 2^29 DoFs or more).
 //
 // Mapping (CDNA4, 64-wide waves): a cell of FE_Q(p) has n^3 = (p+1)^3 points.  A tile of
 // n x n threads owns one cell; each thread holds ONE 1D line of n values in registers, so every
