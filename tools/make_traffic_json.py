@@ -38,7 +38,9 @@ def main():
     names = {0: ("kPlain", 16), 1: ("kResidual", 24), 2: ("kCheb", 40), 3: ("kChebFirst", 32), 4: ("kChebZeroOld", 32),
              5: ("kChebInit", 24), 6: ("kChebOldInit", 32), 7: ("kResidualRestrict", 18)}
     for mode, (nm, alg) in names.items():
-        k = "void mgx::brick_sep_kernel<4, double, %d>" % mode
+        k = "void mgx::brick_sep_kernel<4, double, %d, false>" % mode  # 256-thread form (full launches)
+        if k not in fe:
+            k = "void mgx::brick_sep_kernel<4, double, %d>" % mode     # builds before the 512-thread form
         if k not in fe or k not in wr:
             continue
         big = max(fe[k].keys())
