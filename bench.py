@@ -101,6 +101,11 @@ def main():
 
     import numpy as np
 
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        # torch.distributed.run pins OMP_NUM_THREADS=1; the host-side table construction (mesh
+        # tables, brick schedule, rhs assembly) is OpenMP code: give every rank its share of the cores
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or 8) // world)))
+
     import multigrid_amd as mg
 
     ctx = mg.Context(local_rank)
