@@ -26,6 +26,7 @@ def lex_of(o, l, v):
 
 def main():
     mode, p, nr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    vfloat = len(sys.argv) > 4 and sys.argv[4] == "f32"  # V-cycle number type (reference default: float)
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
@@ -40,7 +41,7 @@ def main():
 
     procs = mg.process_grid(world)
     cube = mg.Cube(p, n_refine=nr, box=procs, procs=procs, rank=rank)
-    orc = Oracle(p, n_refine=nr, degree=3, n_cycles=1, box=procs)
+    orc = Oracle(p, n_refine=nr, degree=3, n_cycles=1, box=procs, vfloat=vfloat)
     l = cube.max_level
     gid = cube.dof_grid(l)
 
@@ -84,7 +85,8 @@ def main():
     else:
         ctx = mg.Context(0)
         comm = mg.Communicator(ctx, dist)
-        solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64, comm=comm)
+        solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32 if vfloat else mg.F64, comm=comm)
+        tol_v, tol_r, tol_l2 = (2e-4, 2e-3, 1e-4) if vfloat else (1e-9, 1e-6, 1e-8)
         if mode == "nccl":
             assert comm.native_ready, "library-side RCCL communicator was not created"
             assert comm.verify_and_enable_native(solver.matrix_dp(l), cube.n_dofs(l))
@@ -114,7 +116,7 @@ def main():
             assert abs(ctx.l2_norm(src) - np.linalg.norm(xo)) < 1e-12 * np.linalg.norm(xo)
             gi, oi = solver.smoother(lev).info(), orc.cheb_info(lev)
             assert gi["degree"] == oi["degree"] and gi["cg_its"] == oi["cg_its"], (lev, gi, oi)
-            assert abs(gi["lambda_max"] - oi["lambda_max"]) < 1e-8 * oi["lambda_max"], (lev, gi, oi)
+            assert abs(gi["lambda_max"] - oi["lambda_max"]) < (1e-4 if vfloat else 1e-8) * oi["lambda_max"], (lev, gi, oi)
         # V-cycle, FMG, PCG
         x = cube.seeded_vector(l, 5)
         import tests.golden.make_golden as mk
@@ -123,18 +125,18 @@ def main():
         solver.vmult(dst, src)
         ref = lex_of(orc, l, orc.vcycle(xo))[gid]
         err = np.abs(dst.download() - ref).max() / np.abs(ref).max()
-        assert err < 1e-9, ("vcycle", err)
+        assert err < tol_v, ("vcycle", err)
         rate, trace = solver.solve(True)
         orate, otrace = orc.solve(True)
-        assert abs(rate - orate) < 1e-6 * orate, (rate, orate)
-        assert np.allclose(trace[1:, 0], otrace[1:, 1], rtol=1e-9)
+        assert abs(rate - orate) < max(tol_r, 1e-6) * orate * (100 if vfloat else 1), (rate, orate)
+        assert np.allclose(trace[1:, 0], otrace[1:, 1], rtol=1e-3 if vfloat else 1e-9)
         l2 = solver.compute_l2_error()
-        assert abs(l2 - orc.l2_error()) < 1e-8 * l2, (l2, orc.l2_error())
+        assert abs(l2 - orc.l2_error()) < tol_l2 * l2, (l2, orc.l2_error())
         its, red = solver.solve_cg()
         oits, ored = orc.solve_cg()
         assert its == oits, (its, oits)
         l2 = solver.compute_l2_error()
-        assert abs(l2 - orc.l2_error()) < 1e-8 * l2
+        assert abs(l2 - orc.l2_error()) < tol_l2 * l2
         print("rank %d gpu ok: FMG L2 %.6e, cg its %d%s" % (rank, l2, its, ", native RCCL" if comm.native_enabled else ""),
               flush=True)
         solver.close()

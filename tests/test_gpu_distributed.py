@@ -7,9 +7,15 @@ from test_decomposition import launch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,p,nr", [(2, 4, 3), (4, 4, 2), (2, 2, 3)])
+@pytest.mark.parametrize("world,p,nr", [(2, 4, 3), (4, 4, 2), (2, 2, 3), (2, 5, 2), (2, 8, 1)])
 def test_decomposed_solver_matches_oracle(world, p, nr):
     outs = launch("gpu", world, p, nr)
+    assert all("gpu ok" in o for o in outs), outs
+
+
+def test_decomposed_mixed_precision_solver_matches_oracle():
+    """the reference's default: fp32 V-cycle inside the fp64 outer iteration, on two ranks"""
+    outs = launch("gpu", 2, 4, 3, extra=("f32",))
     assert all("gpu ok" in o for o in outs), outs
 
 
