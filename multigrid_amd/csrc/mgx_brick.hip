@@ -790,7 +790,11 @@ namespace mgx
     constexpr int E1 = C::NE1;
     constexpr int H1 = N / 2 + 1;
     __shared__ T        acc[G * G * G];
-    __shared__ T        U[C::ROUND_CELLS * C::CELL_LDS];
+    // fp32: two transpose buffers per cell, so that both arrays of a transpose move in one
+    // write / one read phase (half the LDS round trips per round); the fp64 accumulator leaves no
+    // room for that at 3 workgroups per CU
+    constexpr bool kDualU = sizeof(T) == 4;
+    __shared__ T        U[(kDualU ? 2 : 1) * C::ROUND_CELLS * C::CELL_LDS];
     __shared__ uint32_t ebase[C::NE];
 
     const int      tid   = threadIdx.x;
@@ -809,6 +813,7 @@ namespace mgx
     const int  a       = compute ? t % N : 0;
     const int  b       = compute ? t / N : 0;
     T         *Uc      = U + lc * C::CELL_LDS;
+    T         *Ud      = U + (kDualU ? C::ROUND_CELLS + lc : lc) * C::CELL_LDS; // second buffer (fp32)
     const int  xl      = (b * N + a) * LN;
     const int  yl      = b * PL + a;
     const int  zl      = b * LN + a;
@@ -897,28 +902,51 @@ namespace mgx
         eo_split<N, T>(r, xe, xo);
         eo_apply<N, T>(M, xe, xo, t1);
         eo_apply<N, T>(K, xe, xo, k1);
-        if (compute)
+        if (kDualU)
           {
+            if (compute)
+              {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  {
+                    Uc[xl + i] = t1[i];
+                    Ud[xl + i] = k1[i];
+                  }
+              }
+            phase_sync();
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              Uc[xl + i] = t1[i];
+              {
+                t1[i] = Uc[yl + i * LN]; // y-lines of M_x u and K_x u
+                k1[i] = Ud[yl + i * LN];
+              }
+            phase_sync();
           }
-        phase_sync();
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-          t1[i] = Uc[yl + i * LN]; // y-line of M_x u
-        phase_sync();
-        if (compute)
+        else
           {
+            if (compute)
+              {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  Uc[xl + i] = t1[i];
+              }
+            phase_sync();
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              Uc[xl + i] = k1[i];
-          }
-        phase_sync();
+              t1[i] = Uc[yl + i * LN]; // y-line of M_x u
+            phase_sync();
+            if (compute)
+              {
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          k1[i] = Uc[yl + i * LN]; // y-line of K_x u
-        phase_sync();
+                for (int i = 0; i < N; ++i)
+                  Uc[xl + i] = k1[i];
+              }
+            phase_sync();
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              k1[i] = Uc[yl + i * LN]; // y-line of K_x u
+            phase_sync();
+          }
         // y: t2 = M t1 ; s2 = c_x M k1 + c_y K t1
         T t2[N], s2[N];
         eo_split<N, T>(t1, xe, xo);
@@ -929,27 +957,50 @@ namespace mgx
 #pragma unroll
         for (int i = 0; i < N; ++i)
           s2[i] = fma(c0, r[i], c1 * s2[i]);
-        if (compute)
+        if (kDualU)
           {
+            if (compute)
+              {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  {
+                    Uc[yl + i * LN] = t2[i];
+                    Ud[yl + i * LN] = s2[i];
+                  }
+              }
+            phase_sync();
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              Uc[yl + i * LN] = t2[i];
+              {
+                t2[i] = Uc[zl + i * PL]; // z-lines
+                s2[i] = Ud[zl + i * PL];
+              }
+            phase_sync(); // the next round overwrites both buffers
           }
-        phase_sync();
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-          t2[i] = Uc[zl + i * PL]; // z-line of M_y M_x u
-        phase_sync();
-        if (compute)
+        else
           {
+            if (compute)
+              {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  Uc[yl + i * LN] = t2[i];
+              }
+            phase_sync();
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              Uc[yl + i * LN] = s2[i];
-          }
-        phase_sync();
+              t2[i] = Uc[zl + i * PL]; // z-line of M_y M_x u
+            phase_sync();
+            if (compute)
+              {
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-          s2[i] = Uc[zl + i * PL];
+                for (int i = 0; i < N; ++i)
+                  Uc[yl + i * LN] = s2[i];
+              }
+            phase_sync();
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              s2[i] = Uc[zl + i * PL];
+          }
         // z: out = M s2 + c_z K t2
         eo_split<N, T>(s2, xe, xo);
         eo_apply<N, T>(M, xe, xo, r);

@@ -258,15 +258,24 @@ def test_readme_known_answers_on_gpu(ctx):
     cube.close()
 
 
-def test_mixed_precision_vcycle(ctx):
-    cube = mg.Cube(4, 1, 3)
-    orc = oracle_for(cube, 4, 1, 3, degree=3, n_cycles=1, vfloat=True)
+@pytest.mark.parametrize("p,ns,nr", [(4, 1, 3), (2, 1, 3), (5, 1, 2), (8, 1, 2), (3, 3, 2)])
+def test_mixed_precision_vcycle(ctx, p, ns, nr):
+    """the reference's default: fp32 V-cycle (fp32 level operators, smoothers, transfers) inside the
+    fp64 outer iteration, against the oracle run the same way"""
+    cube = mg.Cube(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr, degree=3, n_cycles=1, vfloat=True)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32)
     lmax = cube.max_level
     x = cube.seeded_vector(lmax, 5)
     src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
     solver.vmult(dst, src)
     assert rel(dst.download(), orc.vcycle(x)) < 2e-4
+    # the fp32 level operator itself
+    A = solver.matrix(lmax)
+    s32, d32 = ctx.vector(x.size, mg.F32, x), ctx.vector(x.size, mg.F32)
+    A.vmult(d32, s32)
+    x32 = x.astype(np.float32).astype(np.float64)
+    assert rel(d32.download().astype(np.float64), orc.vmult(lmax, x32)) < 3e-6
     solver.solve(False)
     orc.solve(False)
     assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-4)
