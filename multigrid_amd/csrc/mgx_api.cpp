@@ -911,6 +911,14 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
           MGX_HIP(hipMemcpy(b.ent_base, bh.ent_base.data(), sizeof(uint32_t) * bh.ent_base.size(),
                             hipMemcpyHostToDevice));
           b.ent_flags = nullptr;
+          if (d.separable)
+            {
+              // write-out order of the macro-element kernel (mgx_macro.hip)
+              std::vector<uint32_t> map;
+              build_item_map(p, map);
+              MGX_HIP(hipMalloc((void **)&b.item_map, sizeof(uint32_t) * map.size()));
+              MGX_HIP(hipMemcpy(b.item_map, map.data(), sizeof(uint32_t) * map.size(), hipMemcpyHostToDevice));
+            }
           MGX_TRACE("operator_create: %u bricks, %d colours", b.n_bricks, b.n_colours);
         }
       else
@@ -1101,6 +1109,8 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.inv_diag);
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
+  (void)hipFree(op->d.bricks.item_map);
+  (void)hipFree(op->d.diag_items);
   (void)hipFree(op->global_index_dev);
   if (op->plan)
     {
@@ -1211,6 +1221,35 @@ int mgx_compute_diagonal(mgx_operator_t op)
   launch_invert(s, op->d.number, op->d.inv_diag, op->d.n_dofs);
   MGX_HIP(hipGetLastError());
   op->has_diag = true;
+  // Is the diagonal the same for every brick (uniform mesh)?  Then the macro-element kernel keeps
+  // it in registers instead of streaming it (mgx_macro.hip, DTAB).  MGX_NO_DIAG_TABLE=1: A/B timing.
+  if (op->d.diag_items)
+    {
+      MGX_HIP(hipFree(op->d.diag_items));
+      op->d.diag_items = nullptr;
+    }
+  if (op->d.bricks.item_map && op->d.separable && !std::getenv("MGX_NO_DIAG_TABLE"))
+    {
+      const uint32_t nb = op->d.p <= 4 ? 4 : 2, g = nb * op->d.p + 1, npts = g * g * g;
+      void          *table = nullptr;
+      uint32_t      *flag  = nullptr, mismatch = 1;
+      MGX_HIP(hipMalloc(&table, number_size(op->d.number) * npts));
+      MGX_HIP(hipMalloc((void **)&flag, sizeof(uint32_t)));
+      MGX_HIP(hipMemsetAsync(table, 0, number_size(op->d.number) * npts, s));
+      MGX_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+      if (op->d.number == MGX_F64)
+        macro_diag_table_f64(s, op->d, table, flag);
+      else
+        macro_diag_table_f32(s, op->d, table, flag);
+      MGX_HIP(hipMemcpyAsync(&mismatch, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+      MGX_HIP(hipFree(flag));
+      if (mismatch == 0)
+        op->d.diag_items = table;
+      else
+        MGX_HIP(hipFree(table));
+      MGX_TRACE("compute_diagonal: diagonal %s per brick item", mismatch == 0 ? "uniform" : "not uniform");
+    }
   return MGX_OK;
 }
 

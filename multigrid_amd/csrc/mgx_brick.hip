@@ -27,43 +27,15 @@
 // bricks = 91 kB per brick): 41 kB gathered source (17^3 points for 16^3 owned, brick-grouped
 // numbering), 46 kB result + partial sums written/re-read on the brick surface, 2.9 kB entity
 // table -- against the algorithmic 66 kB (4096 DoFs x 16 B).  DESIGN.md 4.1 has the time budget.
-#include "mgx_internal.hpp"
+#include "mgx_brick_device.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <string>
 
 namespace mgx
 {
-  // Brick shape: 4x4x4 cells for p <= 4 (64 consecutive Morton cells), 2x2x2 for p >= 5 (the 8
-  // children of one parent), so that the (NB p + 1)^3 fp64 accumulator stays below 55 kB of LDS.
-  // p <= 4: a cell needs (p+1)^2 <= 25 threads, a wave owns two cells of a round, four waves
-  // process the 8 same-parity cells of a round.  p >= 5: the 8 cells of a brick are mutually
-  // adjacent; two of them are integrated side by side on (p+1)^2 threads each (one or two waves
-  // per cell) and added to the accumulator one after the other (fixed order: deterministic).
-  template <int P, bool WIDE = false>
-  struct BCfg
-  {
-    static constexpr int  NB         = P <= 4 ? 4 : 2; // cells per direction
-    static constexpr int  NCELLS     = NB * NB * NB;
-    static constexpr int  N          = P + 1;
-    static constexpr int  LN         = N | 1;          // odd x-line pitch (bank-conflict free)
-    static constexpr int  G          = NB * P + 1;     // points per direction
-    static constexpr int  NE1        = 2 * NB + 1;     // mesh entities per direction
-    static constexpr int  NE         = NE1 * NE1 * NE1;
-    static constexpr int  TPC        = N * N;
-    static constexpr bool kTwoPerWave = P <= 4;        // two cells per wave, 8 cells per round
-    static constexpr int  TPW        = kTwoPerWave ? 32 : ((TPC + 63) / 64) * 64; // threads reserved per cell
-    // WIDE (p <= 4 only): two parity classes of 8 cells side by side on 512 threads, added to the
-    // accumulator one after the other.  Halves the number of sequential rounds of a workgroup: used
-    // for launches with too few bricks to fill the chip, whose duration is one workgroup's latency.
-    static constexpr bool kWide      = WIDE && kTwoPerWave;
-    static constexpr int  ROUND_CELLS = kTwoPerWave ? (kWide ? 16 : 8) : 2;
-    static constexpr int  ROUNDS     = NCELLS / ROUND_CELLS;
-    static constexpr int  THREADS    = kTwoPerWave ? (kWide ? 512 : 256) : 2 * TPW;
-    static constexpr bool kWaveSync  = kTwoPerWave || TPW == 64; // transposes stay inside one wave
-    static constexpr int  CELL_LDS   = N * N * LN;
-  };
 
   template <int N, typename T>
   __device__ __forceinline__ void bmv(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
@@ -93,44 +65,6 @@ namespace mgx
       }
   }
 
-  // fused post-operations (what the reference passes as operation_after_loop)
-  enum BrickMode
-  {
-    kPlain    = 0, // out = A src                                   (vmult, laplace_operator.h:573)
-    kResidual = 1, // out = a - A src                               (vmult_residual, :605)
-    kCheb     = 2, // out = x + f1 (x - out) + f2 b (a - A x)       (PreconditionChebyshev update)
-    kChebFirst = 3, // out = x + f2 b (a - A x)                     (first step: no x_old term)
-    kChebZeroOld = 4, // out = x + f1 x + f2 b (a - A x)             (x_old known to be zero)
-    // start of PreconditionChebyshev::vmult (zero initial guess): the first iterate x_1 = f0 b a is
-    // never stored -- the first loop iteration computes it while gathering (kChebInit, x_old = 0),
-    // the second one recomputes it as its x_old (kChebOldInit); separable kernel only
-    kChebInit    = 5, // x := f0 b a ; out = x + f1 x + f2 b (a - A x)
-    kChebOldInit = 6, // out = x + f1 (x - f0 b a) + f2 b (a - A x)
-    // V-cycle: the residual a - A x is only needed restricted to the next coarser level
-    // (multigrid_solver.h:663-668).  Every brick restricts the residual values it completes (its
-    // LAST points, everything else masked to zero) with the transposed embedding and adds the
-    // (PB p + 1)^3 coarse values to the coarse vector; the residual itself is never stored.
-    kResidualRestrict = 7,
-    // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
-    kNoStore   = 8, // rounds only, no write-out
-    kNoCompute = 9, // write-out only, no rounds
-    kInitOnly  = 10, // prologue only
-    kNoScatter = 11, // rounds without the accumulator update and its barrier, no write-out
-    kNoBarrier = 12  // rounds without the per-round barrier, no write-out
-  };
-
-  template <typename T>
-  struct BrickPost
-  {
-    const T *a;       // kResidual: rhs ; kCheb: rhs b of the smoother
-    const T *b;       // kCheb: inverse diagonal
-    const T *old;     // kCheb: previous iterate x_old (may alias out: read before written)
-    T       *out;     // result vector
-    T       *partial; // carrier of partial sums between colour launches (may alias out)
-    T        f1, f2, f0;
-    T              *coarse;        // kResidualRestrict: coarse-level vector the restriction adds to
-    const uint32_t *coarse_blocks; // kResidualRestrict: coarse entity table of the brick's parents
-  };
 
 
   // ------------------------------------------------------------------------------------------
@@ -140,10 +74,6 @@ namespace mgx
   // global addresses: runs of (p-1)^3, (p-1)^2, (p-1) or 1 values instead of the runs of p-1 a
   // lexicographic sweep over the brick points would give.
   // ------------------------------------------------------------------------------------------
-  // Entity table word: bits 0..29 first DoF of the entity, bit 30 FIRST, bit 31 LAST;
-  // 0xFFFFFFFF = constrained / empty entity (the host refuses levels with >= 2^30 - 1 DoFs)
-  __device__ __forceinline__ uint32_t ent_index(uint32_t w) { return w & 0x3FFFFFFFu; }
-  __device__ __forceinline__ uint32_t ent_flags_of(uint32_t w) { return w >> 30; }
 
   // Pass 1 of the write-out: everything that has to be READ (partial sums of earlier launches and
   // the operands of the fused post-operation) is loaded with unconditional, branch-free loads
@@ -395,132 +325,8 @@ namespace mgx
       }
   }
 
-  // ------------------------------------------------------------------------------------------
-  // Restriction of the brick array in place (kResidualRestrict).  acc holds the G^3 fine values of
-  // the brick (G = NB p + 1) whose cells are the children of PB^3 parents (PB = NB / 2): three 1D
-  // sweeps with the transposed embedding P1 (one line per thread, values in registers, outputs
-  // written over the head of the line), then the (PB p + 1)^3 coarse values are added to the
-  // coarse vector through the coarse entity table of the brick.  Bricks of one colour launch are
-  // not adjacent, so their parents share no coarse DoF: plain read-modify-write.
-  // ------------------------------------------------------------------------------------------
-  template <int P, typename T>
-  __device__ __forceinline__ void restrict_line(const T *__restrict__ p1, const T (&r)[BCfg<P>::G],
-                                                T (&out)[(BCfg<P>::NB / 2) * P + 1])
-  {
-    constexpr int N = P + 1, M = 2 * P + 1, PB = BCfg<P>::NB / 2;
-#pragma unroll
-    for (int pb = 0; pb < PB; ++pb)
-      {
-        T o[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-          {
-            T s = p1[j] * r[pb * 2 * P];
-#pragma unroll
-            for (int a = 1; a < M; ++a)
-              s = fma(p1[a * N + j], r[pb * 2 * P + a], s);
-            o[j] = s;
-          }
-        if (pb == 0)
-          {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-              out[j] = o[j];
-          }
-        else
-          {
-            // the node shared by the two parents was counted by both (unit weight in each)
-            out[pb * P] += o[0] - r[pb * 2 * P];
-#pragma unroll
-            for (int j = 1; j < N; ++j)
-              out[pb * P + j] = o[j];
-          }
-      }
-  }
-
-  template <int P, typename T, int NT>
-  __device__ __forceinline__ void restrict_brick(int tid, T *acc, const T *__restrict__ p1, T *__restrict__ coarse,
-                                                 const uint32_t *__restrict__ ctab)
-  {
-    using C           = BCfg<P>;
-    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1;
-    // x: lines (y, z)
-    for (int l = tid; l < G * G; l += NT)
-      {
-        T r[G], o[CN];
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-          r[i] = acc[l * G + i];
-        restrict_line<P, T>(p1, r, o);
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-          acc[l * G + j] = o[j];
-      }
-    __syncthreads();
-    // y: lines (x < CN, z)
-    for (int l = tid; l < CN * G; l += NT)
-      {
-        const int x = l % CN, z = l / CN;
-        T         r[G], o[CN];
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-          r[i] = acc[(z * G + i) * G + x];
-        restrict_line<P, T>(p1, r, o);
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-          acc[(z * G + j) * G + x] = o[j];
-      }
-    __syncthreads();
-    // z: lines (x, y) with x, y < CN; the results go to the coarse vector
-    auto layer = [](int a, int &e, int &o, int &n) {
-      const int q = a / P, rr = a - q * P;
-      e           = 2 * q + (rr != 0);
-      o           = rr ? rr - 1 : 0;
-      n           = rr ? P - 1 : 1;
-    };
-    for (int l = tid; l < CN * CN; l += NT)
-      {
-        const int x = l % CN, y = l / CN;
-        T         r[G], o[CN];
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-          r[i] = acc[(i * G + y) * G + x];
-        restrict_line<P, T>(p1, r, o);
-        int ex, ey, ox, oy, nx, ny;
-        layer(x, ex, ox, nx);
-        layer(y, ey, oy, ny);
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-          {
-            int ez, oz, nz;
-            layer(j, ez, oz, nz);
-            const uint32_t w = ctab[(ez * CE1 + ey) * CE1 + ex];
-            if (w != kInvalid)
-              {
-                T *c = coarse + w + (uint32_t)((oz * ny + oy) * nx + ox);
-                *c += o[j];
-              }
-          }
-      }
-  }
 
 
-  // wave-local ordering of LDS traffic: the two cells of a wave exchange data only among the
-  // lanes of that wave, which execute in lockstep; the LDS services one wave's operations in
-  // order, so a compiler-level barrier is all that is needed between the transposes
-  __device__ __forceinline__ void wave_sync()
-  {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-  }
-
-  // workgroup barrier that orders LDS traffic only: global loads issued earlier (the prefetch of
-  // the next round's source values) stay in flight across it, which __syncthreads() would drain
-  __device__ __forceinline__ void lds_barrier()
-  {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
 
   template <int P, typename T, int MODE>
   __global__ void __launch_bounds__(BCfg<P>::THREADS)
@@ -731,50 +537,6 @@ namespace mgx
   // 7 sweeps instead of 12 and 2 LDS transposes instead of 8; M and K are symmetric and
   // persymmetric, so every sweep runs in even-odd form with coefficients that stay in SGPRs.
   // ------------------------------------------------------------------------------------------
-  template <int N, typename T>
-  __device__ __forceinline__ void eo_split(const T (&x)[N], T (&xe)[N / 2 + 1], T (&xo)[N / 2 + 1])
-  {
-    constexpr int H = N / 2;
-#pragma unroll
-    for (int i = 0; i < H; ++i)
-      {
-        xe[i] = x[i] + x[N - 1 - i];
-        xo[i] = x[i] - x[N - 1 - i];
-      }
-    xe[H] = (N % 2) ? x[H] : T(0); // middle entry
-    xo[H] = T(0);
-  }
-
-  template <int N, typename T>
-  __device__ __forceinline__ void eo_apply(const EOMat<T> &A, const T (&xe)[N / 2 + 1], const T (&xo)[N / 2 + 1],
-                                           T (&y)[N])
-  {
-    constexpr int H = N / 2;
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-      {
-        T r0 = A.ee[a * H] * xe[0];
-        T r1 = A.eo[a * H] * xo[0];
-#pragma unroll
-        for (int i = 1; i < H; ++i)
-          {
-            r0 = fma(A.ee[a * H + i], xe[i], r0);
-            r1 = fma(A.eo[a * H + i], xo[i], r1);
-          }
-        if (N % 2)
-          r0 = fma(A.mc[a], xe[H], r0);
-        y[a]         = r0 + r1;
-        y[N - 1 - a] = r0 - r1;
-      }
-    if (N % 2)
-      {
-        T r = A.mhh * xe[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i)
-          r = fma(A.mc[i], xe[i], r);
-        y[H] = r;
-      }
-  }
 
   template <int P, typename T, int MODE, bool WIDE>
   __global__ void __launch_bounds__((BCfg<P, WIDE>::THREADS))
@@ -1164,6 +926,17 @@ namespace mgx
       old = out;
     if (!src)
       src = (const void *)a; // kChebInit: never dereferenced, but keep the pointer valid
+    // separable operator: macro-element form (mgx_macro.hip); MGX_BRICK_FORM=cells keeps the
+    // cell-by-cell form below (A/B measurements, and the reference point of the consistency tests)
+    static const bool cells_form = std::getenv("MGX_BRICK_FORM") && std::string(std::getenv("MGX_BRICK_FORM")) == "cells";
+    if (op.separable && op.bricks.item_map && !cells_form)
+      {
+        const bool done = op.number == 1
+                            ? launch_macro_loop_f64(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks)
+                            : launch_macro_loop_f32(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
+        if (done)
+          return;
+      }
     if (op.number == 1)
       brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
     else

@@ -1,0 +1,255 @@
+// mgx_brick_device.hpp -- device code shared by the two forms of the brick cell loop
+// (mgx_brick.hip: cell-by-cell rounds; mgx_macro.hip: macro-element sweeps over the assembled brick).
+#pragma once
+
+#include "mgx_internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace mgx
+{
+  // Brick shape: 4x4x4 cells for p <= 4 (64 consecutive Morton cells), 2x2x2 for p >= 5 (the 8
+  // children of one parent), so that the (NB p + 1)^3 fp64 accumulator stays below 55 kB of LDS.
+  // p <= 4: a cell needs (p+1)^2 <= 25 threads, a wave owns two cells of a round, four waves
+  // process the 8 same-parity cells of a round.  p >= 5: the 8 cells of a brick are mutually
+  // adjacent; two of them are integrated side by side on (p+1)^2 threads each (one or two waves
+  // per cell) and added to the accumulator one after the other (fixed order: deterministic).
+  template <int P, bool WIDE = false>
+  struct BCfg
+  {
+    static constexpr int  NB         = P <= 4 ? 4 : 2; // cells per direction
+    static constexpr int  NCELLS     = NB * NB * NB;
+    static constexpr int  N          = P + 1;
+    static constexpr int  LN         = N | 1;          // odd x-line pitch (bank-conflict free)
+    static constexpr int  G          = NB * P + 1;     // points per direction
+    static constexpr int  NE1        = 2 * NB + 1;     // mesh entities per direction
+    static constexpr int  NE         = NE1 * NE1 * NE1;
+    static constexpr int  TPC        = N * N;
+    static constexpr bool kTwoPerWave = P <= 4;        // two cells per wave, 8 cells per round
+    static constexpr int  TPW        = kTwoPerWave ? 32 : ((TPC + 63) / 64) * 64; // threads reserved per cell
+    // WIDE (p <= 4 only): two parity classes of 8 cells side by side on 512 threads, added to the
+    // accumulator one after the other.  Halves the number of sequential rounds of a workgroup: used
+    // for launches with too few bricks to fill the chip, whose duration is one workgroup's latency.
+    static constexpr bool kWide      = WIDE && kTwoPerWave;
+    static constexpr int  ROUND_CELLS = kTwoPerWave ? (kWide ? 16 : 8) : 2;
+    static constexpr int  ROUNDS     = NCELLS / ROUND_CELLS;
+    static constexpr int  THREADS    = kTwoPerWave ? (kWide ? 512 : 256) : 2 * TPW;
+    static constexpr bool kWaveSync  = kTwoPerWave || TPW == 64; // transposes stay inside one wave
+    static constexpr int  CELL_LDS   = N * N * LN;
+  };
+
+  // fused post-operations (what the reference passes as operation_after_loop)
+  enum BrickMode
+  {
+    kPlain    = 0, // out = A src                                   (vmult, laplace_operator.h:573)
+    kResidual = 1, // out = a - A src                               (vmult_residual, :605)
+    kCheb     = 2, // out = x + f1 (x - out) + f2 b (a - A x)       (PreconditionChebyshev update)
+    kChebFirst = 3, // out = x + f2 b (a - A x)                     (first step: no x_old term)
+    kChebZeroOld = 4, // out = x + f1 x + f2 b (a - A x)             (x_old known to be zero)
+    // start of PreconditionChebyshev::vmult (zero initial guess): the first iterate x_1 = f0 b a is
+    // never stored -- the first loop iteration computes it while gathering (kChebInit, x_old = 0),
+    // the second one recomputes it as its x_old (kChebOldInit); separable kernel only
+    kChebInit    = 5, // x := f0 b a ; out = x + f1 x + f2 b (a - A x)
+    kChebOldInit = 6, // out = x + f1 (x - f0 b a) + f2 b (a - A x)
+    // V-cycle: the residual a - A x is only needed restricted to the next coarser level
+    // (multigrid_solver.h:663-668).  Every brick restricts the residual values it completes (its
+    // LAST points, everything else masked to zero) with the transposed embedding and adds the
+    // (PB p + 1)^3 coarse values to the coarse vector; the residual itself is never stored.
+    kResidualRestrict = 7,
+    // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
+    kNoStore   = 8, // rounds only, no write-out
+    kNoCompute = 9, // write-out only, no rounds
+    kInitOnly  = 10, // prologue only
+    kNoScatter = 11, // rounds without the accumulator update and its barrier, no write-out
+    kNoBarrier = 12  // rounds without the per-round barrier, no write-out
+  };
+
+  template <typename T>
+  struct BrickPost
+  {
+    const T *a;       // kResidual: rhs ; kCheb: rhs b of the smoother
+    const T *b;       // kCheb: inverse diagonal
+    const T *old;     // kCheb: previous iterate x_old (may alias out: read before written)
+    T       *out;     // result vector
+    T       *partial; // carrier of partial sums between colour launches (may alias out)
+    T        f1, f2, f0;
+    T              *coarse;        // kResidualRestrict: coarse-level vector the restriction adds to
+    const uint32_t *coarse_blocks; // kResidualRestrict: coarse entity table of the brick's parents
+  };
+
+  // Entity table word: bits 0..29 first DoF of the entity, bit 30 FIRST, bit 31 LAST;
+  // 0xFFFFFFFF = constrained / empty entity (the host refuses levels with >= 2^30 - 1 DoFs)
+  __device__ __forceinline__ uint32_t ent_index(uint32_t w) { return w & 0x3FFFFFFFu; }
+  __device__ __forceinline__ uint32_t ent_flags_of(uint32_t w) { return w >> 30; }
+
+  // wave-local ordering of LDS traffic: the two cells of a wave exchange data only among the
+  // lanes of that wave, which execute in lockstep; the LDS services one wave's operations in
+  // order, so a compiler-level barrier is all that is needed between the transposes
+  __device__ __forceinline__ void wave_sync()
+  {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // workgroup barrier that orders LDS traffic only: global loads issued earlier (the prefetch of
+  // the next round's source values) stay in flight across it, which __syncthreads() would drain
+  __device__ __forceinline__ void lds_barrier()
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  template <int N, typename T>
+  __device__ __forceinline__ void eo_split(const T (&x)[N], T (&xe)[N / 2 + 1], T (&xo)[N / 2 + 1])
+  {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+      {
+        xe[i] = x[i] + x[N - 1 - i];
+        xo[i] = x[i] - x[N - 1 - i];
+      }
+    xe[H] = (N % 2) ? x[H] : T(0); // middle entry
+    xo[H] = T(0);
+  }
+
+  template <int N, typename T>
+  __device__ __forceinline__ void eo_apply(const EOMat<T> &A, const T (&xe)[N / 2 + 1], const T (&xo)[N / 2 + 1],
+                                           T (&y)[N])
+  {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+      {
+        T r0 = A.ee[a * H] * xe[0];
+        T r1 = A.eo[a * H] * xo[0];
+#pragma unroll
+        for (int i = 1; i < H; ++i)
+          {
+            r0 = fma(A.ee[a * H + i], xe[i], r0);
+            r1 = fma(A.eo[a * H + i], xo[i], r1);
+          }
+        if (N % 2)
+          r0 = fma(A.mc[a], xe[H], r0);
+        y[a]         = r0 + r1;
+        y[N - 1 - a] = r0 - r1;
+      }
+    if (N % 2)
+      {
+        T r = A.mhh * xe[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+          r = fma(A.mc[i], xe[i], r);
+        y[H] = r;
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Restriction of the brick array in place (kResidualRestrict).  acc holds the G^3 fine values of
+  // the brick (G = NB p + 1) whose cells are the children of PB^3 parents (PB = NB / 2): three 1D
+  // sweeps with the transposed embedding P1 (one line per thread, values in registers, outputs
+  // written over the head of the line), then the (PB p + 1)^3 coarse values are added to the
+  // coarse vector through the coarse entity table of the brick.  Bricks of one colour launch are
+  // not adjacent, so their parents share no coarse DoF: plain read-modify-write.
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T>
+  __device__ __forceinline__ void restrict_line(const T *__restrict__ p1, const T (&r)[BCfg<P>::G],
+                                                T (&out)[(BCfg<P>::NB / 2) * P + 1])
+  {
+    constexpr int N = P + 1, M = 2 * P + 1, PB = BCfg<P>::NB / 2;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+      {
+        T o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          {
+            T s = p1[j] * r[pb * 2 * P];
+#pragma unroll
+            for (int a = 1; a < M; ++a)
+              s = fma(p1[a * N + j], r[pb * 2 * P + a], s);
+            o[j] = s;
+          }
+        if (pb == 0)
+          {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              out[j] = o[j];
+          }
+        else
+          {
+            // the node shared by the two parents was counted by both (unit weight in each)
+            out[pb * P] += o[0] - r[pb * 2 * P];
+#pragma unroll
+            for (int j = 1; j < N; ++j)
+              out[pb * P + j] = o[j];
+          }
+      }
+  }
+
+  template <int P, typename T, int NT>
+  __device__ __forceinline__ void restrict_brick(int tid, T *acc, const T *__restrict__ p1, T *__restrict__ coarse,
+                                                 const uint32_t *__restrict__ ctab)
+  {
+    using C           = BCfg<P>;
+    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1;
+    // x: lines (y, z)
+    for (int l = tid; l < G * G; l += NT)
+      {
+        T r[G], o[CN];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          r[i] = acc[l * G + i];
+        restrict_line<P, T>(p1, r, o);
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          acc[l * G + j] = o[j];
+      }
+    __syncthreads();
+    // y: lines (x < CN, z)
+    for (int l = tid; l < CN * G; l += NT)
+      {
+        const int x = l % CN, z = l / CN;
+        T         r[G], o[CN];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          r[i] = acc[(z * G + i) * G + x];
+        restrict_line<P, T>(p1, r, o);
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          acc[(z * G + j) * G + x] = o[j];
+      }
+    __syncthreads();
+    // z: lines (x, y) with x, y < CN; the results go to the coarse vector
+    auto layer = [](int a, int &e, int &o, int &n) {
+      const int q = a / P, rr = a - q * P;
+      e           = 2 * q + (rr != 0);
+      o           = rr ? rr - 1 : 0;
+      n           = rr ? P - 1 : 1;
+    };
+    for (int l = tid; l < CN * CN; l += NT)
+      {
+        const int x = l % CN, y = l / CN;
+        T         r[G], o[CN];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          r[i] = acc[(i * G + y) * G + x];
+        restrict_line<P, T>(p1, r, o);
+        int ex, ey, ox, oy, nx, ny;
+        layer(x, ex, ox, nx);
+        layer(y, ey, oy, ny);
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          {
+            int ez, oz, nz;
+            layer(j, ez, oz, nz);
+            const uint32_t w = ctab[(ez * CE1 + ey) * CE1 + ex];
+            if (w != kInvalid)
+              {
+                T *c = coarse + w + (uint32_t)((oz * ny + oy) * nx + ox);
+                *c += o[j];
+              }
+          }
+      }
+  }
+} // namespace mgx

@@ -245,4 +245,50 @@ namespace mgx
     (void)n_dofs;
     return true;
   }
+
+  void build_item_map(int p, std::vector<uint32_t> &map)
+  {
+    const int NB = p <= 4 ? 4 : 2, G = NB * p + 1, E1 = 2 * NB + 1, P3 = p * p * p;
+    map.clear();
+    map.reserve((size_t)G * G * G);
+    auto word = [](int slot, int pnt, int off) { return (uint32_t)slot | ((uint32_t)pnt << 10) | ((uint32_t)off << 23); };
+    // part A: cell blocks
+    for (int m = 0; m < NB * NB * NB; ++m)
+      {
+        const int bx = compact3(m), by = compact3(m >> 1), bz = compact3(m >> 2);
+        for (int kk = 0, j = 0; j < 8; ++j)
+          {
+            const int cx = 1 + (j & 1), cy = 1 + ((j >> 1) & 1), cz = 1 + (j >> 2);
+            const int nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
+            for (int kl = 0; kl < nx * ny * nz; ++kl, ++kk)
+              {
+                const int ox = kl % nx, oy = (kl / nx) % ny, oz = kl / (nx * ny);
+                const int lx = cx == 1 ? 1 + ox : p, ly = cy == 1 ? 1 + oy : p, lz = cz == 1 ? 1 + oz : p;
+                const int slot = ((2 * bz + cz) * E1 + 2 * by + cy) * E1 + 2 * bx + cx;
+                const int pnt  = ((bz * p + lz) * G + by * p + ly) * G + bx * p + lx;
+                map.push_back(word(slot, pnt, kl));
+              }
+            (void)kk;
+          }
+      }
+    (void)P3;
+    // part B: the low faces z = 0, y = 0 (z > 0), x = 0 (y, z > 0); their DoFs belong to the cell
+    // blocks of neighbouring bricks
+    auto point = [&](int gx, int gy, int gz) {
+      const int rx = gx % p, ry = gy % p, rz = gz % p;
+      const int ex = 2 * (gx / p) + (rx != 0), ey = 2 * (gy / p) + (ry != 0), ez = 2 * (gz / p) + (rz != 0);
+      const int nx = rx ? p - 1 : 1, ny = ry ? p - 1 : 1;
+      const int ox = rx ? rx - 1 : 0, oy = ry ? ry - 1 : 0, oz = rz ? rz - 1 : 0;
+      map.push_back(word((ez * E1 + ey) * E1 + ex, (gz * G + gy) * G + gx, (oz * ny + oy) * nx + ox));
+    };
+    for (int gy = 0; gy < G; ++gy)
+      for (int gx = 0; gx < G; ++gx)
+        point(gx, gy, 0);
+    for (int gz = 1; gz < G; ++gz)
+      for (int gx = 0; gx < G; ++gx)
+        point(gx, 0, gz);
+    for (int gz = 1; gz < G; ++gz)
+      for (int gy = 1; gy < G; ++gy)
+        point(0, gy, gz);
+  }
 } // namespace mgx

@@ -24,4 +24,12 @@ namespace mgx
   bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
                     const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, BrickHost &out,
                     std::string &why);
+
+  // Item table of the macro-element kernel (mgx_macro.hip), one per degree: the (NB p + 1)^3 points
+  // of a brick in write-out order -- first the p^3 DoFs on the high side / in the interior of each
+  // cell, cell after cell in Morton order and entity after entity inside a cell ({hex, x-face,
+  // y-face, xy-line, z-face, xz-line, yz-line, vertex}), then the points on the three low faces of
+  // the brick.  Word: bits 0..9 entity slot of the brick, 10..22 brick point (z G + y) G + x,
+  // 23..31 offset inside the entity.
+  void build_item_map(int p, std::vector<uint32_t> &map);
 } // namespace mgx

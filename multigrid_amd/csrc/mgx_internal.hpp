@@ -49,6 +49,7 @@ namespace mgx
     uint32_t  colour_start[33] = {0};
     uint32_t *ent_base  = nullptr; // device [n_bricks * 729]
     uint8_t  *ent_flags = nullptr; // device [n_bricks * 729]  bit0 FIRST, bit1 LAST
+    uint32_t *item_map  = nullptr; // device [(NB p + 1)^3]: write-out order of the macro-element kernel
     std::vector<uint32_t> order; // host: colour-sorted position -> brick index in cell order
     bool      available() const { return n_bricks > 0; }
   };
@@ -71,6 +72,10 @@ namespace mgx
     double    coef[6]       = {0, 0, 0, 0, 0, 0};
     BrickData bricks;
     bool      separable     = true; // Cartesian constant-coefficient fast path of the brick loop
+    // inverse diagonal per brick item ((NB p + 1)^3 values in item order) if it is the same for
+    // every brick (uniform mesh), else nullptr: the macro-element kernel then reads it from
+    // registers instead of streaming inv_diag (mgx_macro.hip, DTAB)
+    void     *diag_items    = nullptr;
   };
 
   struct TransferData
@@ -109,6 +114,16 @@ namespace mgx
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr,
                          double f0 = 0., void *coarse = nullptr, const uint32_t *coarse_blocks = nullptr);
+  // macro-element form of the separable brick loop (mgx_macro.hip), one translation unit per number
+  // type; false: mode / degree not covered (the caller falls back to the cell-by-cell form)
+  bool launch_macro_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
+                             const void *b, void *out, void *partial, double f1, double f2, const void *old,
+                             double f0, void *coarse, const uint32_t *coarse_blocks);
+  bool launch_macro_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
+                             const void *b, void *out, void *partial, double f1, double f2, const void *old,
+                             double f0, void *coarse, const uint32_t *coarse_blocks);
+  void macro_diag_table_f64(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
+  void macro_diag_table_f32(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)

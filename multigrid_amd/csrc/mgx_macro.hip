@@ -1,0 +1,731 @@
+// mgx_macro.hip -- the production cell loop of the separable (Cartesian, constant coefficient)
+// operator in macro-element form: sum factorisation over the whole brick instead of cell by cell.
+//
+// Why this is the same operator.  On a Cartesian mesh with one constant diagonal coefficient the
+// cell matrix is  A_cell = sum_d c_d (M x M x K_d)  with the 1D matrices M = S^T W S and
+// K = S^T D^T W D S (mgx_brick.hip, laplace_operator.h:374-387, 447-491).  A brick is a tensor
+// product of NB cells per direction, so the sum of its NB^3 cell matrices factorises as well:
+//     sum_cells A_cell = c_x (Mb x Mb x Kb) + c_y (Mb x Kb x Mb) + c_z (Kb x Mb x Mb)
+// where Mb, Kb are the 1D matrices *assembled* over the NB cells of a line (G = NB p + 1 points,
+// block-banded: one dense (p+1)^2 block per cell, neighbouring blocks overlap in one point).
+// The brick's G^3 results are therefore three sweeps over G^2 lines of G points,
+//     t1 = Mb_x u, k1 = Kb_x u ; t2 = Mb_y t1, s2 = c_x Mb_y k1 + c_y Kb_y t1 ;
+//     out = Mb_z s2 + c_z Kb_z t2,
+// exactly the sweeps of brick_sep_kernel but on lines that run through the whole brick: a line
+// that is shared by the cells on both sides of a face is swept once instead of once per cell
+// ((G/(NB (p+1)))^2 = 0.72 of the flops at p = 4), the result comes out assembled (no LDS
+// accumulator, no parity rounds, no read-modify-write), and the two LDS transposes are per brick
+// instead of per cell (0.6 of the LDS traffic).  Constrained DoFs enter as zeros and their rows are
+// never written, as in read_dof_values_compressed / distribute_local_to_global_compressed
+// (vector_access_reduced.h:174-179, 431-433).
+//
+// Schedule of one 320-thread workgroup (p = 4 and p = 8: G = 17, 289 lines):
+//   1. gather: the G^3 source values are loaded entity by entity (consecutive work items are
+//      consecutive DoFs of one mesh entity = consecutive addresses) through a per-degree item table
+//      (item -> entity slot, offset inside the entity, brick point) and written to the LDS array U;
+//      every thread keeps the values it loaded in registers: the write-out below uses the same
+//      item -> thread mapping, so the fused Chebyshev update has its x_i without a second read.
+//   2. x sweep, thread = line (y,z): reads its line of U, writes Mb u to W and Kb u back to its own
+//      line of U (in place: no other thread touches that line in this phase).
+//   3. y sweep, thread = line (x,z): reads its lines of W and U, writes t2 / s2 back in place.
+//   4. z sweep, thread = line (x,y): reads its lines of W and U, writes the result to W.
+//   5. write-out entity by entity with the fused post-operation (BrickMode), as store_brick does:
+//      pass 1 loads everything that has to be read, pass 2 only stores.
+// One workgroup barrier between the phases (5 per brick, against 8 + 1 per cell round before).
+// LDS: two fp64 arrays of 17^3 + the 729-word entity table = 81.5 kB: two workgroups per CU.
+#include "mgx_brick_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#ifndef MGX_MACRO_CHUNK
+#define MGX_MACRO_CHUNK 4
+#endif
+#ifndef MGX_MACRO_CHUNK_CHEB
+#define MGX_MACRO_CHUNK_CHEB 3
+#endif
+#ifndef MGX_MACRO_T
+#define MGX_MACRO_T double
+#endif
+
+#ifdef MGX_MACRO_STAMPS
+// Diagnostic build only (make MACROFLAGS=-DMGX_MACRO_STAMPS): thread 0 of every workgroup records
+// s_memtime at the phase boundaries; tools/macro_stamps.py reads them back.  Never compiled into
+// the production library.
+__device__ unsigned long long g_mgx_stamps[8192 * 16];
+#define MGX_STAMP(k)                                                                    \
+  do                                                                                    \
+    {                                                                                   \
+      if (threadIdx.x == 0 && blockIdx.x < 8192)                                        \
+        g_mgx_stamps[blockIdx.x * 16 + (k)] = ((k) == 15 || (k) == 13) ? __builtin_amdgcn_s_memrealtime() \
+                                                        : __builtin_amdgcn_s_memtime();  \
+    }                                                                                   \
+  while (0)
+extern "C" int mgx_debug_read_stamps(unsigned long long *host, int n_blocks)
+{
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mgx_stamps), sizeof(unsigned long long) * 16 * n_blocks);
+}
+// stamps inside the brick loop: recorded for the fourth brick of the workgroup only (steady state)
+#define MGX_STAMP_IT(k)      \
+  do                         \
+    {                        \
+      if (mgx_iter == 3)     \
+        MGX_STAMP(k);        \
+    }                        \
+  while (0)
+#define MGX_STAMP_NEXT() ++mgx_iter
+#define mgx_iter_is(k) (mgx_iter == (k))
+#else
+#define MGX_STAMP(k) ((void)0)
+#define MGX_STAMP_IT(k) ((void)0)
+#define MGX_STAMP_NEXT() ((void)0)
+#define mgx_iter_is(k) false
+#endif
+
+namespace mgx
+{
+  template <int P, typename T>
+  struct MCfg
+  {
+    using C = BCfg<P>;
+    static constexpr int NB = C::NB, G = C::G, NE = C::NE, N = P + 1;
+    static constexpr int LINES   = G * G;
+    // One thread per line, except that a small remainder of lines beyond a multiple of 64 goes to
+    // the first wave as a second pass instead of to a wave of its own (G = 17: 289 lines on 256
+    // threads).  Measured on MI355X (tools/experiments/occupancy_probe.hip): workgroups of 5 or 6
+    // waves are admitted one per CU only as soon as they use more than 48 kB of LDS, workgroups of
+    // 2, 3, 4 or 8 waves two per CU up to 80 kB each.
+    static constexpr int THREADS = (LINES > 128 && LINES % 64 <= 40) ? (LINES / 64) * 64 : ((LINES + 63) / 64) * 64;
+    static constexpr int NPTS    = G * G * G;
+    static constexpr int IT      = (NPTS + THREADS - 1) / THREADS; // items per thread
+    static constexpr int TSZ     = (2 * NE * 4 + (int)sizeof(T) - 1) / (int)sizeof(T); // two entity tables, in T's
+    static constexpr int ASZ     = NPTS > TSZ ? NPTS : TSZ;                            // LDS array size
+    static constexpr int LDS     = 2 * ASZ * (int)sizeof(T);
+    static constexpr int WG_LDS  = 163840 / LDS;
+    static constexpr int WG_WAVE = 32 / (THREADS / 64);
+    static constexpr int WGS     = WG_LDS < WG_WAVE ? (WG_LDS < 8 ? WG_LDS : 8) : (WG_WAVE < 8 ? WG_WAVE : 8);
+    static constexpr int WAVES   = WGS * (THREADS / 64);
+    // waves per SIMD the register allocation must allow for WGS workgroups per CU (at most 4: 128
+    // VGPRs are needed for the line sweeps)
+    static constexpr int MINW = (WAVES + 3) / 4 > 4 ? 4 : (WAVES + 3) / 4;
+  };
+
+  // out = Ab in for the assembled 1D matrix of A over the NB cells of a line, cell block by cell
+  // block in even-odd form (coefficients wave-uniform: scalar registers)
+  template <int P, typename T>
+  __device__ __forceinline__ void macro_apply(const EOMat<T> &A, const T (&in)[BCfg<P>::G], T (&out)[BCfg<P>::G])
+  {
+    constexpr int N = P + 1, NB = BCfg<P>::NB, H1 = N / 2 + 1;
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      {
+        T seg[N], xe[H1], xo[H1], y[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = in[c * P + i];
+        eo_split<N, T>(seg, xe, xo);
+        eo_apply<N, T>(A, xe, xo, y);
+        if (c == 0)
+          out[0] = y[0];
+        else
+          out[c * P] += y[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+          out[c * P + i] = y[i];
+      }
+  }
+
+  // the same for two matrices applied to one line (the even-odd split is shared)
+  template <int P, typename T>
+  __device__ __forceinline__ void macro_apply2(const EOMat<T> &A, const EOMat<T> &Bm, const T (&in)[BCfg<P>::G],
+                                               T (&oa)[BCfg<P>::G], T (&ob)[BCfg<P>::G])
+  {
+    constexpr int N = P + 1, NB = BCfg<P>::NB, H1 = N / 2 + 1;
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      {
+        T seg[N], xe[H1], xo[H1], y[N], z[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = in[c * P + i];
+        eo_split<N, T>(seg, xe, xo);
+        eo_apply<N, T>(A, xe, xo, y);
+        eo_apply<N, T>(Bm, xe, xo, z);
+        if (c == 0)
+          {
+            oa[0] = y[0];
+            ob[0] = z[0];
+          }
+        else
+          {
+            oa[c * P] += y[0];
+            ob[c * P] += z[0];
+          }
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+          {
+            oa[c * P + i] = y[i];
+            ob[c * P + i] = z[i];
+          }
+      }
+  }
+
+  // item table word: bits 0..9 entity slot of the brick, 10..22 brick point, 23..31 offset in the entity
+  __device__ __forceinline__ uint32_t item_slot(uint32_t m) { return m & 1023u; }
+  __device__ __forceinline__ uint32_t item_point(uint32_t m) { return (m >> 10) & 8191u; }
+  __device__ __forceinline__ uint32_t item_offset(uint32_t m) { return m >> 23; }
+
+  // Vector access through buffer descriptors: address = (scalar base) + (32-bit byte offset in one
+  // VGPR), no 64-bit address arithmetic and no VGPR pair per access in flight; offsets at or beyond
+  // the vector's size are out of range: such a load returns zero and such a store is dropped
+  // without touching memory, which is how constrained / masked items are handled (kOob).  The host
+  // only selects this kernel for vectors below 4 GB.
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+  constexpr uint32_t kOob = 0xFFFFFFFFu;
+  __device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes)
+  {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+  }
+  __device__ __forceinline__ double buf_ld(rsrc_t r, uint32_t off, double)
+  {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+  }
+  __device__ __forceinline__ float buf_ld(rsrc_t r, uint32_t off, float)
+  {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  }
+  __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t off, double v)
+  {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, off, 0, 0);
+  }
+  __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t off, float v)
+  {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, off, 0, 0);
+  }
+
+  template <typename T>
+  struct PostRsrc
+  {
+    rsrc_t a, b, old, out, partial;
+  };
+
+  // The fused post-operation on one assembled value (what the reference passes as
+  // operation_after_loop, laplace_operator.h:723-741), split into the part that issues the loads
+  // and the part that consumes them, so that the loads of the next chunk of items can be in flight
+  // while a chunk is computed and stored.
+  template <typename T>
+  struct PostOps
+  {
+    T pv, av, bv, ov; // partial sum of earlier launches, operands of the post-operation
+  };
+
+  // w = entity table word (bit 30 FIRST, bit 31 LAST), off = byte offset of the DoF
+  template <typename T, int MODE, bool DTAB>
+  __device__ __forceinline__ void post_issue(const PostRsrc<T> &R, uint32_t w, uint32_t off, PostOps<T> &o)
+  {
+    const bool valid        = w != kInvalid;
+    const bool need_partial = valid && !(w & 0x40000000u); // not FIRST
+    const bool last         = valid && (w >> 31);
+    o.pv = o.av = o.bv = o.ov = T(0);
+    const uint32_t ol = last ? off : kOob;
+    // partial sums of earlier colour launches exist on the brick surface only: whole waves of
+    // interior items skip the load
+    if (__builtin_amdgcn_ballot_w64(need_partial) != 0)
+      o.pv = buf_ld(R.partial, need_partial ? off : kOob, T());
+    if (MODE != kPlain)
+      o.av = buf_ld(R.a, ol, T());
+    if (MODE >= kCheb && MODE <= kChebOldInit && !DTAB)
+      o.bv = buf_ld(R.b, ol, T());
+    if (MODE == kCheb)
+      o.ov = buf_ld(R.old, ol, T());
+  }
+
+  // val = assembled value, xi = source value at this DoF (kept in registers since the gather)
+  // bv = inverse diagonal at this DoF (loaded with the operands, or from the per-item table)
+  template <typename T, int MODE>
+  __device__ __forceinline__ T post_finish(const BrickPost<T> &post, const PostOps<T> &o, T bv, bool last, T val, T xi)
+  {
+    val += o.pv; // out-of-range loads returned zero
+    if (MODE == kPlain)
+      return val;
+    else if (MODE == kResidual || MODE == kResidualRestrict)
+      return last ? o.av - val : val;
+    else
+      {
+        T ov = o.ov;
+        if (MODE == kChebOldInit)
+          ov = post.f0 * bv * o.av; // the x_1 of the previous iteration, recomputed (bitwise the same)
+        T xn = xi + post.f2 * bv * (o.av - val);
+        if (MODE == kCheb || MODE == kChebOldInit)
+          xn += post.f1 * (xi - ov);
+        else if (MODE == kChebZeroOld || MODE == kChebInit)
+          xn += post.f1 * xi;
+        return last ? xn : val;
+      }
+  }
+
+  // Persistent, software-pipelined: a workgroup walks over the bricks b = blockIdx.x + j gridDim.x
+  // of the colour launch.  While brick b is swept, the entity table of the next brick is in flight
+  // (three words per thread); as soon as the z sweep has freed the array U, that table is parked
+  // in U's space, the gather of the next brick is issued from it, and the write-out of brick b
+  // runs with those loads in flight.  Afterwards the table moves to its own buffer and the
+  // gathered values to U.  A brick's two round trips to memory before the first sweep (table,
+  // source) are hidden this way; the item table words stay in registers for all bricks.
+  //
+  // DTAB: the inverse diagonal is not streamed.  On a uniform Cartesian mesh it takes one value per
+  // position of a DoF inside the cell period, i.e. per item of the brick (verified against the
+  // stored vector when the diagonal is computed, macro_diag_table below); every thread holds the
+  // values of its items in registers for all bricks.  One vector stream less in the fused
+  // Chebyshev iterations (4 instead of 5 accesses per DoF).
+  template <int P, typename T, int MODE, bool DTAB>
+  __global__ void __launch_bounds__((MCfg<P, T>::THREADS), (MCfg<P, T>::MINW))
+    brick_macro_kernel(const T *__restrict__ src, uint32_t brick_first, uint32_t brick_count,
+                       const uint32_t *__restrict__ ent_base, const uint32_t *__restrict__ item_map,
+                       const Basis1D<T> *__restrict__ B, T c0, T c1, T c2, BrickPost<T> post, uint32_t vec_bytes)
+  {
+    using C              = MCfg<P, T>;
+    constexpr int G      = C::G;
+    constexpr int NT     = C::THREADS;
+    constexpr int NPTS   = C::NPTS;
+    constexpr int IT     = C::IT;
+    constexpr int LINES  = C::LINES;
+    constexpr int NEW    = (C::NE + NT - 1) / NT; // entity words per thread
+    // the fused Chebyshev forms need the source value again at write-out time
+    constexpr bool kKeepX = MODE >= kCheb && MODE <= kChebOldInit;
+    constexpr int  NG     = (MODE == kChebInit && !DTAB) ? 2 : 1; // operands gathered per value
+    // two arrays of G^3 values and nothing else: 78.6 kB in fp64 at G = 17, two workgroups per CU.
+    // The entity table of a brick has no LDS of its own: it is needed before the first sweep (gather)
+    // and after the last one (write-out), when one of the arrays is free, and rests in registers
+    // (three words per thread) in between.
+    // (low degrees: the arrays are padded to hold two parked tables)
+    __shared__ T U[C::ASZ];
+    __shared__ T W[C::ASZ];
+
+    const int tid = threadIdx.x;
+    uint32_t  b   = blockIdx.x;
+    if (b >= brick_count)
+      return;
+    MGX_STAMP(0);
+    MGX_STAMP(15);
+    auto live = [&](int it) { return (it + 1) * NT <= NPTS || tid + it * NT < NPTS; };
+    // item table words: the same for every brick, resident in registers
+    uint32_t mw[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+      {
+        const int i = tid + it * NT;
+        mw[it]      = item_map[i < NPTS ? i : 0];
+      }
+    T dv[DTAB ? IT : 1]; // inverse diagonal of this thread's items
+    if (DTAB)
+      {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+          {
+            const int i = tid + it * NT;
+            dv[it]      = post.b[i < NPTS ? i : 0]; // DTAB: post.b is the item-ordered table
+          }
+      }
+    const rsrc_t      rsrc = make_rsrc(src, vec_bytes);
+    const PostRsrc<T> R{make_rsrc(post.a, vec_bytes), make_rsrc(post.b, vec_bytes), make_rsrc(post.old, vec_bytes),
+                        make_rsrc(post.out, vec_bytes), make_rsrc(post.partial, vec_bytes)};
+    const EOMat<T>   &M = B->mass, &K = B->lapl;
+
+    uint32_t ec[NEW], en[NEW]; // entity table words of the current / the next brick
+    auto table_load = [&](uint32_t brick, uint32_t(&e)[NEW]) {
+#pragma unroll
+      for (int j = 0; j < NEW; ++j)
+        {
+          const int i = tid + j * NT;
+          e[j]        = ent_base[(size_t)(brick_first + brick) * C::NE + (i < C::NE ? i : 0)];
+        }
+    };
+    auto table_store = [&](uint32_t *E, const uint32_t(&e)[NEW]) {
+#pragma unroll
+      for (int j = 0; j < NEW; ++j)
+        if (tid + j * NT < C::NE)
+          E[tid + j * NT] = e[j];
+    };
+    // read_dof_values_compressed through the entity table E: issues the loads of this thread's
+    // items (constrained entity: out of range, reads zero -- vector_access_reduced.h:174-179)
+    T    g[NG][IT];
+    auto gather_issue = [&](const uint32_t *E) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+        {
+          g[0][it] = T(0);
+          if (NG == 2)
+            g[NG - 1][it] = T(0);
+          if (live(it))
+            {
+              const uint32_t m = mw[it], w = E[item_slot(m)];
+              const uint32_t off = w != kInvalid ? (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T) : kOob;
+              if (MODE == kChebInit && !DTAB)
+                {
+                  g[0][it]      = buf_ld(R.b, off, T());
+                  g[NG - 1][it] = buf_ld(R.a, off, T());
+                }
+              else if (MODE == kChebInit)
+                g[0][it] = buf_ld(R.a, off, T());
+              else
+                g[0][it] = buf_ld(rsrc, off, T());
+            }
+        }
+    };
+    T    xs[kKeepX ? IT : 1];
+    auto gather_land = [&]() {
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+        {
+          T v = g[0][it];
+          if (MODE == kChebInit) // x_1 = (1/theta) D^-1 b, never stored
+            v = DTAB ? post.f0 * dv[DTAB ? it : 0] * g[0][it] : post.f0 * g[0][it] * g[NG - 1][it];
+          if (live(it))
+            U[item_point(mw[it])] = v;
+          if (kKeepX)
+            xs[it] = v;
+        }
+    };
+
+    // ---- prologue: table and source of the first brick ----
+    table_load(b, ec);
+    table_store(reinterpret_cast<uint32_t *>(W), ec);
+    __syncthreads();
+    MGX_STAMP(1);
+    gather_issue(reinterpret_cast<const uint32_t *>(W));
+    gather_land();
+    MGX_STAMP(2);
+    __syncthreads();
+
+#ifdef MGX_MACRO_STAMPS
+    int mgx_iter = 0;
+#endif
+    for (;;)
+      {
+        if (mgx_iter_is(4))
+          MGX_STAMP(11);
+        const uint32_t bn       = b + gridDim.x;
+        const bool     has_next = bn < brick_count;
+        MGX_STAMP_IT(3);
+        if (has_next)
+          table_load(bn, en); // in flight during the sweeps
+        // keep what is derived from the item words (LDS addresses, offsets) out of the registers
+        // that live across the sweeps: the compiler must not hoist it out of the brick loop
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+          asm volatile("" : "+v"(mw[it]));
+        // ---- x sweep: line l = (y,z), contiguous; M u -> W, K u -> U in place ----
+#pragma unroll 1
+        for (int l = tid; l < LINES; l += NT)
+          {
+            T in[G], t1[G], k1[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              in[j] = U[l * G + j];
+            macro_apply2<P, T>(M, K, in, t1, k1);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              {
+                W[l * G + j] = t1[j];
+                U[l * G + j] = k1[j];
+              }
+          }
+        __syncthreads();
+        MGX_STAMP_IT(4);
+        // ---- y sweep: line l = (x,z), stride G ----
+#pragma unroll 1
+        for (int l = tid; l < LINES; l += NT)
+          {
+            const int base = (l / G) * (G * G) + l % G;
+            T         a[G], t2[G], s2[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              a[j] = W[base + j * G];
+            macro_apply2<P, T>(M, K, a, t2, s2);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              W[base + j * G] = t2[j];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              a[j] = U[base + j * G];
+            macro_apply<P, T>(M, a, t2);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              U[base + j * G] = fma(c0, t2[j], c1 * s2[j]);
+          }
+        __syncthreads();
+        MGX_STAMP_IT(5);
+        // ---- z sweep: line l = (x,y), stride G^2; result -> W ----
+#pragma unroll 1
+        for (int l = tid; l < LINES; l += NT)
+          {
+            T a[G], r[G], o[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              a[j] = W[l + j * (G * G)];
+            macro_apply<P, T>(K, a, r);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              a[j] = U[l + j * (G * G)];
+            macro_apply<P, T>(M, a, o);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              W[l + j * (G * G)] = fma(c2, r[j], o[j]);
+          }
+        __syncthreads();
+        MGX_STAMP_IT(6);
+        // ---- U is free: park both tables there and issue the next gather ----
+        uint32_t *ebase = reinterpret_cast<uint32_t *>(U), *E2 = ebase + C::NE;
+        table_store(ebase, ec);
+        if (has_next)
+          table_store(E2, en);
+        __syncthreads();
+        // (kChebInit gathers two operands per value: too many registers in flight next to the
+        // write-out, its gather is issued afterwards)
+        constexpr bool kPipeGather = MODE != kChebInit || DTAB;
+        if (has_next && kPipeGather)
+          gather_issue(E2);
+        MGX_STAMP_IT(7);
+
+        // ---- write-out with the fused post-operation, same item -> thread mapping as the gather.
+        // Chunks of kChunk items, software-pipelined: the loads of chunk c + 1 are issued before chunk c
+        // is computed and stored, so no load ever has to wait for an older store (vmcnt counts loads
+        // and stores in issue order) and two chunks of operands are in flight. ----
+        {
+          // (kCheb has four operands per item in flight: smaller chunks)
+          constexpr int kChunk = MODE == kCheb ? MGX_MACRO_CHUNK_CHEB : MGX_MACRO_CHUNK, NCH = (IT + kChunk - 1) / kChunk;
+          PostOps<T>    ops[2][kChunk];
+          auto          issue = [&](int c, PostOps<T>(&o)[kChunk]) {
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)
+              {
+                const int it = c * kChunk + j;
+                o[j].pv = o[j].av = o[j].bv = o[j].ov = T(0);
+                if (it < IT && live(it))
+                  {
+                    const uint32_t m = mw[it], w = ebase[item_slot(m)];
+                    post_issue<T, MODE, DTAB>(R, w, (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T), o[j]);
+                  }
+              }
+          };
+          issue(0, ops[0]);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            {
+              if (c + 1 < NCH)
+                issue(c + 1, ops[(c + 1) & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < kChunk; ++j)
+                {
+                  const int it = c * kChunk + j;
+                  if (it < IT && live(it))
+                    {
+                      // the table word and the offset are looked up again rather than kept in
+                      // registers next to the operands in flight
+                      const uint32_t m = mw[it], w = ebase[item_slot(m)];
+                      const uint32_t off  = w != kInvalid ? (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T) : kOob;
+                      const bool     last = w != kInvalid && (w >> 31);
+                      const T        res  = post_finish<T, MODE>(post, ops[c & 1][j], DTAB ? dv[DTAB ? it : 0] : ops[c & 1][j].bv,
+                                                                 last, W[item_point(m)], xs[kKeepX ? it : 0]);
+                      if (MODE == kResidualRestrict)
+                        {
+                          // completed residuals stay in W for the restriction, partial sums go to the
+                          // carrier, everything that is not a completed residual becomes zero
+                          if (__builtin_amdgcn_ballot_w64(!last) != 0)
+                            buf_st(R.partial, last ? kOob : off, res);
+                          W[item_point(m)] = last ? res : T(0);
+                        }
+                      else
+                        {
+                          // out-of-range offsets drop the store; whole waves of interior items skip
+                          // the carrier store
+                          buf_st(R.out, last ? off : kOob, res);
+                          if (__builtin_amdgcn_ballot_w64(!last) != 0)
+                            buf_st(R.partial, last ? kOob : off, res);
+                        }
+                    }
+                }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        MGX_STAMP_IT(8);
+        if (MODE == kResidualRestrict)
+          {
+            constexpr int CE1 = C::NB + 1; // 2 PB + 1
+            __syncthreads();
+            restrict_brick<P, T, NT>(tid, W, B->P1, post.coarse,
+                                     post.coarse_blocks + (size_t)(brick_first + b) * (CE1 * CE1 * CE1));
+          }
+        if (!has_next)
+          break;
+        if (!kPipeGather)
+          gather_issue(E2);
+        __syncthreads(); // everyone is done with the parked tables and with W
+#pragma unroll
+        for (int j = 0; j < NEW; ++j)
+          ec[j] = en[j];
+        gather_land();
+        MGX_STAMP_IT(9);
+        __syncthreads();
+        MGX_STAMP_IT(10);
+        b = bn;
+        MGX_STAMP_NEXT();
+      }
+#ifdef MGX_MACRO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MGX_STAMP(14);
+    MGX_STAMP(13);
+#endif
+  }
+
+  // ------------------------------------------------------------------------------------------
+  static uint32_t macro_cus()
+  {
+    static const uint32_t n = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (const char *e = std::getenv("MGX_MACRO_WG_PER_CU_X16")) // tuning aid: grid = value/16 workgroups per CU
+        return (uint32_t)std::max(1, cus * std::atoi(e) / 16);
+      return (uint32_t)std::max(1, cus);
+    }();
+    return n;
+  }
+
+  template <int P, typename T, int MODE>
+  static void macro_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post)
+  {
+    using C             = MCfg<P, T>;
+    const BrickData &bd = op.bricks;
+    for (int c = 0; c < bd.n_colours; ++c)
+      {
+        const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
+        if (count == 0)
+          continue;
+        // persistent workgroups: as many as are resident at once (WGS per CU), each walks over
+        // count / grid bricks
+        const uint32_t grid = std::min<uint32_t>(count, (uint32_t)C::WGS * macro_cus());
+        constexpr bool kUsesDiag = MODE >= kCheb && MODE <= kChebOldInit;
+        if (kUsesDiag && op.diag_items)
+          {
+            BrickPost<T> pt = post;
+            pt.b            = (const T *)op.diag_items;
+            hipLaunchKernelGGL((brick_macro_kernel<P, T, MODE, kUsesDiag>), dim3(grid), dim3(C::THREADS), 0, s, src, first,
+                               count, bd.ent_base, bd.item_map, (const Basis1D<T> *)op.basis, (T)op.coef[0],
+                               (T)op.coef[1], (T)op.coef[2], pt, (uint32_t)(op.n_dofs * sizeof(T)));
+          }
+        else
+          hipLaunchKernelGGL((brick_macro_kernel<P, T, MODE, false>), dim3(grid), dim3(C::THREADS), 0, s, src, first,
+                             count, bd.ent_base, bd.item_map, (const Basis1D<T> *)op.basis, (T)op.coef[0],
+                             (T)op.coef[1], (T)op.coef[2], post, (uint32_t)(op.n_dofs * sizeof(T)));
+      }
+  }
+
+  template <int P, typename T>
+  static void macro_modes(hipStream_t s, const OperatorData &op, int mode, const T *src, const BrickPost<T> &post)
+  {
+    switch (mode)
+      {
+        case kPlain: macro_launch<P, T, kPlain>(s, op, src, post); break;
+        case kResidual: macro_launch<P, T, kResidual>(s, op, src, post); break;
+        case kCheb: macro_launch<P, T, kCheb>(s, op, src, post); break;
+        case kChebFirst: macro_launch<P, T, kChebFirst>(s, op, src, post); break;
+        case kChebZeroOld: macro_launch<P, T, kChebZeroOld>(s, op, src, post); break;
+        case kChebInit: macro_launch<P, T, kChebInit>(s, op, src, post); break;
+        case kChebOldInit: macro_launch<P, T, kChebOldInit>(s, op, src, post); break;
+        case kResidualRestrict: macro_launch<P, T, kResidualRestrict>(s, op, src, post); break;
+        default: break;
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Item-ordered table of the inverse diagonal (DTAB).  collect: every brick writes the value of
+  // each of its unconstrained items into the table (all bricks write the same value if the diagonal
+  // is periodic); verify: any item of any brick that differs bitwise from the table raises the flag.
+  template <typename T, bool VERIFY>
+  __global__ void diag_table_kernel(const T *__restrict__ inv_diag, const uint32_t *__restrict__ ent_base,
+                                    const uint32_t *__restrict__ item_map, uint32_t ne, uint32_t npts, T *table,
+                                    uint32_t *flag)
+  {
+    const uint32_t brick = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < npts; i += blockDim.x)
+      {
+        const uint32_t m = item_map[i], w = ent_base[(size_t)brick * ne + item_slot(m)];
+        if (w == kInvalid)
+          continue;
+        const T v = inv_diag[ent_index(w) + item_offset(m)];
+        if (!VERIFY)
+          table[i] = v;
+        else
+          {
+            const T t = table[i];
+            bool    same;
+            if constexpr (sizeof(T) == 8)
+              same = __builtin_bit_cast(unsigned long long, v) == __builtin_bit_cast(unsigned long long, t);
+            else
+              same = __builtin_bit_cast(unsigned int, v) == __builtin_bit_cast(unsigned int, t);
+            if (!same)
+              atomicOr(flag, 1u);
+          }
+      }
+  }
+
+#define MGX_CAT2(a, b) a##b
+#define MGX_CAT(a, b) MGX_CAT2(a, b)
+  // builds the table into `table` (device, (NB p + 1)^3 values, zero-initialised by the caller);
+  // *flag_dev (device, zero-initialised) is nonzero afterwards if the diagonal is not periodic
+  void MGX_CAT(macro_diag_table_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev)
+  {
+    using T             = MGX_MACRO_T;
+    const BrickData &bd = op.bricks;
+    const uint32_t   nb = op.p <= 4 ? 4 : 2, g = nb * op.p + 1, npts = g * g * g, e1 = 2 * nb + 1, ne = e1 * e1 * e1;
+    hipLaunchKernelGGL((diag_table_kernel<T, false>), dim3(bd.n_bricks), dim3(256), 0, s, (const T *)op.inv_diag,
+                       bd.ent_base, bd.item_map, ne, npts, (T *)table, flag_dev);
+    hipLaunchKernelGGL((diag_table_kernel<T, true>), dim3(bd.n_bricks), dim3(256), 0, s, (const T *)op.inv_diag,
+                       bd.ent_base, bd.item_map, ne, npts, (T *)table, flag_dev);
+  }
+
+  // one translation unit per number type (Makefile: -DMGX_MACRO_T=double|float -DMGX_MACRO_SUFFIX=f64|f32)
+  bool MGX_CAT(launch_macro_loop_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, int mode, const void *src,
+                                                     const void *a, const void *b, void *out, void *partial,
+                                                     double f1, double f2, const void *old, double f0, void *coarse,
+                                                     const uint32_t *coarse_blocks)
+  {
+    using T = MGX_MACRO_T;
+    if (mode < kPlain || mode > kResidualRestrict || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFFFull)
+      return false;
+    BrickPost<T> post;
+    post.a             = (const T *)a;
+    post.b             = (const T *)b;
+    post.old           = (const T *)old;
+    post.out           = (T *)out;
+    post.partial       = (T *)partial;
+    post.f1            = (T)f1;
+    post.f2            = (T)f2;
+    post.f0            = (T)f0;
+    post.coarse        = (T *)coarse;
+    post.coarse_blocks = coarse_blocks;
+    switch (op.p)
+      {
+#ifdef MGX_MACRO_ONLY_P
+        case MGX_MACRO_ONLY_P: macro_modes<MGX_MACRO_ONLY_P, T>(s, op, mode, (const T *)src, post); break;
+#else
+        case 1: macro_modes<1, T>(s, op, mode, (const T *)src, post); break;
+        case 2: macro_modes<2, T>(s, op, mode, (const T *)src, post); break;
+        case 3: macro_modes<3, T>(s, op, mode, (const T *)src, post); break;
+        case 4: macro_modes<4, T>(s, op, mode, (const T *)src, post); break;
+        case 5: macro_modes<5, T>(s, op, mode, (const T *)src, post); break;
+        case 6: macro_modes<6, T>(s, op, mode, (const T *)src, post); break;
+        case 7: macro_modes<7, T>(s, op, mode, (const T *)src, post); break;
+        case 8: macro_modes<8, T>(s, op, mode, (const T *)src, post); break;
+        case 9: macro_modes<9, T>(s, op, mode, (const T *)src, post); break;
+#endif
+        default: return false;
+      }
+    return true;
+  }
+} // namespace mgx
