@@ -26,10 +26,19 @@ namespace mgx
                     std::string &why);
 
   // Item table of the macro-element kernel (mgx_macro.hip), one per degree: the (NB p + 1)^3 points
-  // of a brick in write-out order -- first the p^3 DoFs on the high side / in the interior of each
-  // cell, cell after cell in Morton order and entity after entity inside a cell ({hex, x-face,
-  // y-face, xy-line, z-face, xz-line, yz-line, vertex}), then the points on the three low faces of
-  // the brick.  Word: bits 0..9 entity slot of the brick, 10..22 brick point (z G + y) G + x,
-  // 23..31 offset inside the entity.
+  // of a brick in the order they are gathered and written out.  Entities are taken cell after cell
+  // in Morton order ({hex, x-face, y-face, xy-line, z-face, xz-line, yz-line, vertex} on the high
+  // side / in the interior of each cell), then the entities on the three low faces of the brick.
+  // First section: all pairs of DoFs (2k, 2k+1) of one entity -- adjacent in memory for every
+  // numbering that satisfies the entity-contiguity contract, so one lane moves both with a 16-byte
+  // access; second section: the last DoF of every entity of odd size.  Word: bits 0..9 entity
+  // slot of the brick, 10..22 brick point (z G + y) G + x, 23..31 offset inside the entity.
+  // MGX_MACRO_PAIRS=0 (default): no pair section, every DoF is a single item in entity order.
+  // Measured on MI355X (135M DoFs, p = 4): the 16-byte accesses of the pair section buy nothing for
+  // the plain form (107 vs 106 us per colour launch) and the scattered left-over singles cost the
+  // fused Chebyshev forms 10-20 % (180 vs 150 us); kept as a build option for other numberings.
+#ifndef MGX_MACRO_PAIRS
+#define MGX_MACRO_PAIRS 0
+#endif
   void build_item_map(int p, std::vector<uint32_t> &map);
 } // namespace mgx

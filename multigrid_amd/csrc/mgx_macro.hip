@@ -34,17 +34,19 @@
 // One workgroup barrier between the phases (5 per brick, against 8 + 1 per cell round before).
 // LDS: two fp64 arrays of 17^3 + the 729-word entity table = 81.5 kB: two workgroups per CU.
 #include "mgx_brick_device.hpp"
+#include "mgx_bricks.hpp" // MGX_MACRO_PAIRS
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdlib>
 
+// units (pairs of DoFs) per chunk of the write-out
 #ifndef MGX_MACRO_CHUNK
-#define MGX_MACRO_CHUNK 4
+#define MGX_MACRO_CHUNK (MGX_MACRO_PAIRS ? 3 : 4)
 #endif
 #ifndef MGX_MACRO_CHUNK_CHEB
-#define MGX_MACRO_CHUNK_CHEB 3
+#define MGX_MACRO_CHUNK_CHEB (MGX_MACRO_PAIRS ? 2 : 3)
 #endif
 #ifndef MGX_MACRO_T
 #define MGX_MACRO_T double
@@ -99,7 +101,18 @@ namespace mgx
     // 2, 3, 4 or 8 waves two per CU up to 80 kB each.
     static constexpr int THREADS = (LINES > 128 && LINES % 64 <= 40) ? (LINES / 64) * 64 : ((LINES + 63) / 64) * 64;
     static constexpr int NPTS    = G * G * G;
-    static constexpr int IT      = (NPTS + THREADS - 1) / THREADS; // items per thread
+    // item table (mgx_bricks.hpp): NPAIR pairs of adjacent DoFs, then NSINGLE single DoFs.  Entities
+    // with t cell-interior directions: C(3,t) NB^t (NB+1)^(3-t) of them, (p-1)^t DoFs each
+    static constexpr int ent_count(int t) { return (t == 0 || t == 3 ? 1 : 3) * ipow(NB, t) * ipow(NB + 1, 3 - t); }
+    static constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+    static constexpr int ent_size(int t) { return ipow(P - 1, t); }
+    static constexpr int NPAIR   = MGX_MACRO_PAIRS ? ent_count(0) * (ent_size(0) / 2) + ent_count(1) * (ent_size(1) / 2) +
+                                                     ent_count(2) * (ent_size(2) / 2) + ent_count(3) * (ent_size(3) / 2)
+                                                 : 0;
+    static constexpr int NSINGLE = NPTS - 2 * NPAIR;
+    static constexpr int JP      = (NPAIR + THREADS - 1) / THREADS;   // pairs per thread
+    static constexpr int JS      = (NSINGLE + THREADS - 1) / THREADS; // singles per thread
+    static constexpr int IT      = 2 * JP + JS;                       // value slots per thread
     static constexpr int TSZ     = (2 * NE * 4 + (int)sizeof(T) - 1) / (int)sizeof(T); // two entity tables, in T's
     static constexpr int ASZ     = NPTS > TSZ ? NPTS : TSZ;                            // LDS array size
     static constexpr int LDS     = 2 * ASZ * (int)sizeof(T);
@@ -107,9 +120,13 @@ namespace mgx
     static constexpr int WG_WAVE = 32 / (THREADS / 64);
     static constexpr int WGS     = WG_LDS < WG_WAVE ? (WG_LDS < 8 ? WG_LDS : 8) : (WG_WAVE < 8 ? WG_WAVE : 8);
     static constexpr int WAVES   = WGS * (THREADS / 64);
-    // waves per SIMD the register allocation must allow for WGS workgroups per CU (at most 4: 128
-    // VGPRs are needed for the line sweeps)
-    static constexpr int MINW = (WAVES + 3) / 4 > 4 ? 4 : (WAVES + 3) / 4;
+    // Waves per SIMD the register allocation is asked to allow: what WGS workgroups per CU need, but
+    // not more than the registers of the line sweeps (three lines of G values) and of the per-item
+    // state (source value, inverse diagonal, item word) leave room for -- spilling costs more than a
+    // wave per SIMD
+    static constexpr int REGS = (3 * G + 2 * IT) * ((int)sizeof(T) / 4) + 2 * IT + 40;
+    static constexpr int RMAX = REGS > 168 ? 2 : (REGS > 128 ? 3 : 4);
+    static constexpr int MINW = (WAVES + 3) / 4 < RMAX ? (WAVES + 3) / 4 : RMAX;
   };
 
   // out = Ab in for the assembled 1D matrix of A over the NB cells of a line, cell block by cell
@@ -172,6 +189,29 @@ namespace mgx
       }
   }
 
+  // one cell block of a line: y = A seg (even-odd form)
+  template <int P, typename T>
+  __device__ __forceinline__ void cell_apply(const EOMat<T> &A, const T (&seg)[P + 1], T (&y)[P + 1])
+  {
+    constexpr int N = P + 1, H1 = N / 2 + 1;
+    T             xe[H1], xo[H1];
+    eo_split<N, T>(seg, xe, xo);
+    eo_apply<N, T>(A, xe, xo, y);
+  }
+  template <int P, typename T>
+  __device__ __forceinline__ void cell_apply2(const EOMat<T> &A, const EOMat<T> &Bm, const T (&seg)[P + 1],
+                                              T (&y)[P + 1], T (&z)[P + 1])
+  {
+    constexpr int N = P + 1, H1 = N / 2 + 1;
+    T             xe[H1], xo[H1];
+    eo_split<N, T>(seg, xe, xo);
+    eo_apply<N, T>(A, xe, xo, y);
+    eo_apply<N, T>(Bm, xe, xo, z);
+  }
+  // value of the next lane (the next cell of the same line in the cell-split pass)
+  __device__ __forceinline__ double next_lane(double v) { return __shfl_down(v, 1); }
+  __device__ __forceinline__ float  next_lane(float v) { return __shfl_down(v, 1); }
+
   // item table word: bits 0..9 entity slot of the brick, 10..22 brick point, 23..31 offset in the entity
   __device__ __forceinline__ uint32_t item_slot(uint32_t m) { return m & 1023u; }
   __device__ __forceinline__ uint32_t item_point(uint32_t m) { return (m >> 10) & 8191u; }
@@ -184,7 +224,8 @@ namespace mgx
   // only selects this kernel for vectors below 4 GB.
   using rsrc_t = __amdgpu_buffer_rsrc_t;
   typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-  constexpr uint32_t kOob = 0xFFFFFFFFu;
+  // (16-byte aligned, so that no dword of a 16-byte access wraps around to a small offset)
+  constexpr uint32_t kOob = 0xFFFFFFF0u;
   __device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes)
   {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
@@ -206,6 +247,34 @@ namespace mgx
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, off, 0, 0);
   }
 
+  // two adjacent values with one 16-byte (fp64) / 8-byte (fp32) access per lane
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  __device__ __forceinline__ void buf_ld2(rsrc_t r, uint32_t off, double &a, double &b)
+  {
+    const u32x4_t v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    a               = __builtin_bit_cast(double, u32x2_t{v.x, v.y});
+    b               = __builtin_bit_cast(double, u32x2_t{v.z, v.w});
+  }
+  __device__ __forceinline__ void buf_ld2(rsrc_t r, uint32_t off, float &a, float &b)
+  {
+    // The two dwords are taken from one 64-bit integer: read as elements 0 and 1 of the vector the
+    // builtin returns, hipcc 7.2 narrows the access to ONE dword load and hands the same dword to
+    // both (tools/experiments/buffer_probe.hip shows the hardware side is fine).
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    a                          = __builtin_bit_cast(float, (unsigned int)u);
+    b                          = __builtin_bit_cast(float, (unsigned int)(u >> 32));
+  }
+  __device__ __forceinline__ void buf_st2(rsrc_t r, uint32_t off, double a, double b)
+  {
+    const u32x2_t lo = __builtin_bit_cast(u32x2_t, a), hi = __builtin_bit_cast(u32x2_t, b);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lo.x, lo.y, hi.x, hi.y}, r, off, 0, 0);
+  }
+  __device__ __forceinline__ void buf_st2(rsrc_t r, uint32_t off, float a, float b)
+  {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned int, a), __builtin_bit_cast(unsigned int, b)}, r,
+                                          off, 0, 0);
+  }
+
   template <typename T>
   struct PostRsrc
   {
@@ -216,49 +285,55 @@ namespace mgx
   // operation_after_loop, laplace_operator.h:723-741), split into the part that issues the loads
   // and the part that consumes them, so that the loads of the next chunk of items can be in flight
   // while a chunk is computed and stored.
+  // operands of one unit of the write-out: a pair of adjacent DoFs of one entity ([0], [1]) or a
+  // single DoF ([0])
   template <typename T>
   struct PostOps
   {
-    T pv, av, bv, ov; // partial sum of earlier launches, operands of the post-operation
+    T pv[2], av[2], bv[2], ov[2]; // partial sum of earlier launches, operands of the post-operation
   };
 
-  // w = entity table word (bit 30 FIRST, bit 31 LAST), off = byte offset of the DoF
-  template <typename T, int MODE, bool DTAB>
+  // w = entity table word (bit 30 FIRST, bit 31 LAST), off = byte offset of the (first) DoF
+  template <typename T, int MODE, bool DTAB, bool PAIR>
   __device__ __forceinline__ void post_issue(const PostRsrc<T> &R, uint32_t w, uint32_t off, PostOps<T> &o)
   {
     const bool valid        = w != kInvalid;
     const bool need_partial = valid && !(w & 0x40000000u); // not FIRST
     const bool last         = valid && (w >> 31);
-    o.pv = o.av = o.bv = o.ov = T(0);
-    const uint32_t ol = last ? off : kOob;
+    o.pv[0] = o.pv[1] = o.av[0] = o.av[1] = o.bv[0] = o.bv[1] = o.ov[0] = o.ov[1] = T(0);
+    const uint32_t ol = last ? off : kOob, op = need_partial ? off : kOob;
+    auto           ld = [&](rsrc_t r, uint32_t f, T(&v)[2]) {
+      if (PAIR)
+        buf_ld2(r, f, v[0], v[1]);
+      else
+        v[0] = buf_ld(r, f, T());
+    };
     // partial sums of earlier colour launches exist on the brick surface only: whole waves of
     // interior items skip the load
     if (__builtin_amdgcn_ballot_w64(need_partial) != 0)
-      o.pv = buf_ld(R.partial, need_partial ? off : kOob, T());
+      ld(R.partial, op, o.pv);
     if (MODE != kPlain)
-      o.av = buf_ld(R.a, ol, T());
+      ld(R.a, ol, o.av);
     if (MODE >= kCheb && MODE <= kChebOldInit && !DTAB)
-      o.bv = buf_ld(R.b, ol, T());
+      ld(R.b, ol, o.bv);
     if (MODE == kCheb)
-      o.ov = buf_ld(R.old, ol, T());
+      ld(R.old, ol, o.ov);
   }
 
-  // val = assembled value, xi = source value at this DoF (kept in registers since the gather)
   // bv = inverse diagonal at this DoF (loaded with the operands, or from the per-item table)
   template <typename T, int MODE>
-  __device__ __forceinline__ T post_finish(const BrickPost<T> &post, const PostOps<T> &o, T bv, bool last, T val, T xi)
+  __device__ __forceinline__ T post_finish(const BrickPost<T> &post, T pv, T av, T ov, T bv, bool last, T val, T xi)
   {
-    val += o.pv; // out-of-range loads returned zero
+    val += pv; // out-of-range loads returned zero
     if (MODE == kPlain)
       return val;
     else if (MODE == kResidual || MODE == kResidualRestrict)
-      return last ? o.av - val : val;
+      return last ? av - val : val;
     else
       {
-        T ov = o.ov;
         if (MODE == kChebOldInit)
-          ov = post.f0 * bv * o.av; // the x_1 of the previous iteration, recomputed (bitwise the same)
-        T xn = xi + post.f2 * bv * (o.av - val);
+          ov = post.f0 * bv * av; // the x_1 of the previous iteration, recomputed (bitwise the same)
+        T xn = xi + post.f2 * bv * (av - val);
         if (MODE == kCheb || MODE == kChebOldInit)
           xn += post.f1 * (xi - ov);
         else if (MODE == kChebZeroOld || MODE == kChebInit)
@@ -293,6 +368,8 @@ namespace mgx
     constexpr int IT     = C::IT;
     constexpr int LINES  = C::LINES;
     constexpr int NEW    = (C::NE + NT - 1) / NT; // entity words per thread
+    constexpr int N = P + 1, NB = C::NB;
+    constexpr int REM    = LINES - NT;            // lines beyond the thread count (cell-split pass)
     // the fused Chebyshev forms need the source value again at write-out time
     constexpr bool kKeepX = MODE >= kCheb && MODE <= kChebOldInit;
     constexpr int  NG     = (MODE == kChebInit && !DTAB) ? 2 : 1; // operands gathered per value
@@ -310,23 +387,43 @@ namespace mgx
       return;
     MGX_STAMP(0);
     MGX_STAMP(15);
-    auto live = [&](int it) { return (it + 1) * NT <= NPTS || tid + it * NT < NPTS; };
+    // Value slots of a thread: pair j of JP (slots 2j, 2j+1 = the two DoFs of pair tid + j NT of the
+    // item table) and single j of JS (slot 2 JP + j).  live: the slot exists for this thread.
+    constexpr int NP = C::NPAIR, NS = C::NSINGLE, JP = C::JP, JS = C::JS, NU = JP + JS; // NU units
+    auto live_p = [&](int j) { return (j + 1) * NT <= NP || tid + j * NT < NP; };
+    auto live_s = [&](int j) { return (j + 1) * NT <= NS || tid + j * NT < NS; };
+    auto live   = [&](int v) { return v < 2 * JP ? live_p(v / 2) : live_s(v - 2 * JP); };
     // item table words: the same for every brick, resident in registers
     uint32_t mw[IT];
 #pragma unroll
-    for (int it = 0; it < IT; ++it)
+    for (int j = 0; j < JP; ++j)
       {
-        const int i = tid + it * NT;
-        mw[it]      = item_map[i < NPTS ? i : 0];
+        const int     q = tid + j * NT;
+        const u32x2_t m = reinterpret_cast<const u32x2_t *>(item_map)[q < NP ? q : 0];
+        mw[2 * j]       = m.x;
+        mw[2 * j + 1]   = m.y;
       }
-    T dv[DTAB ? IT : 1]; // inverse diagonal of this thread's items
+#pragma unroll
+    for (int j = 0; j < JS; ++j)
+      {
+        const int q    = tid + j * NT;
+        mw[2 * JP + j] = item_map[2 * NP + (q < NS ? q : 0)];
+      }
+    T dv[DTAB ? IT : 1]; // inverse diagonal of this thread's items (DTAB: post.b is the table, in item order)
     if (DTAB)
       {
 #pragma unroll
-        for (int it = 0; it < IT; ++it)
+        for (int j = 0; j < JP; ++j)
           {
-            const int i = tid + it * NT;
-            dv[it]      = post.b[i < NPTS ? i : 0]; // DTAB: post.b is the item-ordered table
+            const int q                = tid + j * NT;
+            dv[DTAB ? 2 * j : 0]       = post.b[2 * (q < NP ? q : 0)];
+            dv[DTAB ? 2 * j + 1 : 0]   = post.b[2 * (q < NP ? q : 0) + 1];
+          }
+#pragma unroll
+        for (int j = 0; j < JS; ++j)
+          {
+            const int q               = tid + j * NT;
+            dv[DTAB ? 2 * JP + j : 0] = post.b[2 * NP + (q < NS ? q : 0)];
           }
       }
     const rsrc_t      rsrc = make_rsrc(src, vec_bytes);
@@ -349,29 +446,40 @@ namespace mgx
         if (tid + j * NT < C::NE)
           E[tid + j * NT] = e[j];
     };
+    // byte offset of the (first) DoF of a unit; constrained entity: out of range
+    auto unit_offset = [&](uint32_t w, uint32_t m) {
+      return w != kInvalid ? (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T) : kOob;
+    };
     // read_dof_values_compressed through the entity table E: issues the loads of this thread's
     // items (constrained entity: out of range, reads zero -- vector_access_reduced.h:174-179)
     T    g[NG][IT];
     auto gather_issue = [&](const uint32_t *E) {
+      const rsrc_t r0 = MODE == kChebInit ? (DTAB ? R.a : R.b) : rsrc;
 #pragma unroll
-      for (int it = 0; it < IT; ++it)
+      for (int j = 0; j < JP; ++j)
         {
-          g[0][it] = T(0);
-          if (NG == 2)
-            g[NG - 1][it] = T(0);
-          if (live(it))
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            g[0][2 * j + e] = g[NG - 1][2 * j + e] = T(0);
+          if (live_p(j))
             {
-              const uint32_t m = mw[it], w = E[item_slot(m)];
-              const uint32_t off = w != kInvalid ? (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T) : kOob;
-              if (MODE == kChebInit && !DTAB)
-                {
-                  g[0][it]      = buf_ld(R.b, off, T());
-                  g[NG - 1][it] = buf_ld(R.a, off, T());
-                }
-              else if (MODE == kChebInit)
-                g[0][it] = buf_ld(R.a, off, T());
-              else
-                g[0][it] = buf_ld(rsrc, off, T());
+              const uint32_t off = unit_offset(E[item_slot(mw[2 * j])], mw[2 * j]);
+              buf_ld2(r0, off, g[0][2 * j], g[0][2 * j + 1]);
+              if (NG == 2)
+                buf_ld2(R.a, off, g[NG - 1][2 * j], g[NG - 1][2 * j + 1]);
+            }
+        }
+#pragma unroll
+      for (int j = 0; j < JS; ++j)
+        {
+          const int v = 2 * JP + j;
+          g[0][v] = g[NG - 1][v] = T(0);
+          if (live_s(j))
+            {
+              const uint32_t off = unit_offset(E[item_slot(mw[v])], mw[v]);
+              g[0][v]            = buf_ld(r0, off, T());
+              if (NG == 2)
+                g[NG - 1][v] = buf_ld(R.a, off, T());
             }
         }
     };
@@ -417,11 +525,18 @@ namespace mgx
 #pragma unroll
         for (int it = 0; it < IT; ++it)
           asm volatile("" : "+v"(mw[it]));
-        // ---- x sweep: line l = (y,z), contiguous; M u -> W, K u -> U in place ----
-#pragma unroll 1
-        for (int l = tid; l < LINES; l += NT)
+        if (DTAB && (MODE == kChebInit || MODE == kChebOldInit)) // likewise f0 * dv
           {
-            T in[G], t1[G], k1[G];
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+              asm volatile("" : "+v"(dv[DTAB ? it : 0]));
+          }
+#ifndef MGX_MACRO_NOSWEEP // diagnostic build without the sweeps (wrong results): memory phases alone
+        // ---- x sweep: line l = (y,z), contiguous; M u -> W, K u -> U in place ----
+        if (tid < LINES)
+          {
+            const int l = tid;
+            T         in[G], t1[G], k1[G];
 #pragma unroll
             for (int j = 0; j < G; ++j)
               in[j] = U[l * G + j];
@@ -433,12 +548,74 @@ namespace mgx
                 U[l * G + j] = k1[j];
               }
           }
+        // the REM lines beyond the thread count, one cell block per thread (NB consecutive lanes per
+        // line): the block's first output belongs to the previous cell's thread, which fetches it
+        // from its neighbour lane.  In-place updates are safe: the lanes of a line sit in one wave.
+        if (REM > 0 && tid < REM * NB)
+          {
+            const int l = NT + tid / NB, c = tid % NB, base = l * G + c * P;
+            T         seg[N], y[N], z[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              seg[i] = U[base + i];
+            cell_apply2<P, T>(M, K, seg, y, z);
+            const T yn = next_lane(y[0]), zn = next_lane(z[0]);
+            if (c + 1 < NB)
+              {
+                y[P] += yn;
+                z[P] += zn;
+              }
+#pragma unroll
+            for (int i = 1; i < N; ++i)
+              {
+                W[base + i] = y[i];
+                U[base + i] = z[i];
+              }
+            if (c == 0)
+              {
+                W[base] = y[0];
+                U[base] = z[0];
+              }
+          }
         __syncthreads();
         MGX_STAMP_IT(4);
         // ---- y sweep: line l = (x,z), stride G ----
-#pragma unroll 1
-        for (int l = tid; l < LINES; l += NT)
+        if (REM > 0 && tid < REM * NB)
           {
+            const int l = NT + tid / NB, c = tid % NB, base = (l / G) * (G * G) + l % G + c * P * G;
+            T         seg[N], y[N], z[N], r[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              seg[i] = W[base + i * G];
+            cell_apply2<P, T>(M, K, seg, y, z); // y: M t1, z: K t1
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              seg[i] = U[base + i * G];
+            cell_apply<P, T>(M, seg, r); // M k1
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              z[i] = fma(c0, r[i], c1 * z[i]);
+            const T yn = next_lane(y[0]), zn = next_lane(z[0]);
+            if (c + 1 < NB)
+              {
+                y[P] += yn;
+                z[P] += zn;
+              }
+#pragma unroll
+            for (int i = 1; i < N; ++i)
+              {
+                W[base + i * G] = y[i];
+                U[base + i * G] = z[i];
+              }
+            if (c == 0)
+              {
+                W[base] = y[0];
+                U[base] = z[0];
+              }
+          }
+        if (tid < LINES)
+          {
+            const int l    = tid;
             const int base = (l / G) * (G * G) + l % G;
             T         a[G], t2[G], s2[G];
 #pragma unroll
@@ -459,10 +636,34 @@ namespace mgx
         __syncthreads();
         MGX_STAMP_IT(5);
         // ---- z sweep: line l = (x,y), stride G^2; result -> W ----
-#pragma unroll 1
-        for (int l = tid; l < LINES; l += NT)
+        if (REM > 0 && tid < REM * NB)
           {
-            T a[G], r[G], o[G];
+            const int l = NT + tid / NB, c = tid % NB, base = l + c * P * (G * G);
+            T         seg[N], y[N], r[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              seg[i] = W[base + i * (G * G)];
+            cell_apply<P, T>(K, seg, r); // K t2
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              seg[i] = U[base + i * (G * G)];
+            cell_apply<P, T>(M, seg, y); // M s2
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              y[i] = fma(c2, r[i], y[i]);
+            const T yn = next_lane(y[0]);
+            if (c + 1 < NB)
+              y[P] += yn;
+#pragma unroll
+            for (int i = 1; i < N; ++i)
+              W[base + i * (G * G)] = y[i];
+            if (c == 0)
+              W[base] = y[0];
+          }
+        if (tid < LINES)
+          {
+            const int l = tid;
+            T         a[G], r[G], o[G];
 #pragma unroll
             for (int j = 0; j < G; ++j)
               a[j] = W[l + j * (G * G)];
@@ -475,6 +676,7 @@ namespace mgx
             for (int j = 0; j < G; ++j)
               W[l + j * (G * G)] = fma(c2, r[j], o[j]);
           }
+#endif
         __syncthreads();
         MGX_STAMP_IT(6);
         // ---- U is free: park both tables there and issue the next gather ----
@@ -491,61 +693,105 @@ namespace mgx
         MGX_STAMP_IT(7);
 
         // ---- write-out with the fused post-operation, same item -> thread mapping as the gather.
-        // Chunks of kChunk items, software-pipelined: the loads of chunk c + 1 are issued before chunk c
-        // is computed and stored, so no load ever has to wait for an older store (vmcnt counts loads
-        // and stores in issue order) and two chunks of operands are in flight. ----
+        // Units (pairs, then singles) in chunks, software-pipelined: the loads of chunk c + 1 are
+        // issued before chunk c is computed and stored, so no load ever has to wait for an older
+        // store (vmcnt counts loads and stores in issue order) and two chunks of operands are in
+        // flight.  Both DoFs of a pair belong to one entity: same flags, same target vector. ----
         {
-          // (kCheb has four operands per item in flight: smaller chunks)
-          constexpr int kChunk = MODE == kCheb ? MGX_MACRO_CHUNK_CHEB : MGX_MACRO_CHUNK, NCH = (IT + kChunk - 1) / kChunk;
+          // units per chunk: everything at once where few operands are loaded (plain), fewer where
+          // the fused Chebyshev forms keep three or four operand pairs per unit in flight
+          constexpr int kChunk = MODE == kPlain ? NU : (MODE == kResidual ? (NU + 1) / 2 : (kKeepX ? MGX_MACRO_CHUNK_CHEB : MGX_MACRO_CHUNK)),
+                        NCH    = (NU + kChunk - 1) / kChunk;
           PostOps<T>    ops[2][kChunk];
-          auto          issue = [&](int c, PostOps<T>(&o)[kChunk]) {
+          uint32_t      iw[2][kChunk]; // entity table word of the unit (kInvalid: nothing to do)
+          // unit u: pair u (u < JP) or single u - JP; v0 = its first value slot
+          auto slot0 = [&](int u) { return u < JP ? 2 * u : JP + u; };
+          auto ulive = [&](int u) { return u < JP ? live_p(u) : live_s(u - JP); };
+          auto issue = [&](int c, PostOps<T>(&o)[kChunk], uint32_t(&w)[kChunk]) {
+            // table lookups of the whole chunk first (one batch of LDS reads), then the loads
 #pragma unroll
             for (int j = 0; j < kChunk; ++j)
               {
-                const int it = c * kChunk + j;
-                o[j].pv = o[j].av = o[j].bv = o[j].ov = T(0);
-                if (it < IT && live(it))
-                  {
-                    const uint32_t m = mw[it], w = ebase[item_slot(m)];
-                    post_issue<T, MODE, DTAB>(R, w, (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T), o[j]);
-                  }
+                const int u = c * kChunk + j;
+                w[j]        = kInvalid;
+                if (u < NU && ulive(u))
+                  w[j] = ebase[item_slot(mw[slot0(u)])];
+              }
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)
+              {
+                const int u = c * kChunk + j;
+                if (u < JP)
+                  post_issue<T, MODE, DTAB, true>(R, w[j], unit_offset(w[j], mw[slot0(u < NU ? u : 0)]), o[j]);
+                else if (u < NU)
+                  post_issue<T, MODE, DTAB, false>(R, w[j], unit_offset(w[j], mw[slot0(u < NU ? u : 0)]), o[j]);
               }
           };
-          issue(0, ops[0]);
+          issue(0, ops[0], iw[0]);
 #pragma unroll
           for (int c = 0; c < NCH; ++c)
             {
               if (c + 1 < NCH)
-                issue(c + 1, ops[(c + 1) & 1]);
+                issue(c + 1, ops[(c + 1) & 1], iw[(c + 1) & 1]);
               __builtin_amdgcn_sched_barrier(0);
+              T val[kChunk][2];
 #pragma unroll
               for (int j = 0; j < kChunk; ++j)
                 {
-                  const int it = c * kChunk + j;
-                  if (it < IT && live(it))
+                  const int u = c * kChunk + j;
+                  val[j][0] = val[j][1] = T(0);
+                  if (u < NU && ulive(u))
                     {
-                      // the table word and the offset are looked up again rather than kept in
-                      // registers next to the operands in flight
-                      const uint32_t m = mw[it], w = ebase[item_slot(m)];
-                      const uint32_t off  = w != kInvalid ? (ent_index(w) + item_offset(m)) * (uint32_t)sizeof(T) : kOob;
-                      const bool     last = w != kInvalid && (w >> 31);
-                      const T        res  = post_finish<T, MODE>(post, ops[c & 1][j], DTAB ? dv[DTAB ? it : 0] : ops[c & 1][j].bv,
-                                                                 last, W[item_point(m)], xs[kKeepX ? it : 0]);
+                      val[j][0] = W[item_point(mw[slot0(u)])];
+                      if (u < JP)
+                        val[j][1] = W[item_point(mw[slot0(u) + 1])];
+                    }
+                }
+#pragma unroll
+              for (int j = 0; j < kChunk; ++j)
+                {
+                  const int u = c * kChunk + j;
+                  if (u < NU)
+                    {
+                      const int         v0   = slot0(u);
+                      const bool        pair = u < JP;
+                      const uint32_t    w    = iw[c & 1][j];
+                      const bool        vld  = w != kInvalid, last = vld && (w >> 31);
+                      const uint32_t    off  = unit_offset(w, mw[v0]);
+                      const PostOps<T> &o    = ops[c & 1][j];
+                      T                 res[2];
+#pragma unroll
+                      for (int e = 0; e < 2; ++e)
+                        res[e] = (e == 0 || pair)
+                                   ? post_finish<T, MODE>(post, o.pv[e], o.av[e], o.ov[e], DTAB ? dv[DTAB ? v0 + e : 0] : o.bv[e],
+                                                          last, val[j][e], xs[kKeepX ? v0 + e : 0])
+                                   : T(0);
+                      auto st = [&](rsrc_t r, uint32_t f) {
+                        if (pair)
+                          buf_st2(r, f, res[0], res[1]);
+                        else
+                          buf_st(r, f, res[0]);
+                      };
                       if (MODE == kResidualRestrict)
                         {
                           // completed residuals stay in W for the restriction, partial sums go to the
                           // carrier, everything that is not a completed residual becomes zero
-                          if (__builtin_amdgcn_ballot_w64(!last) != 0)
-                            buf_st(R.partial, last ? kOob : off, res);
-                          W[item_point(m)] = last ? res : T(0);
+                          if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
+                            st(R.partial, last ? kOob : off);
+                          if (ulive(u))
+                            {
+                              W[item_point(mw[v0])] = last ? res[0] : T(0);
+                              if (pair)
+                                W[item_point(mw[v0 + 1])] = last ? res[1] : T(0);
+                            }
                         }
                       else
                         {
                           // out-of-range offsets drop the store; whole waves of interior items skip
                           // the carrier store
-                          buf_st(R.out, last ? off : kOob, res);
-                          if (__builtin_amdgcn_ballot_w64(!last) != 0)
-                            buf_st(R.partial, last ? kOob : off, res);
+                          st(R.out, last ? off : kOob);
+                          if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
+                            st(R.partial, last ? kOob : off);
                         }
                     }
                 }
@@ -696,7 +942,7 @@ namespace mgx
                                                      const uint32_t *coarse_blocks)
   {
     using T = MGX_MACRO_T;
-    if (mode < kPlain || mode > kResidualRestrict || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFFFull)
+    if (mode < kPlain || mode > kResidualRestrict || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
       return false;
     BrickPost<T> post;
     post.a             = (const T *)a;
