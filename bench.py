@@ -9,10 +9,16 @@ restriction, coarse solve, prolongation).  `value` = global DoFs / time per step
 and V-cycle-only rates are reported next to it (`matvec_dofs_per_s`, `vcycle_dofs_per_s`).
 
 N = 1: BASELINE config 1 -- 128^3 cells, 135 005 697 DoFs, one MI355X, inputs resident in HBM.
-N > 1: domain decomposition, one process per GPU over RCCL (torch.distributed "nccl"): the mesh is
-       the reference's "doubling" family (program.cc:509-529), one 128^3-cell coarse cube per rank on a
-       2x1x1 / 2x2x1 / 2x2x2 process grid (weak scaling), interface DoFs exchanged and summed once
-       per operator application.  `--replicas` runs N independent copies instead.
+N > 1: domain decomposition, one process per GPU over RCCL (torch.distributed "nccl"), interface
+       DoFs exchanged and summed once per operator application.
+       --scaling strong (default): the SAME 128^3-cell mesh, block-split 2x1x1 / 2x2x1 / 2x2x2
+       (n_subdiv = 2 coarse cells per direction so that every level splits evenly:
+       the finest level is identical to N = 1, the hierarchy is one level shorter).
+       --scaling weak: the reference's "doubling" family (program.cc:509-529), one 128^3-cell
+       coarse cube per rank.   --replicas: N independent copies.
+`python bench.py --gpus N` starts the N ranks itself (fresh child processes with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) and relays rank 0's JSON line; under
+torch.distributed.run the ranks are already there and --gpus must equal WORLD_SIZE.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--cells 128] [--degree 4]
 """
@@ -41,6 +47,11 @@ def parse():
     ap.add_argument("--vcycle-number", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: split the --cells^3 mesh over the ranks (strong) or give every rank a --cells^3 cube (weak)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch check without a GPU: ranks rendezvous (gloo), build their part of the mesh on the host "
+                         "and exchange one interface vector; prints the JSON line with value null")
     ap.add_argument("--cpu-cells", type=int, default=64, help="finest level of the CPU baseline sample")
     return ap.parse_args()
 
@@ -82,12 +93,98 @@ def cpu_baseline(args):
     }
 
 
+def spawn(args):
+    """`python bench.py --gpus N` outside a launcher: start N fresh child processes (this parent never
+    touches the GPU and never replaces itself), give each its rank environment, relay rank 0's JSON
+    line, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    one_gpu = os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl" or args.dry_run
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # host-side table construction is OpenMP code: every rank gets its share of the cores
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // args.gpus))))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit("bench.py: rank exit codes %s" % codes)
+
+
+def dry_run(args, rank, world, dist):
+    """No GPU: decomposition tables on the host + one interface exchange over gloo, checked against
+    the multiplicity of every interface DoF."""
+    import numpy as np
+    import torch
+    import multigrid_amd as mg
+    procs = mg.process_grid(world)
+    ns, nr = split_size(args.cells)
+    if world > 1 and args.scaling == "strong":
+        cube = mg.Cube(args.degree, n_refine=nr - 1, box=(2, 2, 2), procs=procs, rank=rank, origin=-0.9, h0=0.95)
+    elif world > 1:
+        cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
+    else:
+        cube = mg.Cube(args.degree, ns, nr)
+    l = cube.max_level
+    ok = True
+    if world > 1:
+        v = np.ones(cube.n_dofs(l))
+        ops, recvs = [], []
+        for (rk, idx) in cube.neighbors(l):
+            st, rt = torch.ones(idx.size, dtype=torch.float64), torch.empty(idx.size, dtype=torch.float64)
+            recvs.append((idx, rt))
+            ops += [dist.P2POp(dist.isend, st, rk), dist.P2POp(dist.irecv, rt, rk)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        for idx, rt in recvs:
+            v[idx] += rt.numpy()
+        # every interface DoF now counts the ranks that share it: 2 on faces, 4 on edges, 8 at corners
+        shared = cube.shared(l)
+        ok = bool(np.isin(v[shared], (2., 4., 8.)).all() and (np.delete(v, shared) == 1.).all())
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+    g = np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * args.degree + 1
+    if rank == 0:
+        print(json.dumps({"metric": "DoFs/s for Laplace matvec + V-cycle, poisson_cube p=%d fp64" % args.degree,
+                          "value": None, "unit": "DoFs/s", "n_gpus": world, "dry_run": True, "exchange_ok": ok,
+                          "scaling": args.scaling if world > 1 else "weak",
+                          "config": {"global_dofs": int(g.prod()), "n_dofs_per_gpu": cube.n_dofs(l),
+                                     "process_grid": list(procs)}}))
+    cube.close()
+    if not ok:
+        raise SystemExit("bench.py --dry-run: interface exchange check failed")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under "
+                         "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     dist = None
+    if args.dry_run:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        dry_run(args, rank, world, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -115,18 +212,23 @@ def main():
     decomposed = world > 1 and not args.replicas
     native = False
     if decomposed:
-        if ns != 1:
-            raise SystemExit("--cells must be a power of two for N > 1 (one coarse cube per rank)")
+        if ns != 1 or nr < 1:
+            raise SystemExit("--cells must be a power of two (>= 2) for N > 1")
         procs = mg.process_grid(world)
         comm = mg.Communicator(ctx, dist)
-        cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
+        if args.scaling == "strong":
+            # the square mesh [-0.9,1]^3 with n_subdiv = 2, block-split: every rank owns
+            # (2/procs[d]) coarse cells per direction on every level
+            cube = mg.Cube(args.degree, n_refine=nr - 1, box=(2, 2, 2), procs=procs, rank=rank, origin=-0.9, h0=0.95)
+        else:
+            cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
         solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, comm=comm)
         # RCCL send/recv issued by the library on its own stream (no host round trip per exchange),
         # switched on only after one exchange + one reduction agree bitwise with the torch transport
         native = comm.verify_and_enable_native(solver.matrix_dp(cube.max_level), cube.n_dofs(cube.max_level))
         global_dofs = 1
         for d in range(3):
-            global_dofs *= procs[d] * args.cells * args.degree + 1
+            global_dofs *= (1 if args.scaling == "strong" else procs[d]) * args.cells * args.degree + 1
     else:
         procs = (1, 1, 1)
         cube = mg.Cube(args.degree, ns, nr)
@@ -234,22 +336,29 @@ def main():
                                / (avg * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                                "frac": FLOP_PER_DOF_P4 * (n_dofs / n_col) / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
                               if args.degree == 4 else None)}
+    transport = None
+    if decomposed:
+        transport = ("RCCL ncclSend/ncclRecv issued by the library on the solver stream" if native else
+                     "torch.distributed (%s) point-to-point batches" % dist.get_backend())
     out = {
         "metric": "DoFs/s for Laplace matvec + V-cycle, poisson_cube p=%d fp64" % args.degree,
         "value": total_dofs / (elapsed / args.steps),
         "unit": "DoFs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if decomposed else "weak", "vs_baseline": None,
         "dtype": "f64" if vnum == mg.F64 else "f64 outer / f32 V-cycle", "data": "synthetic",
-        "config": {"workload": "poisson_cube FE_Q(%d) %d^3 cells, %d DoFs per GPU, %d levels, "
+        "config": {"workload": "poisson_cube FE_Q(%d) %d^3 cells%s, %d DoFs per GPU, %d levels, "
                                "step = 1 fp64 vmult + 1 V-cycle (Chebyshev degree %d)" %
-                               (args.degree, args.cells, n_dofs, cube.n_levels, args.smoother_degree),
+                               (args.degree, args.cells, " in total" if decomposed and args.scaling == "strong" else "", n_dofs,
+                                cube.n_levels, args.smoother_degree),
                    "cells_per_dim": args.cells, "degree": args.degree, "n_dofs_per_gpu": n_dofs,
                    "global_dofs": total_dofs,
                    "parallelism": "1 GPU" if world == 1 else
-                   ("domain decomposition %dx%dx%d, one %d^3-cell cube per GPU, interface exchange over RCCL (%s)" %
-                    (procs + (args.cells, "ncclSend/Recv on the solver stream" if native else
-                              "torch.distributed P2P batches")) if decomposed else "%d independent replicas" % world)},
+                   ("domain decomposition %dx%dx%d, %s, interface exchange over %s" %
+                    (procs + (("the %d^3-cell mesh block-split over the GPUs" if args.scaling == "strong" else
+                               "one %d^3-cell cube per GPU") % args.cells, transport)) if decomposed
+                    else "%d independent replicas" % world),
+                   "transport": transport if decomposed else None},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
         "roofline": roof(2) if vnum == mg.F64 else roof(0),

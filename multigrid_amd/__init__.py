@@ -301,11 +301,15 @@ class Cube:
 
     NUMBERING = {"brick": 0, "cell": 1}
 
-    def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0, numbering="brick"):
+    def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0, numbering="brick",
+                 origin=-1.0, h0=1.9):
         """box=None: the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction.
-        box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1),
-        program.cc:509-529), optionally distributed over the process grid `procs`; this rank owns
-        box[d]/procs[d] coarse cells per direction.
+        box=(sx,sy,sz): a box of sx x sy x sz cubic coarse cells of size h0 from (origin,)*3,
+        optionally distributed over the process grid `procs`; this rank owns box[d]/procs[d] coarse
+        cells per direction on every level.  The defaults (size 1.9 from -1) are the reference's
+        doubling-mesh family (program.cc:509-529: one coarse cube per rank = weak scaling);
+        box=(n,n,n), origin=-0.9, h0=1.9/n is the square mesh of poisson_cube with n_subdiv = n,
+        block-split over the ranks (strong scaling of one problem).
         numbering: "brick" (default, grouped for the device cell loop) or "cell" (the
         plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h."""
         self.lib = _lib.load()
@@ -314,7 +318,7 @@ class Cube:
         if box is None:
             check(self.lib.mgx_cube_create_numbered(degree, n_subdiv, n_refine, num, C.byref(h)))
         else:
-            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), -1.0, 1.9, (C.c_int * 3)(*procs), rank, num)
+            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), origin, h0, (C.c_int * 3)(*procs), rank, num)
             check(self.lib.mgx_cube_create_box(C.byref(d), C.byref(h)))
         self.h = h
         self.rank, self.size = self.lib.mgx_cube_rank(h), self.lib.mgx_cube_size(h)

@@ -26,7 +26,8 @@ def lex_of(o, l, v):
 
 def main():
     mode, p, nr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    vfloat = len(sys.argv) > 4 and sys.argv[4] == "f32"  # V-cycle number type (reference default: float)
+    vfloat = "f32" in sys.argv[4:]  # V-cycle number type (reference default: float)
+    strong = "strong" in sys.argv[4:]  # block-split of the square mesh with n_subdiv = 2 (bench.py --scaling strong)
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
@@ -40,8 +41,12 @@ def main():
     from oracle import Oracle
 
     procs = mg.process_grid(world)
-    cube = mg.Cube(p, n_refine=nr, box=procs, procs=procs, rank=rank)
-    orc = Oracle(p, n_refine=nr, degree=3, n_cycles=1, box=procs, vfloat=vfloat)
+    if strong:
+        cube = mg.Cube(p, n_refine=nr, box=(2, 2, 2), procs=procs, rank=rank, origin=-0.9, h0=0.95)
+        orc = Oracle(p, n_subdiv=2, n_refine=nr, degree=3, n_cycles=1, vfloat=vfloat)
+    else:
+        cube = mg.Cube(p, n_refine=nr, box=procs, procs=procs, rank=rank)
+        orc = Oracle(p, n_refine=nr, degree=3, n_cycles=1, box=procs, vfloat=vfloat)
     l = cube.max_level
     gid = cube.dof_grid(l)
 

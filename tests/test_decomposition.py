@@ -112,3 +112,11 @@ def test_box_mesh_matches_oracle_single_rank():
 def test_gloo_exchange_protocol(world):
     outs = launch("host", world, 3, 2)
     assert all("host ok" in o for o in outs)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_exchange_protocol_block_split_cube(world):
+    """the strong-scaling layout (square mesh with n_subdiv = 2, block-split 2x1x1 / 2x2x2): assembled
+    rhs and unique ownership on every level against the single-domain oracle"""
+    outs = launch("host", world, 2, 2, extra=("strong",))
+    assert all("host ok" in o for o in outs), outs

@@ -13,6 +13,33 @@ def test_decomposed_solver_matches_oracle(world, p, nr):
     assert all("gpu ok" in o for o in outs), outs
 
 
+@pytest.mark.parametrize("world,p,nr", [(2, 4, 2), (4, 4, 2), (4, 2, 3)])
+def test_block_split_cube_matches_oracle(world, p, nr):
+    """strong scaling layout of bench.py: the square mesh (n_subdiv = 2) block-split 2x1x1 / 2x2x1,
+    against the single-domain oracle on the same mesh (2x2x2: host tables and exchange protocol in
+    tests/test_decomposition.py -- a one-GPU box takes at most 6 GPU processes)"""
+    outs = launch("gpu", world, p, nr, extra=("strong",))
+    assert all("gpu ok" in o for o in outs), outs
+
+
+def test_bench_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` starts two ranks itself; here over gloo, both on the one GPU"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGX_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "32", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["global_dofs"] == (32 * 4 + 1) ** 3
+    assert "gloo" in line["config"]["transport"]
+
+
 def test_decomposed_mixed_precision_solver_matches_oracle():
     """the reference's default: fp32 V-cycle inside the fp64 outer iteration, on two ranks"""
     outs = launch("gpu", 2, 4, 3, extra=("f32",))
