@@ -292,6 +292,15 @@ int mgx_solver_destroy(mgx_solver_t solver);
  * (the L2 errors printed next to them need the analytic solution and are computed by the
  * caller from mgx_solver_get_solution, as the reference does on the host, :298-343). */
 int mgx_solver_solve(mgx_solver_t solver, int do_analyze, double *reduction_rate, double *trace);
+/* The same with the two points of the analysed solve at which the reference evaluates
+ * compute_l2_error(level) exposed to the caller: hook(user, level, 0) right after the prolongation
+ * of the coarser solution with its boundary values (:420-424, "error start level"), hook(user,
+ * level, 1) after the correction has been added (:468-472, "error end level").  The stream is
+ * idle during the call; the hook typically calls mgx_solver_get_solution(level, 1) and evaluates
+ * the error on the host (mgx_cube_l2_error).  Only called when do_analyze != 0. */
+typedef void (*mgx_level_hook)(void *user, int level, int stage);
+int mgx_solver_solve_hooked(mgx_solver_t solver, int do_analyze, double *reduction_rate, double *trace,
+                            mgx_level_hook hook, void *user);
 /* MultigridSolver::solve_cg() :483-493: SolverCG with ReductionControl(1000,1e-16,1e-9) */
 int mgx_solver_solve_cg(mgx_solver_t solver, unsigned int *iterations, double *reduction_rate);
 /* MultigridSolver::vmult(dst, src) :498-510: one V-cycle; dst/src fp64 device vectors */

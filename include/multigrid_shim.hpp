@@ -289,13 +289,17 @@ namespace multigrid
       std::vector<double> trace(2 * (maxlevel_ + 1), 0.);
       if (do_analyze)
         {
-          // the reference prints error/residual per level (:420-473); errors need the analytic
-          // solution and are evaluated on the host after the fact for the finest level only
-          check(mgx_solver_solve(s_.solver, 1, &rate, trace.data()));
+          // the reference prints error and residual before and after the cycles of every level
+          // (:420-473); the errors are evaluated on the host against the analytic solution at the
+          // same two points of the solve (mgx_solver_solve_hooked)
+          errors_.assign(2 * (maxlevel_ + 1), 0.);
+          check(mgx_solver_solve_hooked(s_.solver, 1, &rate, trace.data(), &MultigridSolver::level_hook, this));
           for (int l = 1; l <= maxlevel_; ++l)
             {
+              std::printf("error start         level %d: %g\n", l, errors_[2 * l]);
               std::printf("residual norm start level %d: %g\n", l, trace[2 * l]);
               std::printf("residual norm end   level %d: %g\n", l, trace[2 * l + 1]);
+              std::printf("error end           level %d: %g\n", l, errors_[2 * l + 1]);
             }
         }
       else
@@ -314,6 +318,8 @@ namespace multigrid
     void vmult(Vector<Number2> &dst, const Vector<Number2> &src) const { check(mgx_solver_vmult(s_.solver, dst.begin(), src.begin())); }
     void do_matvec() { check(mgx_solver_do_matvec(s_.solver)); }                   // :624-628
     void do_matvec_smoother() { check(mgx_solver_do_matvec_smoother(s_.solver)); } // :633-637
+    // L2 errors {start, end} per level of the last solve(true) (:420-424, 468-472)
+    const std::vector<double> &level_errors() const { return errors_; }
     // compute_l2_error(level) (:298-343): host evaluation against the analytic solution
     double compute_l2_error(const unsigned int level)
     {
@@ -345,6 +351,12 @@ namespace multigrid
     mgx_solver_t  handle() const { return s_.solver; }
 
   private:
+    static void level_hook(void *user, int level, int stage)
+    {
+      auto *self                          = static_cast<MultigridSolver *>(user);
+      self->errors_[2 * level + stage] = self->compute_l2_error((unsigned int)level);
+    }
+    std::vector<double>       errors_;
     const Context            &ctx_;
     const CubeDiscretization &disc_;
     mgx_cube_solver           s_{};

@@ -578,12 +578,24 @@ class MultigridSolver:
         check(self.lib.mgx_solver_get_smoother(self.h, level, C.byref(p)))
         return Chebyshev(self.matrix(level), handle=p.value)
 
-    def solve(self, do_analyze=False):
-        """returns (reduction_rate, trace[n_levels,2] = residual norm start/end per level)"""
+    def solve(self, do_analyze=False, level_errors=False):
+        """returns (reduction_rate, trace[n_levels,2] = residual norm start/end per level); with
+        level_errors also errors[n_levels,2] = the L2 error of every level before / after its
+        cycles, evaluated at the points of the solve where the reference prints them
+        (multigrid_solver.h:420-424, 468-472)"""
         rate = C.c_double(1.0)
         trace = np.zeros(2 * self.n_levels)
-        check(self.lib.mgx_solver_solve(self.h, int(do_analyze), C.byref(rate), trace.ctypes.data_as(_lib.f64p)))
-        return rate.value, trace.reshape(-1, 2)
+        if not (do_analyze and level_errors):
+            check(self.lib.mgx_solver_solve(self.h, int(do_analyze), C.byref(rate), trace.ctypes.data_as(_lib.f64p)))
+            return rate.value, trace.reshape(-1, 2)
+        errors = np.zeros((self.n_levels, 2))
+
+        def hook(user, level, stage):
+            errors[level, stage] = self.compute_l2_error(level)
+
+        cb = _lib.LEVEL_HOOK_FN(hook)
+        check(self.lib.mgx_solver_solve_hooked(self.h, 1, C.byref(rate), trace.ctypes.data_as(_lib.f64p), cb, None))
+        return rate.value, trace.reshape(-1, 2), errors
 
     def solve_cg(self):
         its = C.c_uint()

@@ -29,6 +29,7 @@ class ExchangeDesc(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), u32p, C.POINTER(vp), C.POINTER(vp))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, f64p, C.c_int)
 ALLOC_FN = C.CFUNCTYPE(vp, vp, C.c_size_t)
+LEVEL_HOOK_FN = C.CFUNCTYPE(None, vp, C.c_int, C.c_int)
 
 
 class CommDesc(C.Structure):
@@ -120,6 +121,7 @@ SIGNATURES = {
     "mgx_solver_create": (C.c_int, [vp, C.POINTER(SolverDesc), C.POINTER(vp)]),
     "mgx_solver_destroy": (C.c_int, [vp]),
     "mgx_solver_solve": (C.c_int, [vp, C.c_int, f64p, f64p]),
+    "mgx_solver_solve_hooked": (C.c_int, [vp, C.c_int, f64p, f64p, LEVEL_HOOK_FN, vp]),
     "mgx_solver_solve_cg": (C.c_int, [vp, C.POINTER(C.c_uint), f64p]),
     "mgx_solver_vmult": (C.c_int, [vp, vp, vp]),
     "mgx_solver_do_matvec": (C.c_int, [vp]),

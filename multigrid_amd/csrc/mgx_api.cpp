@@ -2099,6 +2099,12 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
 
 int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, double *trace)
 {
+  return mgx_solver_solve_hooked(S, do_analyze, reduction_rate, trace, nullptr, nullptr);
+}
+
+int mgx_solver_solve_hooked(mgx_solver_t S, int do_analyze, double *reduction_rate, double *trace, mgx_level_hook hook,
+                            void *user)
+{
   MGX_REQUIRE(S, "mgx_solver_solve: null solver");
   hipStream_t s    = S->ctx->stream;
   double      rate = 1.;
@@ -2124,6 +2130,11 @@ int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, dou
         MGX_TRY(mgx_prolongate(S->transfer_dp[level], S->solution[level], S->solution[level - 1], 0, 0)); // :415
       }
       double init_residual = 1.;
+      if (do_analyze && hook) // :420-424 "error start level"
+        {
+          MGX_HIP(hipStreamSynchronize(s));
+          hook(user, level, 0);
+        }
       set_bc(S, level, S->solution[level], true); // :427-428
       {
         Stopwatch sw(S, level, 0);
@@ -2154,6 +2165,11 @@ int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, dou
           rate = std::pow(res_norm / init_residual, 1. / S->n_cycles);                        // :467
           if (trace)
             trace[2 * level + 1] = res_norm;
+          if (hook) // :468-472 "error end level"
+            {
+              MGX_HIP(hipStreamSynchronize(s));
+              hook(user, level, 1);
+            }
         }
     }
   MGX_HIP(hipGetLastError());

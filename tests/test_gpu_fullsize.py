@@ -11,10 +11,12 @@ pytestmark = pytest.mark.gpu
 mg = pytest.importorskip("multigrid_amd")
 
 
-@pytest.fixture(scope="module")
-def big():
+# C2: FE_Q(4) on 128^3 cells; C3: FE_Q(8) on 64^3 cells -- both 513^3 = 135 005 697 DoFs
+@pytest.fixture(scope="module", params=[(4, 7), (8, 6)], ids=["C2-p4", "C3-p8"])
+def big(request):
+    p, nr = request.param
     ctx = mg.Context(0)
-    cube = mg.Cube(4, 1, 7)
+    cube = mg.Cube(p, 1, nr)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
     yield ctx, cube, solver
     solver.close()
@@ -92,9 +94,16 @@ def test_c2_full_solve_reaches_the_readme_accuracy(big):
     assert 0.05 < rate < 0.25                      # README.md:159: 0.1403 (mixed precision, 2 cycles)
     assert (trace[1:, 1] < trace[1:, 0]).all()     # every level's V-cycle reduces the residual
     its, red = solver.solve_cg()
-    assert its == 8                                # README.md:159
-    assert red == pytest.approx(6.8e-2, rel=0.1)   # README.md:159: 6.799e-02
-    assert solver.compute_l2_error() == pytest.approx(4.2068e-10, rel=0.02)  # README.md:128
+    if cube.degree == 4:
+        assert its == 8                                # README.md:159
+        assert red == pytest.approx(6.8e-2, rel=0.1)   # README.md:159: 6.799e-02
+        assert solver.compute_l2_error() == pytest.approx(4.2068e-10, rel=0.02)  # README.md:128
+    else:
+        # C3 (p = 8): no README row.  The discretisation error (h^9) is far below what the PCG
+        # tolerance (1e-9 relative residual, multigrid_solver.h:486) leaves: measured 8.8e-11, i.e.
+        # more accurate than C2 on the same 513^3 grid
+        assert 6 <= its <= 11
+        assert solver.compute_l2_error() < 4.2068e-10
 
 
 FALLBACKS = {"MGX_NO_FUSED_RESTRICT": "1", "MGX_NO_FUSED_INIT": "1", "MGX_TRANSFER_V1": "1",

@@ -243,6 +243,83 @@ def test_default_brick_threshold(ctx, monkeypatch):
     orc.close()
 
 
+def test_production_thresholds_p4_against_oracle(ctx, monkeypatch):
+    """FE_Q(4) on 64^3 cells (16 974 593 DoFs, 4096 bricks on the finest level): the production
+    configuration -- default brick / colour thresholds, macro-element brick loop on the fine levels,
+    per-cell kernel and graph replay on the coarse ones -- against the oracle, not against another
+    path of the same library."""
+    monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
+    monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
+    p, nr = 4, 6
+    cube = mg.Cube(p, 1, nr)
+    orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    x, b = cube.seeded_vector(nr, 5), cube.seeded_vector(nr, 6)
+    src, rhs, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=b), ctx.vector(x.size)
+    A = solver.matrix_dp(nr)
+    A.vmult(dst, src)
+    assert rel(dst.download(), orc.vmult(nr, x)) < 1e-12
+    A.vmult_residual(rhs, src, dst)
+    assert rel(dst.download(), orc.vmult_residual(nr, b, x)) < 1e-12
+    sm = solver.smoother(nr)
+    sm.vmult(dst, rhs)
+    x_ref = orc.cheb_vmult(nr, b)
+    assert rel(dst.download(), x_ref) < 1e-10
+    sm.step(dst, rhs)
+    assert rel(dst.download(), orc.cheb_step(nr, x_ref, b)) < 1e-10
+    solver.vmult(dst, src)
+    assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    solver.vmult(dst, src)  # coarse levels replayed from the HIP graph
+    assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    for v in (src, rhs, dst):
+        v.free()
+    solver.close()
+    cube.close()
+    orc.close()
+
+
+def test_level_errors_of_the_analysed_solve(ctx):
+    """multigrid_solver.h:420-424, 468-472: L2 error of every level before and after its cycles"""
+    cube = mg.Cube(4, 1, 3)
+    orc = oracle_for(cube, 4, 1, 3, degree=3, n_cycles=2)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 2, mg.F64)
+    rate, trace, errors = solver.solve(True, level_errors=True)
+    orate, otrace = orc.solve(True)
+    assert rate == pytest.approx(orate, rel=1e-6)
+    np.testing.assert_allclose(errors[1:, 0], otrace[1:, 0], rtol=1e-8)  # error start
+    np.testing.assert_allclose(trace[1:, 0], otrace[1:, 1], rtol=1e-9)   # residual start
+    np.testing.assert_allclose(trace[1:, 1], otrace[1:, 2], rtol=1e-6)   # residual end
+    np.testing.assert_allclose(errors[1:, 1], otrace[1:, 3], rtol=1e-8)  # error end
+    solver.close()
+    cube.close()
+    orc.close()
+
+
+def test_poisson_cube_driver_reproduces_the_readme_row():
+    """the C++ driver (reference CLI, protocol and table on the shim classes) at README.md:143:
+    ./poisson_cube 4 30000 40000 2 3 3 s  ->  512 cells, 35937 DoFs, mixed precision"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "multigrid_amd", "poisson_cube")
+    out = subprocess.run([exe, "4", "30000", "40000", "2", "3", "3", "s", "f32"], cwd=root, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout.decode()
+    for l in range(1, 4):  # the four analysis lines per level of solve(true)
+        for key in ("error start         level %d:", "residual norm start level %d:", "residual norm end   level %d:",
+                    "error end           level %d:"):
+            assert key % l in text, key % l
+    rows = [ln.split() for ln in text.splitlines() if ln.split()[:2] == ["512", "35937"]]
+    assert rows, text[-2000:]
+    r = rows[-1]
+    # cells dofs mv_outer mv_inner reduction fmg_L2error rate fmg_time cg_L2error rate cg_time cg_its cg_reduction
+    assert float(r[4]) == pytest.approx(1.319e-01, rel=0.10)
+    assert float(r[5]) == pytest.approx(4.037e-04, rel=0.05)
+    assert float(r[8]) == pytest.approx(3.822e-04, rel=0.01)
+    assert int(r[11]) == 8
+    assert float(r[12]) == pytest.approx(6.689e-02, rel=0.05)
+
+
 def test_readme_known_answers_on_gpu(ctx):
     """README.md:143 (512 cells): the GPU path itself reproduces the reference's printed numbers."""
     cube = mg.Cube(4, 1, 3)
