@@ -160,6 +160,10 @@ struct mgx_context_s
 {
   int         device = 0;
   hipStream_t stream = nullptr;
+  // interface exchange overlapped with the interior bricks: side stream and the two events that
+  // order it against `stream` (created with the communicator)
+  hipStream_t side     = nullptr;
+  hipEvent_t  ev_iface = nullptr, ev_side = nullptr;
   double     *partial_dev = nullptr; // kDotBlocks block partials
   double     *result_dev  = nullptr; // 4 scalars
   double     *result_host = nullptr; // pinned
@@ -287,13 +291,13 @@ namespace
 
   // Vector::compress(add) for duplicated interface DoFs: every rank ends up with the sum of all
   // sharers' entries, added in ascending rank order on every rank (bitwise identical copies).
-  int exchange_add(mgx_operator_t op, void *vec)
+  int exchange_add(mgx_operator_t op, void *vec, hipStream_t on = nullptr)
   {
     ExchangePlan *P = op->plan.get();
     if (!P)
       return MGX_OK;
     mgx_context_t ctx = op->ctx;
-    hipStream_t   s   = ctx->stream;
+    hipStream_t   s   = on ? on : ctx->stream;
     const int     num = op->d.number;
     if (P->fused)
       launch_pack_all(s, num, P->send.data(), P->start.data(), (int)P->rank.size(), vec, P->all_index_dev,
@@ -344,6 +348,19 @@ namespace
     return MGX_OK;
   }
 
+
+  // side stream + events of the overlapped interface exchange (created with the communicator)
+  int ensure_side_stream(mgx_context_t ctx)
+  {
+    if (ctx->side)
+      return MGX_OK;
+    MGX_HIP(hipSetDevice(ctx->device));
+    MGX_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    MGX_HIP(hipEventCreateWithFlags(&ctx->ev_iface, hipEventDisableTiming));
+    MGX_HIP(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+    return MGX_OK;
+  }
+
   // HIP-event bracket around the cell loop of a profiled operator
   struct ProfileBracket
   {
@@ -383,22 +400,63 @@ namespace
     }
   };
 
+  // The brick loop of a level followed, on a decomposed mesh, by the completion of the interface
+  // DoFs: exchange of their partial sums in `carrier`, then `fix(stream)` = the list kernel(s) that
+  // apply the fused post-operation to them (they were never flagged LAST).
+  // Split schedule (BrickData::n_iface_groups > 0): the bricks on the rank interface run first,
+  // colour by colour; the exchange and the list kernels go to the side stream behind an event and
+  // overlap with the interior bricks, which touch no interface DoF -- the pattern of the
+  // reference's explicit version, laplace_operator_dg.h:986-1057 (send-side cells first,
+  // MPI_Waitall after the interior).  With the callback transport the host blocks in the exchange
+  // while the interior launches, enqueued before, execute.
+  template <typename Launch, typename Fix>
+  int brick_loop_with_exchange(mgx_operator_t op, int form, void *carrier, Launch launch, Fix fix)
+  {
+    mgx_context_t ctx = op->ctx;
+    hipStream_t   s   = ctx->stream;
+    const int     ng = op->d.bricks.n_colours, ni = op->d.bricks.n_iface_groups;
+    if (!op->plan || ni == 0 || !ctx->side)
+      {
+        {
+          ProfileBracket pb(op, form);
+          launch(s, 0, ng);
+        }
+        if (op->plan)
+          {
+            MGX_TRY(exchange_add(op, carrier));
+            fix(s);
+          }
+        return MGX_OK;
+      }
+    {
+      ProfileBracket pb(op, form);
+      launch(s, 0, ni);
+      MGX_HIP(hipEventRecord(ctx->ev_iface, s));
+      MGX_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_iface, 0));
+      launch(s, ni, ng); // enqueued before the (possibly host-blocking) exchange
+    }
+    MGX_TRY(exchange_add(op, carrier, ctx->side));
+    fix(ctx->side);
+    MGX_HIP(hipEventRecord(ctx->ev_side, ctx->side));
+    MGX_HIP(hipStreamWaitEvent(s, ctx->ev_side, 0));
+    return MGX_OK;
+  }
+
   // dst = A src on the unconstrained rows (constrained rows untouched)
   int apply_plain(mgx_operator_t op, void *dst, const void *src)
   {
-    hipStream_t    s = op->ctx->stream;
-    ProfileBracket pb(op, 0);
+    hipStream_t s = op->ctx->stream;
     if (op->d.bricks.available())
-      {
-        static const int ablate = std::getenv("MGX_BRICK_ABLATE") ? std::atoi(std::getenv("MGX_BRICK_ABLATE")) : 0;
-        launch_brick_loop(s, op->d, ablate, src, nullptr, nullptr, dst, dst, 0., 0.);
-      }
-    else
-      {
-        // "zero dst within the loop" (laplace_operator.h:590)
-        MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
-        launch_cell_loop(s, op->d, dst, src);
-      }
+      return brick_loop_with_exchange(
+        op, 0, dst,
+        [&](hipStream_t st, int g0, int g1) {
+          launch_brick_loop(st, op->d, 0, src, nullptr, nullptr, dst, dst, 0., 0., nullptr, 0., nullptr, nullptr, g0, g1);
+        },
+        [](hipStream_t) {});
+    ProfileBracket pb(op, 0);
+    // "zero dst within the loop" (laplace_operator.h:590)
+    MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
+    launch_cell_loop(s, op->d, dst, src);
     return exchange_add(op, dst); // no-op on a single rank
   }
 
@@ -516,6 +574,12 @@ int mgx_context_destroy(mgx_context_t ctx)
         (void)hipEventDestroy(ev.start);
         (void)hipEventDestroy(ev.stop);
       }
+  if (ctx->side)
+    (void)hipStreamDestroy(ctx->side);
+  if (ctx->ev_iface)
+    (void)hipEventDestroy(ctx->ev_iface);
+  if (ctx->ev_side)
+    (void)hipEventDestroy(ctx->ev_side);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MGX_OK;
@@ -537,6 +601,8 @@ int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm)
               "mgx_context_set_comm: bad communicator");
   ctx->comm     = *comm;
   ctx->has_comm = comm->size > 1;
+  if (ctx->has_comm)
+    MGX_TRY(ensure_side_stream(ctx));
   return MGX_OK;
 }
 
@@ -574,6 +640,8 @@ int mgx_context_set_rccl(mgx_context_t ctx, int rank, int size, const void *id12
   ctx->rccl_rank = rank;
   ctx->rccl_size = size;
   ctx->has_comm  = size > 1 || std::getenv("MGX_RCCL_SELFTEST") != nullptr;
+  if (ctx->has_comm)
+    MGX_TRY(ensure_side_stream(ctx));
   ctx->use_rccl  = true;
   return MGX_OK;
 }
@@ -890,16 +958,23 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       // MI355X: between 512 and 4096 bricks for p = 4 and p = 8 (tools/vcycle_levels.py).
       const uint32_t brick_min   = std::getenv("MGX_BRICK_MIN") ? (uint32_t)std::atoi(std::getenv("MGX_BRICK_MIN")) : 2048u;
       const uint32_t brick_cells = p <= 4 ? 64u : 8u;
+      // Decomposed mesh: from this many bricks per rank on, the bricks on the rank interface are
+      // launched first and the exchange overlaps with the interior bricks.  The split costs one
+      // small (latency-bound) launch per colour; DESIGN.md 6 has the measured break-even.
+      const uint32_t overlap_min =
+        std::getenv("MGX_OVERLAP_MIN_BRICKS") ? (uint32_t)std::atol(std::getenv("MGX_OVERLAP_MIN_BRICKS")) : 16384u;
       if (desc->n_dofs >= 0x3FFFFFFFu)
         MGX_TRACE("operator_create: per-cell kernel (%u DoFs do not fit the 30-bit entity index)", desc->n_dofs);
       else if (desc->n_cells / brick_cells < brick_min)
         MGX_TRACE("operator_create: per-cell kernel (%u bricks < %u)", desc->n_cells / brick_cells, brick_min);
       else if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, desc->brick_colour,
-                            ex ? ex->shared : nullptr, ex ? ex->n_shared : 0, bh, why))
+                            ex ? ex->shared : nullptr, ex ? ex->n_shared : 0,
+                            ex && desc->n_cells / brick_cells >= overlap_min, bh, why))
         {
           BrickData &b = d.bricks;
           b.n_bricks   = bh.n_bricks;
           b.n_colours  = bh.n_colours;
+          b.n_iface_groups = bh.n_iface_groups;
           b.order      = bh.order;
           for (int c = 0; c <= bh.n_colours; ++c)
             b.colour_start[c] = bh.colour_start[c];
@@ -1169,17 +1244,16 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
   hipStream_t s = op->ctx->stream;
   if (op->d.bricks.available())
     {
-      // zeroing (:617-623) and rhs - A lhs (:624-631) are fused into the brick loop
-      {
-        ProfileBracket pb(op, 1);
-        launch_brick_loop(s, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0.);
-      }
-      if (op->plan)
-        {
-          // interface DoFs hold partial sums of A lhs: complete them, then rhs - (.)
-          MGX_TRY(exchange_add(op, res));
-          launch_list_residual(s, op->d.number, res, rhs, op->plan->shared_dev, op->plan->n_shared);
-        }
+      // zeroing (:617-623) and rhs - A lhs (:624-631) are fused into the brick loop; interface
+      // DoFs hold partial sums of A lhs: complete them, then rhs - (.)
+      MGX_TRY(brick_loop_with_exchange(
+        op, 1, res,
+        [&](hipStream_t st, int g0, int g1) {
+          launch_brick_loop(st, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0., nullptr, 0., nullptr, nullptr, g0, g1);
+        },
+        [&](hipStream_t st) {
+          launch_list_residual(st, op->d.number, res, rhs, op->plan->shared_dev, op->plan->n_shared);
+        }));
     }
   else
     {
@@ -1414,18 +1488,16 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
-  {
-    ProfileBracket pb(op, mode);
-    launch_brick_loop(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old, f0);
-  }
-  if (op->plan)
-    {
-      // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the
-      // update there
-      MGX_TRY(exchange_add(op, sm->tmp));
-      launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
+  // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the update there
+  MGX_TRY(brick_loop_with_exchange(
+    op, mode, sm->tmp,
+    [&](hipStream_t st, int g0, int g1) {
+      launch_brick_loop(st, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old, f0, nullptr, nullptr, g0, g1);
+    },
+    [&](hipStream_t st) {
+      launch_cheb_constrained(st, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
                               op->plan->n_shared, sm->tmp, old, f0);
-    }
+    }));
   launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
                           op->d.n_constrained, nullptr, old, f0);
   MGX_HIP(hipGetLastError());

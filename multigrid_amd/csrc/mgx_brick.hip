@@ -838,11 +838,11 @@ namespace mgx
   }
 
   template <int P, typename T, int MODE>
-  static void brick_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post)
+  static void brick_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post, int g0, int g1)
   {
     using C               = BCfg<P>;
     const BrickData &bd   = op.bricks;
-    for (int c = 0; c < bd.n_colours; ++c)
+    for (int c = g0; c < g1; ++c)
       {
         const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
         if (count == 0)
@@ -870,7 +870,7 @@ namespace mgx
   template <typename T>
   static void brick_dispatch(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                              const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0,
-                             void *coarse, const uint32_t *coarse_blocks)
+                             void *coarse, const uint32_t *coarse_blocks, int g0, int g1)
   {
     BrickPost<T> post;
     post.f0      = (T)f0;
@@ -887,19 +887,19 @@ namespace mgx
   case PP:                                                                         \
     switch (mode)                                                                  \
       {                                                                            \
-        case kPlain: brick_launch<PP, T, kPlain>(s, op, (const T *)src, post); break; \
-        case kResidual: brick_launch<PP, T, kResidual>(s, op, (const T *)src, post); break; \
-        case kCheb: brick_launch<PP, T, kCheb>(s, op, (const T *)src, post); break; \
-        case kChebFirst: brick_launch<PP, T, kChebFirst>(s, op, (const T *)src, post); break; \
-        case kChebInit: brick_launch<PP, T, kChebInit>(s, op, (const T *)src, post); break; \
-        case kChebOldInit: brick_launch<PP, T, kChebOldInit>(s, op, (const T *)src, post); break; \
-        case kResidualRestrict: brick_launch<PP, T, kResidualRestrict>(s, op, (const T *)src, post); break; \
-        case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post); break; \
-        case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post); break; \
-        case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post); break; \
-        case kNoScatter: brick_launch<PP, T, kNoScatter>(s, op, (const T *)src, post); break; \
-        case kNoBarrier: brick_launch<PP, T, kNoBarrier>(s, op, (const T *)src, post); break; \
-        default: brick_launch<PP, T, kChebZeroOld>(s, op, (const T *)src, post); break; \
+        case kPlain: brick_launch<PP, T, kPlain>(s, op, (const T *)src, post, g0, g1); break; \
+        case kResidual: brick_launch<PP, T, kResidual>(s, op, (const T *)src, post, g0, g1); break; \
+        case kCheb: brick_launch<PP, T, kCheb>(s, op, (const T *)src, post, g0, g1); break; \
+        case kChebFirst: brick_launch<PP, T, kChebFirst>(s, op, (const T *)src, post, g0, g1); break; \
+        case kChebInit: brick_launch<PP, T, kChebInit>(s, op, (const T *)src, post, g0, g1); break; \
+        case kChebOldInit: brick_launch<PP, T, kChebOldInit>(s, op, (const T *)src, post, g0, g1); break; \
+        case kResidualRestrict: brick_launch<PP, T, kResidualRestrict>(s, op, (const T *)src, post, g0, g1); break; \
+        case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post, g0, g1); break; \
+        case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post, g0, g1); break; \
+        case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post, g0, g1); break; \
+        case kNoScatter: brick_launch<PP, T, kNoScatter>(s, op, (const T *)src, post, g0, g1); break; \
+        case kNoBarrier: brick_launch<PP, T, kNoBarrier>(s, op, (const T *)src, post, g0, g1); break; \
+        default: brick_launch<PP, T, kChebZeroOld>(s, op, (const T *)src, post, g0, g1); break; \
       }                                                                            \
     break;
     switch (op.p)
@@ -920,8 +920,10 @@ namespace mgx
 
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0,
-                         void *coarse, const uint32_t *coarse_blocks)
+                         void *coarse, const uint32_t *coarse_blocks, int g0, int g1)
   {
+    if (g1 < 0)
+      g1 = op.bricks.n_colours;
     if (!old)
       old = out;
     if (!src)
@@ -932,14 +934,14 @@ namespace mgx
     if (op.separable && op.bricks.item_map && !cells_form)
       {
         const bool done = op.number == 1
-                            ? launch_macro_loop_f64(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks)
-                            : launch_macro_loop_f32(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
+                            ? launch_macro_loop_f64(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1)
+                            : launch_macro_loop_f32(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
         if (done)
           return;
       }
     if (op.number == 1)
-      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
+      brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
     else
-      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks);
+      brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
   }
 } // namespace mgx

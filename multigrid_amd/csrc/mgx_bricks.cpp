@@ -34,8 +34,8 @@ namespace mgx
   } // namespace
 
   bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
-                    const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, BrickHost &out,
-                    std::string &why)
+                    const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, bool split_interface,
+                    BrickHost &out, std::string &why)
   {
     out = BrickHost();
     if (p < 1 || p > 9)
@@ -182,7 +182,45 @@ namespace mgx
           }
         n_colours = std::max(n_colours, colour[b] + 1);
       }
-    // 4. FIRST / LAST flags of the surface entities from the launch order (= colour order)
+    // 3b. launch groups.  Normally one per colour.  On a decomposed mesh the bricks that touch an
+    //     interface DoF can be launched first (groups 0 .. n_colours-1, colour by colour), so that
+    //     the exchange of the interface sums overlaps with the interior bricks (groups n_colours ..
+    //     2 n_colours-1); the FIRST / LAST flags below follow the group order.
+    std::vector<uint8_t> group(colour);
+    int                  n_groups = n_colours;
+    std::vector<uint8_t> is_shared;
+    if (n_shared > 0)
+      {
+        is_shared.assign(n_dofs, 0);
+        for (uint32_t i = 0; i < n_shared; ++i)
+          is_shared[shared[i]] = 1;
+      }
+    if (split_interface && n_shared > 0 && 2 * n_colours <= kMaxColours)
+      {
+        uint32_t n_iface = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_iface)
+        for (uint32_t b = 0; b < nb; ++b)
+          {
+            bool iface = false;
+            for (int slot = 0; slot < NE && !iface; ++slot)
+              {
+                const uint32_t v = out.ent_base[(size_t)b * NE + slot];
+                iface            = v != kInvalid && is_shared[v];
+              }
+            if (!iface)
+              group[b] = (uint8_t)(colour[b] + n_colours);
+            else
+              ++n_iface;
+          }
+        if (n_iface > 0 && n_iface < nb)
+          {
+            n_groups          = 2 * n_colours;
+            out.n_iface_groups = n_colours;
+          }
+        else
+          group = colour;
+      }
+    // 4. FIRST / LAST flags of the surface entities from the launch order (= group order)
     for (size_t i = 0; i < refs.size();)
       {
         size_t j = i;
@@ -198,9 +236,9 @@ namespace mgx
                   out = BrickHost();
                   return false;
                 }
-            if (colour[refs[a].brick] < colour[refs[lo].brick])
+            if (group[refs[a].brick] < group[refs[lo].brick])
               lo = a;
-            if (colour[refs[a].brick] > colour[refs[hi].brick])
+            if (group[refs[a].brick] > group[refs[hi].brick])
               hi = a;
           }
         out.ent_flags[(size_t)refs[lo].brick * NE + refs[lo].slot] |= 1;
@@ -210,25 +248,22 @@ namespace mgx
     // 4b. interface entities of a decomposed mesh are complete only after the exchange
     if (n_shared > 0)
       {
-        std::vector<uint8_t> is_shared(n_dofs, 0);
-        for (uint32_t i = 0; i < n_shared; ++i)
-          is_shared[shared[i]] = 1;
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < out.ent_base.size(); ++i)
           if (out.ent_base[i] != kInvalid && is_shared[out.ent_base[i]])
             out.ent_flags[i] &= (uint8_t)~2u;
       }
-    // 5. sort the bricks by colour (stable in cell order) and permute the tables
+    // 5. sort the bricks by launch group (stable in cell order) and permute the tables
     std::vector<uint32_t> order(nb);
-    out.colour_start.assign(n_colours + 1, 0);
+    out.colour_start.assign(n_groups + 1, 0);
     for (uint32_t b = 0; b < nb; ++b)
-      out.colour_start[colour[b] + 1]++;
-    for (int c = 0; c < n_colours; ++c)
+      out.colour_start[group[b] + 1]++;
+    for (int c = 0; c < n_groups; ++c)
       out.colour_start[c + 1] += out.colour_start[c];
     {
       std::vector<uint32_t> pos(out.colour_start.begin(), out.colour_start.end() - 1);
       for (uint32_t b = 0; b < nb; ++b)
-        order[pos[colour[b]]++] = b;
+        order[pos[group[b]]++] = b;
     }
     std::vector<uint32_t> base2((size_t)nb * NE);
     std::vector<uint8_t>  flags2((size_t)nb * NE);
@@ -241,7 +276,7 @@ namespace mgx
     out.ent_base.swap(base2);
     out.ent_flags.swap(flags2);
     out.order = order;
-    out.n_colours = n_colours;
+    out.n_colours = n_groups;
     (void)n_dofs;
     return true;
   }

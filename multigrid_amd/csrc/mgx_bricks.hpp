@@ -10,7 +10,8 @@ namespace mgx
   struct BrickHost
   {
     uint32_t              n_bricks  = 0;
-    int                   n_colours = 0;
+    int                   n_colours = 0;      // launch groups (one launch each)
+    int                   n_iface_groups = 0; // leading groups made of the bricks on the rank interface (0: no split)
     int                   n_entities = 729; // entities per brick: 9^3 (4x4x4 cells) or 5^3 (2x2x2 cells)
     std::vector<uint32_t> colour_start; // [n_colours+1] into the colour-sorted brick order
     std::vector<uint32_t> ent_base;     // [n_bricks*729] first DoF per brick entity (constrained: invalid)
@@ -21,9 +22,10 @@ namespace mgx
   // false (with a reason) if the level cannot be scheduled as 4x4x4 bricks
   // shared/n_shared: DoFs duplicated on other ranks (domain decomposition); their entities are
   // never flagged LAST because the sum is only complete after the interface exchange
+  // split_interface: launch the bricks that touch a shared DoF first (see n_iface_groups)
   bool build_bricks(int p, uint32_t n_cells, uint32_t n_dofs, const uint32_t *idx27, const uint32_t *idx27_plain,
-                    const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, BrickHost &out,
-                    std::string &why);
+                    const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, bool split_interface,
+                    BrickHost &out, std::string &why);
 
   // Item table of the macro-element kernel (mgx_macro.hip), one per degree: the (NB p + 1)^3 points
   // of a brick in the order they are gathered and written out.  Entities are taken cell after cell

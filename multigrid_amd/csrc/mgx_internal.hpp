@@ -45,7 +45,8 @@ namespace mgx
   struct BrickData
   {
     uint32_t  n_bricks  = 0;
-    int       n_colours = 0;
+    int       n_colours = 0;       // launch groups
+    int       n_iface_groups = 0;  // leading groups = bricks on the rank interface (0: not split)
     uint32_t  colour_start[33] = {0};
     uint32_t *ent_base  = nullptr; // device [n_bricks * 729]
     uint8_t  *ent_flags = nullptr; // device [n_bricks * 729]  bit0 FIRST, bit1 LAST
@@ -111,17 +112,20 @@ namespace mgx
   //   2: out = src + f1 (src - out) + f2 b (a - A src)      3: same without the f1 term
   // `partial` carries partial sums of brick-surface DoFs between the colour launches
   //   old: previous iterate of mode 2 (nullptr: it is `out`, which is then read before written)
+  // group_begin / group_end: launch groups to run (default: all; the interface / interior halves of
+  // a split schedule are launched separately, BrickData::n_iface_groups)
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr,
-                         double f0 = 0., void *coarse = nullptr, const uint32_t *coarse_blocks = nullptr);
+                         double f0 = 0., void *coarse = nullptr, const uint32_t *coarse_blocks = nullptr,
+                         int group_begin = 0, int group_end = -1);
   // macro-element form of the separable brick loop (mgx_macro.hip), one translation unit per number
   // type; false: mode / degree not covered (the caller falls back to the cell-by-cell form)
   bool launch_macro_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                              const void *b, void *out, void *partial, double f1, double f2, const void *old,
-                             double f0, void *coarse, const uint32_t *coarse_blocks);
+                             double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
   bool launch_macro_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                              const void *b, void *out, void *partial, double f1, double f2, const void *old,
-                             double f0, void *coarse, const uint32_t *coarse_blocks);
+                             double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
   void macro_diag_table_f64(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   void macro_diag_table_f32(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general

@@ -364,7 +364,6 @@ namespace mgx
     using C              = MCfg<P, T>;
     constexpr int G      = C::G;
     constexpr int NT     = C::THREADS;
-    constexpr int NPTS   = C::NPTS;
     constexpr int IT     = C::IT;
     constexpr int LINES  = C::LINES;
     constexpr int NEW    = (C::NE + NT - 1) / NT; // entity words per thread
@@ -843,11 +842,11 @@ namespace mgx
   }
 
   template <int P, typename T, int MODE>
-  static void macro_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post)
+  static void macro_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post, int g0, int g1)
   {
     using C             = MCfg<P, T>;
     const BrickData &bd = op.bricks;
-    for (int c = 0; c < bd.n_colours; ++c)
+    for (int c = g0; c < g1; ++c)
       {
         const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
         if (count == 0)
@@ -872,18 +871,19 @@ namespace mgx
   }
 
   template <int P, typename T>
-  static void macro_modes(hipStream_t s, const OperatorData &op, int mode, const T *src, const BrickPost<T> &post)
+  static void macro_modes(hipStream_t s, const OperatorData &op, int mode, const T *src, const BrickPost<T> &post, int g0,
+                          int g1)
   {
     switch (mode)
       {
-        case kPlain: macro_launch<P, T, kPlain>(s, op, src, post); break;
-        case kResidual: macro_launch<P, T, kResidual>(s, op, src, post); break;
-        case kCheb: macro_launch<P, T, kCheb>(s, op, src, post); break;
-        case kChebFirst: macro_launch<P, T, kChebFirst>(s, op, src, post); break;
-        case kChebZeroOld: macro_launch<P, T, kChebZeroOld>(s, op, src, post); break;
-        case kChebInit: macro_launch<P, T, kChebInit>(s, op, src, post); break;
-        case kChebOldInit: macro_launch<P, T, kChebOldInit>(s, op, src, post); break;
-        case kResidualRestrict: macro_launch<P, T, kResidualRestrict>(s, op, src, post); break;
+        case kPlain: macro_launch<P, T, kPlain>(s, op, src, post, g0, g1); break;
+        case kResidual: macro_launch<P, T, kResidual>(s, op, src, post, g0, g1); break;
+        case kCheb: macro_launch<P, T, kCheb>(s, op, src, post, g0, g1); break;
+        case kChebFirst: macro_launch<P, T, kChebFirst>(s, op, src, post, g0, g1); break;
+        case kChebZeroOld: macro_launch<P, T, kChebZeroOld>(s, op, src, post, g0, g1); break;
+        case kChebInit: macro_launch<P, T, kChebInit>(s, op, src, post, g0, g1); break;
+        case kChebOldInit: macro_launch<P, T, kChebOldInit>(s, op, src, post, g0, g1); break;
+        case kResidualRestrict: macro_launch<P, T, kResidualRestrict>(s, op, src, post, g0, g1); break;
         default: break;
       }
   }
@@ -939,7 +939,7 @@ namespace mgx
   bool MGX_CAT(launch_macro_loop_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, int mode, const void *src,
                                                      const void *a, const void *b, void *out, void *partial,
                                                      double f1, double f2, const void *old, double f0, void *coarse,
-                                                     const uint32_t *coarse_blocks)
+                                                     const uint32_t *coarse_blocks, int g0, int g1)
   {
     using T = MGX_MACRO_T;
     if (mode < kPlain || mode > kResidualRestrict || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
@@ -958,17 +958,17 @@ namespace mgx
     switch (op.p)
       {
 #ifdef MGX_MACRO_ONLY_P
-        case MGX_MACRO_ONLY_P: macro_modes<MGX_MACRO_ONLY_P, T>(s, op, mode, (const T *)src, post); break;
+        case MGX_MACRO_ONLY_P: macro_modes<MGX_MACRO_ONLY_P, T>(s, op, mode, (const T *)src, post, g0, g1); break;
 #else
-        case 1: macro_modes<1, T>(s, op, mode, (const T *)src, post); break;
-        case 2: macro_modes<2, T>(s, op, mode, (const T *)src, post); break;
-        case 3: macro_modes<3, T>(s, op, mode, (const T *)src, post); break;
-        case 4: macro_modes<4, T>(s, op, mode, (const T *)src, post); break;
-        case 5: macro_modes<5, T>(s, op, mode, (const T *)src, post); break;
-        case 6: macro_modes<6, T>(s, op, mode, (const T *)src, post); break;
-        case 7: macro_modes<7, T>(s, op, mode, (const T *)src, post); break;
-        case 8: macro_modes<8, T>(s, op, mode, (const T *)src, post); break;
-        case 9: macro_modes<9, T>(s, op, mode, (const T *)src, post); break;
+        case 1: macro_modes<1, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 2: macro_modes<2, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 3: macro_modes<3, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 4: macro_modes<4, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 5: macro_modes<5, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 6: macro_modes<6, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 7: macro_modes<7, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 8: macro_modes<8, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 9: macro_modes<9, T>(s, op, mode, (const T *)src, post, g0, g1); break;
 #endif
         default: return false;
       }

@@ -22,6 +22,16 @@ def test_block_split_cube_matches_oracle(world, p, nr):
     assert all("gpu ok" in o for o in outs), outs
 
 
+@pytest.mark.parametrize("world,p,nr,extra", [(2, 4, 3, ()), (4, 4, 3, ("strong",)), (2, 8, 2, ()), (2, 4, 3, ("f32",))])
+def test_interface_bricks_first_with_overlapped_exchange(monkeypatch, world, p, nr, extra):
+    """split schedule forced on every brick level (MGX_OVERLAP_MIN_BRICKS=1): the bricks on the rank
+    interface run first, the exchange and the interface post-operation go to the side stream and
+    overlap with the interior bricks; results against the single-domain oracle as above"""
+    monkeypatch.setenv("MGX_OVERLAP_MIN_BRICKS", "1")
+    outs = launch("gpu", world, p, nr, extra=extra)
+    assert all("gpu ok" in o for o in outs), outs
+
+
 def test_bench_launches_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts two ranks itself; here over gloo, both on the one GPU"""
     import json
