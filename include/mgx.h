@@ -218,6 +218,15 @@ int mgx_vmult(mgx_operator_t op, void *dst, const void *src);
 int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void *residual);
 /* LaplaceOperator::compute_diagonal() laplace_operator.h:745-800; the inverse diagonal is kept
  * by the operator (Base::get_matrix_diagonal_inverse()) */
+/* LaplaceOperator::vmult_with_cg_update(alpha, beta, r, q, p, x) :638-719, one pass of the cell loop
+ * with the vector updates of a PCG step in its before / after hooks:
+ *   x += alpha p ;  p = beta p + q ;  q = A p       (alpha == 0:  p = q ;  q = A p)
+ *   sums = { q.p, r.r, q.r, q.q }  over all DoFs (summed over the ranks)
+ * Constrained rows: the vector updates only; q = 0 there (the reference's loop does not touch them).
+ * scratch: device vector of the operator's size and number type that carries partial sums of the
+ * brick loop, or NULL (then allocated once and kept by the operator). */
+int mgx_vmult_with_cg_update(mgx_operator_t op, double alpha, double beta, const void *r, void *q, void *p, void *x,
+                             void *scratch, double sums[4]);
 int mgx_compute_diagonal(mgx_operator_t op);
 int mgx_get_inverse_diagonal(mgx_operator_t op, const void **dptr);
 
@@ -305,6 +314,17 @@ int mgx_solver_solve_hooked(mgx_solver_t solver, int do_analyze, double *reducti
 int mgx_solver_solve_cg(mgx_solver_t solver, unsigned int *iterations, double *reduction_rate);
 /* MultigridSolver::vmult(dst, src) :498-510: one V-cycle; dst/src fp64 device vectors */
 int mgx_solver_vmult(mgx_solver_t solver, double *dst, const double *src);
+/* MultigridSolver::vmult_with_residual_update(residual, update, factor) :516-619: the V-cycle
+ * as preconditioner with the residual update of the PCG step merged into the two precision casts:
+ *   defect = residual + factor update ; V-cycle ; residual += factor update ; update = z
+ *   out = { z.residual, z.(factor update) }   (factor == 0: both z.residual)
+ * Constrained rows ([n - n_constrained, n), numbered last as the reference assumes :525): identity. */
+int mgx_solver_vmult_with_residual_update(mgx_solver_t solver, double *residual, double *update, double factor,
+                                          double out[2]);
+/* PCG as mgx_solver_solve_cg with the matrix-vector product merged with the vector updates
+ * (mgx_vmult_with_cg_update; the CG "fast path with merged vector operations" the reference prepares
+ * the two functions above for, multigrid_solver.h:514-515).  Single rank. */
+int mgx_solver_solve_cg_fused(mgx_solver_t solver, unsigned int *iterations, double *reduction_rate);
 /* MultigridSolver::do_matvec() :624-628 / do_matvec_smoother() :633-637 */
 int mgx_solver_do_matvec(mgx_solver_t solver);
 int mgx_solver_do_matvec_smoother(mgx_solver_t solver);

@@ -472,6 +472,13 @@ class LaplaceOperator:
     def vmult(self, dst, src):
         check(self.lib.mgx_vmult(self.h, dst.ptr, src.ptr))
 
+    def vmult_with_cg_update(self, alpha, beta, r, q, p, x):
+        """laplace_operator.h:638-719; returns the four sums {q.p, r.r, q.r, q.q}"""
+        sums = np.zeros(4)
+        check(self.lib.mgx_vmult_with_cg_update(self.h, alpha, beta, r.ptr, q.ptr, p.ptr, x.ptr, None,
+                                                sums.ctypes.data_as(_lib.f64p)))
+        return sums
+
     def vmult_residual(self, rhs, lhs, residual):
         check(self.lib.mgx_vmult_residual(self.h, rhs.ptr, lhs.ptr, residual.ptr))
 
@@ -605,6 +612,19 @@ class MultigridSolver:
 
     def vmult(self, dst, src):
         check(self.lib.mgx_solver_vmult(self.h, dst.ptr, src.ptr))
+
+    def vmult_with_residual_update(self, residual, update, factor):
+        """multigrid_solver.h:516-619; returns {z.residual, z.(factor update)}"""
+        out = np.zeros(2)
+        check(self.lib.mgx_solver_vmult_with_residual_update(self.h, residual.ptr, update.ptr, factor,
+                                                             out.ctypes.data_as(_lib.f64p)))
+        return out
+
+    def solve_cg_fused(self):
+        its = C.c_uint()
+        red = C.c_double()
+        check(self.lib.mgx_solver_solve_cg_fused(self.h, C.byref(its), C.byref(red)))
+        return its.value, red.value
 
     def do_matvec(self):
         check(self.lib.mgx_solver_do_matvec(self.h))

@@ -196,6 +196,10 @@ struct mgx_operator_s
   uint32_t     *global_index_dev = nullptr; // optional numbering-independent index (smoother start vector)
   double        start_sum = 0, start_count = 0; // sum of (index mod 11) and number of the owned DoFs
   std::unique_ptr<ExchangePlan> plan;       // interface exchange of a decomposed mesh
+  // fused PCG (mgx_vmult_with_cg_update): partial sums, their result, carrier of the brick loop
+  double  *cg_partials = nullptr, *cg_result = nullptr;
+  void    *cg_carrier  = nullptr;
+  bool     constrained_last = false; // the constrained DoFs are exactly [n_dofs - n_constrained, n_dofs)
 };
 
 struct mgx_smoother_s
@@ -850,6 +854,19 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   }
   auto op          = std::make_unique<mgx_operator_s>();
   op->ctx          = ctx;
+  {
+    // (any order inside the list)
+    std::vector<uint8_t> seen(desc->n_constrained, 0);
+    bool                 last = true;
+    for (uint32_t i = 0; i < desc->n_constrained && last; ++i)
+      {
+        const uint32_t c = desc->constrained[i];
+        last             = c >= desc->n_dofs - desc->n_constrained && !seen[c - (desc->n_dofs - desc->n_constrained)];
+        if (last)
+          seen[c - (desc->n_dofs - desc->n_constrained)] = 1;
+      }
+    op->constrained_last = last;
+  }
   OperatorData &d  = op->d;
   d.p              = p;
   d.number         = desc->number;
@@ -1186,6 +1203,9 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);
   (void)hipFree(op->d.diag_items);
+  (void)hipFree(op->cg_partials);
+  (void)hipFree(op->cg_result);
+  (void)hipFree(op->cg_carrier);
   (void)hipFree(op->global_index_dev);
   if (op->plan)
     {
@@ -1262,6 +1282,75 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
     }
   // res[c] -= lhs[c] on constrained rows (:632-633); the loop never touches them
   launch_constrained_residual(s, op->d.number, res, rhs, lhs, op->d.constrained, op->d.n_constrained);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+/* LaplaceOperator::vmult_with_cg_update (laplace_operator.h:638-719) */
+int mgx_vmult_with_cg_update(mgx_operator_t op, double alpha, double beta, const void *r, void *q, void *p, void *x,
+                             void *scratch, double sums[4])
+{
+  MGX_REQUIRE(op && r && q && p && x && sums, "mgx_vmult_with_cg_update: null argument");
+  MGX_REQUIRE(q != p && q != x && p != x && r != q && r != p && r != x, "mgx_vmult_with_cg_update: vectors must not alias");
+  mgx_context_t ctx = op->ctx;
+  hipStream_t   s   = ctx->stream;
+  const int     num = op->d.number;
+  const size_t  n   = op->d.n_dofs;
+  constexpr uint32_t kCapacity = 1u << 16; // quadruples
+  if (!op->cg_partials)
+    {
+      MGX_HIP(hipMalloc((void **)&op->cg_partials, sizeof(double) * 4 * kCapacity));
+      MGX_HIP(hipMalloc((void **)&op->cg_result, sizeof(double) * 4));
+    }
+  bool fused = op->d.bricks.available() && op->d.separable && op->d.bricks.item_map && !op->plan;
+  if (fused)
+    {
+      // the brick loop reads q (the preconditioned residual) while neighbouring bricks already hold
+      // partial sums of the new q = A p: those travel in a separate carrier vector
+      void *carrier = scratch;
+      if (!carrier)
+        {
+          if (!op->cg_carrier)
+            MGX_HIP(hipMalloc(&op->cg_carrier, number_size(num) * n));
+          carrier = op->cg_carrier;
+        }
+      uint32_t used = 0;
+      {
+        ProfileBracket pb(op, 8);
+        fused = num == MGX_F64 ? launch_macro_cg_update_f64(s, op->d, alpha, beta, r, q, p, x, carrier, op->cg_partials,
+                                                            kCapacity - 2048, &used)
+                               : launch_macro_cg_update_f32(s, op->d, alpha, beta, r, q, p, x, carrier, op->cg_partials,
+                                                            kCapacity - 2048, &used);
+      }
+      if (fused)
+        {
+          // constrained rows: the vector updates of the before-loop hook; the cell loop leaves q = 0 there
+          used += launch_cg_list_update(s, num, op->d.constrained, op->d.n_constrained, alpha, beta, r, q, p, x,
+                                        op->cg_partials + 4 * (size_t)used);
+          launch_reduce4(s, op->cg_partials, used, nullptr, op->cg_result);
+          MGX_HIP(hipMemcpyAsync(sums, op->cg_result, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+          MGX_HIP(hipStreamSynchronize(s));
+          MGX_HIP(hipGetLastError());
+          return MGX_OK;
+        }
+    }
+  // levels without the fused kernel / decomposed meshes: the same operations one after the other
+  launch_cg_pre(s, num, x, p, q, alpha, beta, n);
+  MGX_TRY(apply_plain(op, q, p)); // constrained rows stay zero, as in the reference's cell loop
+  if (!ctx->has_comm)
+    {
+      const uint32_t used = launch_dot4(s, num, q, p, r, n, op->cg_partials);
+      launch_reduce4(s, op->cg_partials, used, nullptr, op->cg_result);
+      MGX_HIP(hipMemcpyAsync(sums, op->cg_result, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+    }
+  else
+    {
+      MGX_TRY(dot(ctx, num, q, p, n, &sums[0]));
+      MGX_TRY(dot(ctx, num, r, r, n, &sums[1]));
+      MGX_TRY(dot(ctx, num, q, r, n, &sums[2]));
+      MGX_TRY(dot(ctx, num, q, q, n, &sums[3]));
+    }
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }
@@ -2317,6 +2406,101 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
     *reduction_rate = it > 0 ? std::pow(res / res0, 1. / it) : 1.; // :491-492
   if (it >= 1000)
     return fail(MGX_ERR_NOT_CONVERGED, "mgx_solver_solve_cg: no convergence in 1000 iterations");
+  return MGX_OK;
+}
+
+/* MultigridSolver::vmult_with_residual_update (multigrid_solver.h:516-619); out3 (may be NULL)
+ * additionally receives residual.residual after the update */
+static int residual_update(mgx_solver_t S, double *residual, double *update, double factor, double out[2], double *rr)
+{
+  const int      lmax = S->n_levels - 1;
+  mgx_operator_t A    = S->matrix[lmax];
+  mgx_context_t  ctx  = S->ctx;
+  hipStream_t    s    = ctx->stream;
+  const size_t   n    = A->d.n_dofs;
+  if (!A->constrained_last)
+    return fail(MGX_ERR_UNSUPPORTED, "mgx_solver_vmult_with_residual_update: the constrained DoFs must be numbered last "
+                                     "(local_size_without_constraints, multigrid_solver.h:525)");
+  if (ctx->has_comm)
+    return fail(MGX_ERR_UNSUPPORTED, "mgx_solver_vmult_with_residual_update: single rank only");
+  if (!A->cg_partials)
+    {
+      MGX_HIP(hipMalloc((void **)&A->cg_partials, sizeof(double) * 4 * (1u << 16)));
+      MGX_HIP(hipMalloc((void **)&A->cg_result, sizeof(double) * 4));
+    }
+  const size_t n_free = n - A->d.n_constrained;
+  launch_residual_pre(s, S->vnumber, S->defect[lmax], residual, update, factor, n); // :527-534
+  MGX_TRY(v_cycle(S, lmax, 1));                                                      // :538
+  const uint32_t used =
+    launch_residual_post(s, S->vnumber, S->solution_update[lmax], residual, update, factor, n_free, n, A->cg_partials);
+  launch_reduce4(s, A->cg_partials, used, nullptr, A->cg_result);
+  double h[4];
+  MGX_HIP(hipMemcpyAsync(h, A->cg_result, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+  MGX_HIP(hipStreamSynchronize(s));
+  out[0] = h[0];
+  out[1] = h[1];
+  if (rr)
+    *rr = h[2];
+  return MGX_OK;
+}
+
+int mgx_solver_vmult_with_residual_update(mgx_solver_t S, double *residual, double *update, double factor, double out[2])
+{
+  MGX_REQUIRE(S && residual && update && out && residual != update, "mgx_solver_vmult_with_residual_update: bad argument");
+  return residual_update(S, residual, update, factor, out, nullptr);
+}
+
+/* PCG with the matrix-vector product merged with the vector updates (mgx_vmult_with_cg_update):
+ *   z = M r (q := z) ; loop: {x += alpha p ; p = beta p + q ; q = A p ; q.p} ; alpha = r.z / p.Ap ;
+ *   {r -= alpha q ; r.r} ; {z = M r written into q ; r.z} ; beta = r.z_new / r.z_old
+ * The residual update and the preconditioner are what vmult_with_residual_update merges; here the
+ * V-cycle runs directly on r and q (no copies into and out of the level vectors in fp64), which
+ * moves fewer bytes than the merged form: 3 + 2 instead of 3 + 5 passes next to the V-cycle.
+ * Same iterates as mgx_solver_solve_cg up to round-off. */
+int mgx_solver_solve_cg_fused(mgx_solver_t S, unsigned int *iterations, double *reduction_rate)
+{
+  MGX_REQUIRE(S, "mgx_solver_solve_cg_fused: null solver");
+  const int      lmax = S->n_levels - 1;
+  const size_t   n    = S->matrix[lmax]->d.n_dofs;
+  mgx_context_t  ctx  = S->ctx;
+  hipStream_t    s    = ctx->stream;
+  mgx_operator_t A    = S->matrix_dp[lmax];
+  double        *x = S->solution[lmax], *r = S->cg_r, *q = S->cg_z, *p = S->cg_d;
+  MGX_REQUIRE(!ctx->has_comm, "mgx_solver_solve_cg_fused: single rank only");
+  MGX_HIP(hipMemsetAsync(x, 0, 8 * n, s));
+  MGX_HIP(hipMemsetAsync(p, 0, 8 * n, s));
+  launch_copy_cast(s, r, MGX_F64, S->rhs[lmax], MGX_F64, n);
+  double res0 = 0;
+  MGX_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
+  MGX_TRY(mgx_solver_vmult(S, q, r)); // q = z_0 = M r_0
+  double rz = 0;
+  MGX_TRY(dot(ctx, MGX_F64, r, q, n, &rz));
+  double       alpha = 0., beta = 0., res = res0;
+  unsigned int it = 0;
+  while (res > 1e-16 && res > 1e-9 * res0 && it < 1000) // ReductionControl(1000, 1e-16, 1e-9), :486
+    {
+      ++it;
+      double sums[4];
+      MGX_TRY(mgx_vmult_with_cg_update(A, alpha, beta, r, q, p, x, S->cg_h, sums));
+      alpha = rz / sums[0];
+      const uint32_t used = launch_axpy_norm(s, MGX_F64, r, q, -alpha, n, A->cg_partials);
+      launch_reduce4(s, A->cg_partials, used, nullptr, A->cg_result);
+      MGX_TRY(mgx_solver_vmult(S, q, r));
+      double h[4], rz_new = 0;
+      MGX_HIP(hipMemcpyAsync(h, A->cg_result, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+      MGX_TRY(dot(ctx, MGX_F64, r, q, n, &rz_new)); // synchronises the stream
+      res  = std::sqrt(h[2]);
+      beta = rz_new / rz;
+      rz   = rz_new;
+    }
+  launch_sadd(s, MGX_F64, x, 1., alpha, p, n); // the update of x that the next step would have made
+  if (iterations)
+    *iterations = it;
+  if (reduction_rate)
+    *reduction_rate = it > 0 ? std::pow(res / res0, 1. / it) : 1.;
+  MGX_HIP(hipGetLastError());
+  if (it >= 1000)
+    return fail(MGX_ERR_NOT_CONVERGED, "mgx_solver_solve_cg_fused: no convergence in 1000 iterations");
   return MGX_OK;
 }
 

@@ -89,7 +89,7 @@ namespace mgx
     const uint32_t ip           = need_partial ? idx : 0u;
     const uint32_t il           = last ? idx : 0u;
     const T        pv           = post.partial[ip];
-    if (MODE == kPlain || MODE == kNoCompute)
+    if (MODE == kPlain)
       return need_partial ? val + pv : val;
     else if (MODE == kResidual || MODE == kResidualRestrict)
       {
@@ -167,7 +167,7 @@ namespace mgx
     constexpr int ITB = (NBF + NT - 1) / NT; // iterations of part B
     // plain / residual forms only read partial sums of earlier launches: whole waves whose
     // entities are all FIRST skip pass 1
-    constexpr bool kLoadsOnlyPartials = (MODE == kPlain || MODE == kNoCompute);
+    constexpr bool kLoadsOnlyPartials = MODE == kPlain;
     int slot_rel = 0, pnt_rel = 0, k = 0;
     if (kFixedLane)
       decode_cell_dof<P>(tid % P3, slot_rel, pnt_rel, k);
@@ -771,14 +771,7 @@ namespace mgx
 #pragma unroll
         for (int i = 0; i < N; ++i)
           r[i] = fma(c2, t1[i], r[i]);
-        if (MODE != kNoScatter && MODE != kNoBarrier)
-          lds_barrier(); // all accumulator updates of the previous round have landed
-        if (MODE == kNoScatter)
-          {
-            if (r[0] == T(12345.678))
-              acc[tid] = r[1]; // keep the sweeps alive
-          }
-        else
+        lds_barrier(); // all accumulator updates of the previous round have landed
           {
             // thread (i = a, j = b) owns the z-line: accumulate the column of the brick array.
             // p >= 5: the two cells of the round touch, the second half adds after the first
@@ -804,7 +797,6 @@ namespace mgx
               }
           }
     };
-    if (MODE != kNoCompute && MODE != kInitOnly)
       {
 #pragma unroll 1
         for (int round = 0; round < C::ROUNDS; round += 2)
@@ -815,12 +807,6 @@ namespace mgx
       }
     __syncthreads();
 
-    if (MODE == kNoStore || MODE == kInitOnly || MODE == kNoScatter || MODE == kNoBarrier)
-      {
-        if (acc[tid] == T(12345.678))
-          post.out[tid] = acc[tid]; // keep the rounds alive
-        return;
-      }
     store_brick<P, T, MODE, C::THREADS>(tid, acc, ebase, src, post);
     if (MODE == kResidualRestrict)
       {
@@ -847,7 +833,7 @@ namespace mgx
         const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
         if (count == 0)
           continue;
-        if (op.separable || MODE >= kNoStore)
+        if (op.separable)
           {
             // few bricks per launch (< 4 per CU): the launch lasts one workgroup's latency, which the
             // 512-thread form roughly halves; with the chip full the 256-thread form is faster
@@ -861,7 +847,7 @@ namespace mgx
                                  (T)op.coef[1], (T)op.coef[2], post);
           }
         else if constexpr (P <= 4 && MODE != kChebInit && MODE != kChebOldInit && MODE != kResidualRestrict) // quadrature-point form: 4x4x4 bricks only
-          hipLaunchKernelGGL((brick_loop_kernel<P, T, (MODE >= kNoStore ? 0 : MODE)>), dim3(count),
+          hipLaunchKernelGGL((brick_loop_kernel<P, T, MODE>), dim3(count),
                              dim3(C::THREADS), 0, s, src, first, bd.ent_base, bd.ent_flags,
                              (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
       }
@@ -894,11 +880,6 @@ namespace mgx
         case kChebInit: brick_launch<PP, T, kChebInit>(s, op, (const T *)src, post, g0, g1); break; \
         case kChebOldInit: brick_launch<PP, T, kChebOldInit>(s, op, (const T *)src, post, g0, g1); break; \
         case kResidualRestrict: brick_launch<PP, T, kResidualRestrict>(s, op, (const T *)src, post, g0, g1); break; \
-        case kNoStore: brick_launch<PP, T, kNoStore>(s, op, (const T *)src, post, g0, g1); break; \
-        case kNoCompute: brick_launch<PP, T, kNoCompute>(s, op, (const T *)src, post, g0, g1); break; \
-        case kInitOnly: brick_launch<PP, T, kInitOnly>(s, op, (const T *)src, post, g0, g1); break; \
-        case kNoScatter: brick_launch<PP, T, kNoScatter>(s, op, (const T *)src, post, g0, g1); break; \
-        case kNoBarrier: brick_launch<PP, T, kNoBarrier>(s, op, (const T *)src, post, g0, g1); break; \
         default: brick_launch<PP, T, kChebZeroOld>(s, op, (const T *)src, post, g0, g1); break; \
       }                                                                            \
     break;

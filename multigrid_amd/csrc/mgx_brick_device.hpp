@@ -56,12 +56,10 @@ namespace mgx
     // LAST points, everything else masked to zero) with the transposed embedding and adds the
     // (PB p + 1)^3 coarse values to the coarse vector; the residual itself is never stored.
     kResidualRestrict = 7,
-    // timing-only ablations (MGX_BRICK_ABLATE=8|9 with tools/matvec_loop.py; results are wrong)
-    kNoStore   = 8, // rounds only, no write-out
-    kNoCompute = 9, // write-out only, no rounds
-    kInitOnly  = 10, // prologue only
-    kNoScatter = 11, // rounds without the accumulator update and its barrier, no write-out
-    kNoBarrier = 12  // rounds without the per-round barrier, no write-out
+    // fused PCG step (vmult_with_cg_update, laplace_operator.h:638-719; macro-element kernel only):
+    // the gather forms p_new = f2 p + q (f1 == 0: p_new = q); at completion x += f1 p_old,
+    // p = p_new, q = A p_new, and q.p, r.r, q.r, q.q are accumulated per workgroup
+    kCgUpdate = 8
   };
 
   template <typename T>
@@ -75,6 +73,10 @@ namespace mgx
     T        f1, f2, f0;
     T              *coarse;        // kResidualRestrict: coarse-level vector the restriction adds to
     const uint32_t *coarse_blocks; // kResidualRestrict: coarse entity table of the brick's parents
+    // kCgUpdate: a = r, b = q (second gathered operand), old = x, out = q, f1 = alpha, f2 = beta
+    T              *src_w;         // kCgUpdate: the source vector p, written at completion
+    T              *x_w;           // kCgUpdate: x, updated at completion
+    double         *sums;          // kCgUpdate: [gridDim.x * 4] partial sums of this launch
   };
 
   // Entity table word: bits 0..29 first DoF of the entity, bit 30 FIRST, bit 31 LAST;

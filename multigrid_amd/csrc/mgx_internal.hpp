@@ -126,6 +126,14 @@ namespace mgx
   bool launch_macro_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                              const void *b, void *out, void *partial, double f1, double f2, const void *old,
                              double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
+  // fused PCG step on a brick-scheduled level (mgx_macro.hip, kCgUpdate)
+  bool launch_macro_cg_update_f64(hipStream_t s, const OperatorData &op, double alpha, double beta, const void *r, void *q,
+                                  void *p, void *x, void *carrier, double *partials, uint32_t capacity,
+                                  uint32_t *n_partials);
+  bool launch_macro_cg_update_f32(hipStream_t s, const OperatorData &op, double alpha, double beta, const void *r, void *q,
+                                  void *p, void *x, void *carrier, double *partials, uint32_t capacity,
+                                  uint32_t *n_partials);
+  void launch_reduce4(hipStream_t s, const double *partials, uint32_t n, const double *extra, double *sums);
   void macro_diag_table_f64(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   void macro_diag_table_f32(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
@@ -194,4 +202,15 @@ namespace mgx
   // z = dinv .* r ; result = r.z
   void launch_jacobi_dot(hipStream_t s, int number, void *z, const void *dinv, const void *r, size_t n,
                          double *partial_dev, double *result_dev);
+  // fused PCG helpers (mgx_vector.hip); the uint32_t results are the numbers of sum quadruples the
+  // kernels appended at `partials` (added up by launch_reduce4)
+  uint32_t launch_cg_list_update(hipStream_t s, int number, const uint32_t *list, uint32_t count, double alpha,
+                                 double beta, const void *r, void *q, void *p, void *x, double *partials);
+  uint32_t launch_axpy_norm(hipStream_t s, int number, void *r, const void *q, double factor, size_t n, double *partials);
+  void     launch_cg_pre(hipStream_t s, int number, void *x, void *p, void *q, double alpha, double beta, size_t n);
+  uint32_t launch_dot4(hipStream_t s, int number, const void *q, const void *p, const void *r, size_t n, double *partials);
+  void     launch_residual_pre(hipStream_t s, int defect_number, void *defect, const double *residual, const double *update,
+                               double factor, size_t n);
+  uint32_t launch_residual_post(hipStream_t s, int z_number, const void *z, double *residual, double *update, double factor,
+                                size_t n_free, size_t n, double *partials);
 } // namespace mgx

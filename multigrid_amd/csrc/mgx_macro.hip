@@ -278,7 +278,7 @@ namespace mgx
   template <typename T>
   struct PostRsrc
   {
-    rsrc_t a, b, old, out, partial;
+    rsrc_t a, b, old, out, partial, src, srcw, xw;
   };
 
   // The fused post-operation on one assembled value (what the reference passes as
@@ -316,8 +316,10 @@ namespace mgx
       ld(R.a, ol, o.av);
     if (MODE >= kCheb && MODE <= kChebOldInit && !DTAB)
       ld(R.b, ol, o.bv);
-    if (MODE == kCheb)
+    if (MODE == kCheb || MODE == kCgUpdate)
       ld(R.old, ol, o.ov);
+    if (MODE == kCgUpdate)
+      ld(R.src, ol, o.bv); // p_old, for x += alpha p_old
   }
 
   // bv = inverse diagonal at this DoF (loaded with the operands, or from the per-item table)
@@ -325,7 +327,7 @@ namespace mgx
   __device__ __forceinline__ T post_finish(const BrickPost<T> &post, T pv, T av, T ov, T bv, bool last, T val, T xi)
   {
     val += pv; // out-of-range loads returned zero
-    if (MODE == kPlain)
+    if (MODE == kPlain || MODE == kCgUpdate)
       return val;
     else if (MODE == kResidual || MODE == kResidualRestrict)
       return last ? av - val : val;
@@ -370,8 +372,8 @@ namespace mgx
     constexpr int N = P + 1, NB = C::NB;
     constexpr int REM    = LINES - NT;            // lines beyond the thread count (cell-split pass)
     // the fused Chebyshev forms need the source value again at write-out time
-    constexpr bool kKeepX = MODE >= kCheb && MODE <= kChebOldInit;
-    constexpr int  NG     = (MODE == kChebInit && !DTAB) ? 2 : 1; // operands gathered per value
+    constexpr bool kKeepX = (MODE >= kCheb && MODE <= kChebOldInit) || MODE == kCgUpdate;
+    constexpr int  NG     = ((MODE == kChebInit && !DTAB) || MODE == kCgUpdate) ? 2 : 1; // operands gathered per value
     // two arrays of G^3 values and nothing else: 78.6 kB in fp64 at G = 17, two workgroups per CU.
     // The entity table of a brick has no LDS of its own: it is needed before the first sweep (gather)
     // and after the last one (write-out), when one of the arrays is free, and rests in registers
@@ -426,8 +428,11 @@ namespace mgx
           }
       }
     const rsrc_t      rsrc = make_rsrc(src, vec_bytes);
-    const PostRsrc<T> R{make_rsrc(post.a, vec_bytes), make_rsrc(post.b, vec_bytes), make_rsrc(post.old, vec_bytes),
-                        make_rsrc(post.out, vec_bytes), make_rsrc(post.partial, vec_bytes)};
+    const PostRsrc<T> R{make_rsrc(post.a, vec_bytes),   make_rsrc(post.b, vec_bytes),       make_rsrc(post.old, vec_bytes),
+                        make_rsrc(post.out, vec_bytes), make_rsrc(post.partial, vec_bytes), rsrc,
+                        make_rsrc(MODE == kCgUpdate ? post.src_w : post.out, vec_bytes),
+                        make_rsrc(MODE == kCgUpdate ? post.x_w : post.out, vec_bytes)};
+    double cg[4] = {0., 0., 0., 0.}; // kCgUpdate: q.p, r.r, q.r, q.q over the DoFs this workgroup completes
     const EOMat<T>   &M = B->mass, &K = B->lapl;
 
     uint32_t ec[NEW], en[NEW]; // entity table words of the current / the next brick
@@ -454,6 +459,7 @@ namespace mgx
     T    g[NG][IT];
     auto gather_issue = [&](const uint32_t *E) {
       const rsrc_t r0 = MODE == kChebInit ? (DTAB ? R.a : R.b) : rsrc;
+      const rsrc_t r1 = MODE == kCgUpdate ? R.b : R.a; // second operand
 #pragma unroll
       for (int j = 0; j < JP; ++j)
         {
@@ -465,7 +471,7 @@ namespace mgx
               const uint32_t off = unit_offset(E[item_slot(mw[2 * j])], mw[2 * j]);
               buf_ld2(r0, off, g[0][2 * j], g[0][2 * j + 1]);
               if (NG == 2)
-                buf_ld2(R.a, off, g[NG - 1][2 * j], g[NG - 1][2 * j + 1]);
+                buf_ld2(r1, off, g[NG - 1][2 * j], g[NG - 1][2 * j + 1]);
             }
         }
 #pragma unroll
@@ -478,7 +484,7 @@ namespace mgx
               const uint32_t off = unit_offset(E[item_slot(mw[v])], mw[v]);
               g[0][v]            = buf_ld(r0, off, T());
               if (NG == 2)
-                g[NG - 1][v] = buf_ld(R.a, off, T());
+                g[NG - 1][v] = buf_ld(r1, off, T());
             }
         }
     };
@@ -490,6 +496,8 @@ namespace mgx
           T v = g[0][it];
           if (MODE == kChebInit) // x_1 = (1/theta) D^-1 b, never stored
             v = DTAB ? post.f0 * dv[DTAB ? it : 0] * g[0][it] : post.f0 * g[0][it] * g[NG - 1][it];
+          if (MODE == kCgUpdate) // p = beta p + q, or p = q in the first step (laplace_operator.h:660-688)
+            v = post.f1 == T(0) ? g[NG - 1][it] : post.f2 * g[0][it] + g[NG - 1][it];
           if (live(it))
             U[item_point(mw[it])] = v;
           if (kKeepX)
@@ -686,7 +694,7 @@ namespace mgx
         __syncthreads();
         // (kChebInit gathers two operands per value: too many registers in flight next to the
         // write-out, its gather is issued afterwards)
-        constexpr bool kPipeGather = MODE != kChebInit || DTAB;
+        constexpr bool kPipeGather = (MODE != kChebInit || DTAB) && MODE != kCgUpdate;
         if (has_next && kPipeGather)
           gather_issue(E2);
         MGX_STAMP_IT(7);
@@ -784,6 +792,26 @@ namespace mgx
                                 W[item_point(mw[v0 + 1])] = last ? res[1] : T(0);
                             }
                         }
+                      else if (MODE == kCgUpdate)
+                        {
+                          // completion: q = A p, p = p_new, x += alpha p_old and the four sums;
+                          // otherwise the partial sum goes to the carrier (q still holds z there)
+                          st(R.out, last ? off : kOob);
+                          if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
+                            st(R.partial, last ? kOob : off);
+                          const T xn = o.ov[0] + post.f1 * o.bv[0];
+                          buf_st(R.srcw, last ? off : kOob, xs[kKeepX ? v0 : 0]);
+                          if (post.f1 != T(0))
+                            buf_st(R.xw, last ? off : kOob, xn);
+                          if (last)
+                            {
+                              const double qv = (double)res[0], pn = (double)xs[kKeepX ? v0 : 0], rv = (double)o.av[0];
+                              cg[0] += qv * pn;
+                              cg[1] += rv * rv;
+                              cg[2] += qv * rv;
+                              cg[3] += qv * qv;
+                            }
+                        }
                       else
                         {
                           // out-of-range offsets drop the store; whole waves of interior items skip
@@ -819,6 +847,30 @@ namespace mgx
         MGX_STAMP_IT(10);
         b = bn;
         MGX_STAMP_NEXT();
+      }
+    if (MODE == kCgUpdate)
+      {
+        // deterministic tree reduction of the four sums over the workgroup (U is free)
+        static_assert(MODE != kCgUpdate || !MGX_MACRO_PAIRS, "kCgUpdate is written for single items");
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(U);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          red[k * NT + tid] = cg[k];
+        __syncthreads();
+        constexpr int P2 = NT <= 64 ? 64 : (NT <= 128 ? 128 : (NT <= 256 ? 256 : 512));
+        for (int stride = P2 / 2; stride > 0; stride >>= 1)
+          {
+            if (tid < stride && tid + stride < NT)
+              {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  red[k * NT + tid] += red[k * NT + tid + stride];
+              }
+            __syncthreads();
+          }
+        if (tid < 4)
+          post.sums[blockIdx.x * 4 + tid] = red[tid * NT];
       }
 #ifdef MGX_MACRO_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -889,6 +941,33 @@ namespace mgx
   }
 
   // ------------------------------------------------------------------------------------------
+#if MGX_MACRO_IS_F64
+  // sums[k] = extra[k] + sum of the n partial quadruples, in index order (deterministic)
+  __global__ void reduce4_kernel(const double *__restrict__ partials, uint32_t n, const double *__restrict__ extra,
+                                 double *__restrict__ sums)
+  {
+    __shared__ double red[4 * 256];
+    const int         tid = threadIdx.x;
+    double            acc[4] = {0., 0., 0., 0.};
+    for (uint32_t i = tid; i < n; i += 256)
+      for (int k = 0; k < 4; ++k)
+        acc[k] += partials[4 * (size_t)i + k];
+    for (int k = 0; k < 4; ++k)
+      red[k * 256 + tid] = acc[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1)
+      {
+        if (tid < stride)
+          for (int k = 0; k < 4; ++k)
+            red[k * 256 + tid] += red[k * 256 + tid + stride];
+        __syncthreads();
+      }
+    if (tid < 4)
+      sums[tid] = red[tid * 256] + (extra ? extra[tid] : 0.);
+  }
+#endif
+
+  // ------------------------------------------------------------------------------------------
   // Item-ordered table of the inverse diagonal (DTAB).  collect: every brick writes the value of
   // each of its unconstrained items into the table (all bricks write the same value if the diagonal
   // is periodic); verify: any item of any brick that differs bitwise from the table raises the flag.
@@ -934,6 +1013,74 @@ namespace mgx
     hipLaunchKernelGGL((diag_table_kernel<T, true>), dim3(bd.n_bricks), dim3(256), 0, s, (const T *)op.inv_diag,
                        bd.ent_base, bd.item_map, ne, npts, (T *)table, flag_dev);
   }
+
+  // vmult_with_cg_update on a brick-scheduled level of one rank (mgx_api.cpp handles the rest):
+  // partials receives gridDim x 4 doubles per launch group, *n_partials their total count
+  bool MGX_CAT(launch_macro_cg_update_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, double alpha, double beta,
+                                                           const void *r, void *q, void *p, void *x, void *carrier,
+                                                           double *partials, uint32_t capacity, uint32_t *n_partials)
+  {
+    using T = MGX_MACRO_T;
+    if (MGX_MACRO_PAIRS || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
+      return false;
+    BrickPost<T> post{};
+    post.a       = (const T *)r;
+    post.b       = (const T *)q;
+    post.old     = (const T *)x;
+    post.out     = (T *)q;
+    post.partial = (T *)carrier;
+    post.f1      = (T)alpha;
+    post.f2      = (T)beta;
+    post.src_w   = (T *)p;
+    post.x_w     = (T *)x;
+    const BrickData &bd   = op.bricks;
+    uint32_t         used = 0;
+    auto             run  = [&](auto cfg) {
+      using C = decltype(cfg);
+      for (int c = 0; c < bd.n_colours; ++c)
+        {
+          const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
+          if (count == 0)
+            continue;
+          const uint32_t grid = std::min<uint32_t>(count, (uint32_t)C::WGS * macro_cus());
+          if (used + grid > capacity)
+            return false;
+          post.sums = partials + 4 * (size_t)used;
+          used += grid;
+          hipLaunchKernelGGL((brick_macro_kernel<C::N - 1, T, kCgUpdate, false>), dim3(grid), dim3(C::THREADS), 0, s,
+                             (const T *)p, first, count, bd.ent_base, bd.item_map, (const Basis1D<T> *)op.basis,
+                             (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post, (uint32_t)(op.n_dofs * sizeof(T)));
+        }
+      return true;
+    };
+    bool ok = false;
+    switch (op.p)
+      {
+#ifdef MGX_MACRO_ONLY_P
+        case MGX_MACRO_ONLY_P: ok = run(MCfg<MGX_MACRO_ONLY_P, T>()); break;
+#else
+        case 1: ok = run(MCfg<1, T>()); break;
+        case 2: ok = run(MCfg<2, T>()); break;
+        case 3: ok = run(MCfg<3, T>()); break;
+        case 4: ok = run(MCfg<4, T>()); break;
+        case 5: ok = run(MCfg<5, T>()); break;
+        case 6: ok = run(MCfg<6, T>()); break;
+        case 7: ok = run(MCfg<7, T>()); break;
+        case 8: ok = run(MCfg<8, T>()); break;
+        case 9: ok = run(MCfg<9, T>()); break;
+#endif
+        default: break;
+      }
+    *n_partials = used;
+    return ok;
+  }
+
+#if MGX_MACRO_IS_F64
+  void launch_reduce4(hipStream_t s, const double *partials, uint32_t n, const double *extra, double *sums)
+  {
+    hipLaunchKernelGGL(reduce4_kernel, dim3(1), dim3(256), 0, s, partials, n, extra, sums);
+  }
+#endif
 
   // one translation unit per number type (Makefile: -DMGX_MACRO_T=double|float -DMGX_MACRO_SUFFIX=f64|f32)
   bool MGX_CAT(launch_macro_loop_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, int mode, const void *src,

@@ -572,4 +572,176 @@ namespace mgx
                                          (const T *)r, n, partial_dev));
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
   }
+
+  // ------------------------------------------------------------------------------------------
+  // fused PCG helpers (vmult_with_cg_update / vmult_with_residual_update of the reference)
+  // ------------------------------------------------------------------------------------------
+  // quadruple of block sums, appended to a partials array that launch_reduce4 adds up in order
+  __device__ __forceinline__ void block_sum4(double (&s)[4], double *__restrict__ out)
+  {
+    for (int k = 0; k < 4; ++k)
+      {
+        const double t = block_sum(s[k]);
+        if (threadIdx.x == 0)
+          out[4 * blockIdx.x + k] = t;
+        __syncthreads();
+      }
+  }
+
+  // laplace_operator.h:655-688 on an index list (the constrained rows, which the cell loop never
+  // touches): x += alpha p ; p = beta p + q ; q = 0   (alpha == 0: p = q ; q = 0);  sums: r.r only
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_cg_list_update(const uint32_t *__restrict__ list, uint32_t count, T alpha, T beta, const T *__restrict__ r,
+                     T *__restrict__ q, T *__restrict__ p, T *__restrict__ x, double *__restrict__ partial)
+  {
+    double s[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(j, count)
+    {
+      const uint32_t i = list[j];
+      if (alpha == T(0))
+        p[i] = q[i];
+      else
+        {
+          x[i] += alpha * p[i];
+          p[i] = beta * p[i] + q[i];
+        }
+      q[i] = T(0);
+      s[1] += (double)r[i] * (double)r[i];
+    }
+    block_sum4(s, partial);
+  }
+
+  // the same over a whole vector (levels without the fused brick kernel), before the matvec
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_cg_pre(T *__restrict__ x, T *__restrict__ p, T *__restrict__ q, T alpha, T beta, size_t n)
+  {
+    GRID_STRIDE(i, n)
+    {
+      if (alpha == T(0))
+        p[i] = q[i];
+      else
+        {
+          x[i] += alpha * p[i];
+          p[i] = beta * p[i] + q[i];
+        }
+      q[i] = T(0);
+    }
+  }
+
+  // q.p, r.r, q.r, q.q in one pass
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_dot4(const T *__restrict__ q, const T *__restrict__ p, const T *__restrict__ r, size_t n, double *__restrict__ partial)
+  {
+    double s[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n)
+    {
+      const double qi = q[i], pi = p[i], ri = r[i];
+      s[0] += qi * pi;
+      s[1] += ri * ri;
+      s[2] += qi * ri;
+      s[3] += qi * qi;
+    }
+    block_sum4(s, partial);
+  }
+
+  // multigrid_solver.h:527-534: defect = residual + factor update (precision cast)
+  template <typename TD>
+  __global__ void __launch_bounds__(256)
+    k_residual_pre(TD *__restrict__ defect, const double *__restrict__ residual, const double *__restrict__ update,
+                   double factor, size_t n)
+  {
+    GRID_STRIDE(i, n) defect[i] = (TD)(factor != 0. ? residual[i] + factor * update[i] : residual[i]);
+  }
+
+  // multigrid_solver.h:545-603: residual += factor update ; {z.res, z.(factor update), res.res} ;
+  // update = z  -- rows [n_free, n) are constrained: identity on the diagonal, z := res
+  template <typename TZ>
+  __global__ void __launch_bounds__(256)
+    k_residual_post(const TZ *__restrict__ z, double *__restrict__ residual, double *__restrict__ update, double factor,
+                    size_t n_free, size_t n, double *__restrict__ partial)
+  {
+    double s[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n)
+    {
+      const double upd = factor != 0. ? update[i] * factor : 0.;
+      const double res = residual[i] + upd;
+      const double zi  = i < n_free ? (double)z[i] : res;
+      residual[i]      = res;
+      update[i]        = zi;
+      s[0] += zi * res;
+      s[1] += factor != 0. ? zi * upd : zi * res;
+      s[2] += res * res;
+    }
+    block_sum4(s, partial);
+  }
+
+  // r += factor q ; partial quadruples {0, 0, r.r, 0} (slot 2, as launch_residual_post)
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_axpy_norm(T *__restrict__ r, const T *__restrict__ q, T factor, size_t n, double *__restrict__ partial)
+  {
+    double s[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n)
+    {
+      const T ri = r[i] + factor * q[i];
+      r[i]       = ri;
+      s[2] += (double)ri * (double)ri;
+    }
+    block_sum4(s, partial);
+  }
+
+  uint32_t launch_axpy_norm(hipStream_t s, int number, void *r, const void *q, double factor, size_t n, double *partials)
+  {
+    const dim3 g = reduce_grid(n);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_axpy_norm<T>), g, dim3(256), 0, s, (T *)r, (const T *)q, (T)factor, n, partials));
+    return g.x;
+  }
+
+  uint32_t launch_cg_list_update(hipStream_t s, int number, const uint32_t *list, uint32_t count, double alpha,
+                                 double beta, const void *r, void *q, void *p, void *x, double *partials)
+  {
+    if (count == 0)
+      return 0;
+    const dim3 g = reduce_grid(count);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_cg_list_update<T>), g, dim3(256), 0, s, list, count, (T)alpha, (T)beta,
+                                         (const T *)r, (T *)q, (T *)p, (T *)x, partials));
+    return g.x;
+  }
+
+  void launch_cg_pre(hipStream_t s, int number, void *x, void *p, void *q, double alpha, double beta, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_cg_pre<T>), stream_grid(n), dim3(256), 0, s, (T *)x, (T *)p, (T *)q,
+                                         (T)alpha, (T)beta, n));
+  }
+
+  uint32_t launch_dot4(hipStream_t s, int number, const void *q, const void *p, const void *r, size_t n, double *partials)
+  {
+    const dim3 g = reduce_grid(n);
+    BY_NUMBER(number, hipLaunchKernelGGL((k_dot4<T>), g, dim3(256), 0, s, (const T *)q, (const T *)p, (const T *)r, n,
+                                         partials));
+    return g.x;
+  }
+
+  void launch_residual_pre(hipStream_t s, int defect_number, void *defect, const double *residual, const double *update,
+                           double factor, size_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(defect_number, hipLaunchKernelGGL((k_residual_pre<T>), stream_grid(n), dim3(256), 0, s, (T *)defect, residual,
+                                                update, factor, n));
+  }
+
+  uint32_t launch_residual_post(hipStream_t s, int z_number, const void *z, double *residual, double *update, double factor,
+                                size_t n_free, size_t n, double *partials)
+  {
+    const dim3 g = reduce_grid(n);
+    BY_NUMBER(z_number, hipLaunchKernelGGL((k_residual_post<T>), g, dim3(256), 0, s, (const T *)z, residual, update, factor,
+                                           n_free, n, partials));
+    return g.x;
+  }
 } // namespace mgx

@@ -72,6 +72,8 @@ def lib():
     L.orc_bc.argtypes = [vp, C.c_int, _u32p, _f64p]
     L.orc_vmult.argtypes = [vp, C.c_int, _f64p, _f64p]
     L.orc_vmult_residual.argtypes = [vp, C.c_int, _f64p, _f64p, _f64p]
+    L.orc_vmult_with_cg_update.argtypes = [vp, C.c_int, C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p, _f64p]
+    L.orc_vmult_with_residual_update.argtypes = [vp, _f64p, _f64p, C.c_double, _f64p]
     L.orc_vmult_dense_lex.argtypes = [vp, C.c_int, _f64p, _f64p]
     L.orc_cheb_vmult.argtypes = [vp, C.c_int, _f64p, _f64p]
     L.orc_cheb_step.argtypes = [vp, C.c_int, _f64p, _f64p]
@@ -253,6 +255,18 @@ class Oracle:
         dst = np.empty_like(src)
         self.L.orc_vcycle_apply(self.h, _p(dst), _p(src))
         return dst
+
+    def vmult_with_cg_update(self, l, alpha, beta, r, q, p, x):
+        """in place on q, p, x (contiguous float64 arrays); returns the four sums"""
+        sums = np.zeros(4)
+        self.L.orc_vmult_with_cg_update(self.h, l, alpha, beta, _p(r), _p(q), _p(p), _p(x), _p(sums))
+        return sums
+
+    def vmult_with_residual_update(self, residual, update, factor):
+        """in place on residual, update; returns {z.res, z.(factor upd), res.res}"""
+        out = np.zeros(3)
+        self.L.orc_vmult_with_residual_update(self.h, _p(residual), _p(update), factor, _p(out))
+        return out
 
     def solve(self, analyze=False):
         trace = np.zeros(4 * self.n_levels)

@@ -1060,6 +1060,70 @@ double orc_solve(orc_problem *P, int do_analyze, double *trace)
 
 /* MultigridSolver::solve_cg (multigrid_solver.h:483-493) with deal.II's SolverCG restated
  * (SURVEY 8a row T): ReductionControl(1000, 1e-16, 1e-9), zero start, V-cycle preconditioner */
+/* LaplaceOperator::vmult_with_cg_update (laplace_operator.h:638-719): the vector updates of the
+ * before-loop hook on every range (:655-688), the cell loop q = A p (:650-654; constrained rows are
+ * not touched and keep the zero the hook wrote), the four sums of the after-loop hook (:689-713) */
+void orc_vmult_with_cg_update(const orc_problem *P, int l, double alpha, double beta, const double *r, double *q, double *p,
+                              double *x, double *sums)
+{
+  const orc_level *L = &P->levels[l];
+  const uint32_t   n = L->n_dofs;
+  for (uint32_t i = 0; i < n; ++i)
+    {
+      if (alpha == 0.)
+        p[i] = q[i];
+      else
+        {
+          x[i] += alpha * p[i];
+          p[i] = beta * p[i] + q[i];
+        }
+      q[i] = 0.;
+    }
+  vmult_d(P, L, BD(P), q, p);
+  for (uint32_t i = 0; i < L->n_constrained; ++i)
+    q[L->constrained[i]] = 0.;
+  sums[0] = sums[1] = sums[2] = sums[3] = 0.;
+  for (uint32_t i = 0; i < n; ++i)
+    {
+      sums[0] += q[i] * p[i];
+      sums[1] += r[i] * r[i];
+      sums[2] += q[i] * r[i];
+      sums[3] += q[i] * q[i];
+    }
+}
+
+/* MultigridSolver::vmult_with_residual_update (multigrid_solver.h:516-619).  Constrained rows:
+ * identity on the diagonal (:570-577, 598-603); out[2] = residual . residual after the update
+ * (not part of the reference's return value; used by the tests of the fused PCG) */
+void orc_vmult_with_residual_update(orc_problem *P, double *residual, double *update, double factor, double *out)
+{
+  const int        lmax = P->n_levels - 1;
+  const orc_level *L    = &P->levels[lmax];
+  const uint32_t   n    = L->n_dofs;
+  unsigned char   *cons = (unsigned char *)calloc(n, 1);
+  double          *def = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n);
+  for (uint32_t i = 0; i < L->n_constrained; ++i)
+    cons[L->constrained[i]] = 1;
+  for (uint32_t i = 0; i < n; ++i) /* :527-534 */
+    def[i] = factor != 0. ? residual[i] + factor * update[i] : residual[i];
+  orc_vcycle_apply(P, z, def); /* :538 */
+  out[0] = out[1] = out[2] = 0.;
+  for (uint32_t i = 0; i < n; ++i) /* :545-603 */
+    {
+      const double upd = factor != 0. ? update[i] * factor : 0.;
+      const double res = residual[i] + upd;
+      const double zi  = cons[i] ? res : z[i];
+      residual[i]      = res;
+      update[i]        = zi;
+      out[0] += zi * res;
+      out[1] += factor != 0. ? zi * upd : zi * res;
+      out[2] += res * res;
+    }
+  free(cons);
+  free(def);
+  free(z);
+}
+
 int orc_solve_cg(orc_problem *P, double *reduction)
 {
   const int        lmax = P->n_levels - 1;

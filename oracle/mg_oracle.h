@@ -76,6 +76,10 @@ uint32_t orc_bc(const orc_problem *P, int level, uint32_t *idx, double *val);
 
 /* LaplaceOperator (fp64 instance matrix_dp; 'vf' variants use the V-cycle number type) */
 void orc_vmult(const orc_problem *P, int level, double *dst, const double *src);
+/* laplace_operator.h:638-719 / multigrid_solver.h:516-619 (out[3]: z.res, z.(factor upd), res.res) */
+void orc_vmult_with_cg_update(const orc_problem *P, int level, double alpha, double beta, const double *r, double *q,
+                              double *p, double *x, double *sums);
+void orc_vmult_with_residual_update(orc_problem *P, double *residual, double *update, double factor, double *out);
 void orc_vmult_residual(const orc_problem *P, int level, const double *rhs, const double *lhs,
                         double *res);
 /* dense reference: assembles the element matrix with plain gradients (no sum factorisation,

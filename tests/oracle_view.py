@@ -85,6 +85,18 @@ class OracleView:
         return self.to_c(l - 1, self.orc.restrict_and_add(l, self.to_o(l - 1, coarse), self.to_o(l, fine),
                                                           with_bc=with_bc))
 
+    def vmult_with_cg_update(self, l, alpha, beta, r, q, p, x):
+        """returns (sums, q, p, x) in the cube's numbering; the inputs are not modified"""
+        ro, qo, po, xo = (self.to_o(l, a).copy() for a in (r, q, p, x))
+        sums = self.orc.vmult_with_cg_update(l, alpha, beta, ro, qo, po, xo)
+        return sums, self.to_c(l, qo), self.to_c(l, po), self.to_c(l, xo)
+
+    def vmult_with_residual_update(self, residual, update, factor):
+        l = self.lmax
+        ro, uo = self.to_o(l, residual).copy(), self.to_o(l, update).copy()
+        out = self.orc.vmult_with_residual_update(ro, uo, factor)
+        return out, self.to_c(l, ro), self.to_c(l, uo)
+
     def vcycle(self, src):
         l = self.lmax
         return self.to_c(l, self.orc.vcycle(self.to_o(l, src)))

@@ -320,6 +320,59 @@ def test_poisson_cube_driver_reproduces_the_readme_row():
     assert float(r[12]) == pytest.approx(6.689e-02, rel=0.05)
 
 
+@pytest.mark.parametrize("p,ns,nr", [(4, 1, 3), (2, 1, 3), (3, 3, 2), (8, 1, 2), (4, 1, 1)])
+def test_vmult_with_cg_update(ctx, p, ns, nr):
+    """laplace_operator.h:638-719: x += alpha p; p = beta p + q; q = A p and the four sums, fused
+    into the brick loop (levels with bricks) or run one after the other (coarse levels)"""
+    cube = mg.Cube(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr)
+    for l in range(cube.n_levels):
+        A = mg.LaplaceOperator.from_cube(ctx, cube, l)
+        vecs = [cube.seeded_vector(l, s) for s in (11, 12, 13, 14)]
+        for alpha, beta in ((0., 0.), (0.37, 0.81)):
+            r, q, pp, x = (ctx.vector(v.size, data=v) for v in vecs)
+            sums = A.vmult_with_cg_update(alpha, beta, r, q, pp, x)
+            osums, oq, op_, ox = orc.vmult_with_cg_update(l, alpha, beta, *vecs)
+            np.testing.assert_allclose(sums, osums, rtol=1e-11, atol=1e-11 * abs(osums).max())
+            assert rel(q.download(), oq) < 1e-12
+            assert rel(pp.download(), op_) < 1e-14
+            assert rel(x.download(), ox) < 1e-14
+        A.clear()
+    cube.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("number", ["f64", "f32"])
+def test_fused_pcg(ctx, number):
+    """multigrid_solver.h:516-619 and the PCG built on the two merged operations: same iteration
+    count and error as the plain PCG and as the oracle's"""
+    vf = number == "f32"
+    cube = mg.Cube(4, 1, 3)
+    orc = oracle_for(cube, 4, 1, 3, degree=3, n_cycles=1, vfloat=vf)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32 if vf else mg.F64)
+    l = cube.max_level
+    res, upd = cube.seeded_vector(l, 21), cube.seeded_vector(l, 22)
+    for factor in (0., -0.43):
+        r, u = ctx.vector(res.size, data=res), ctx.vector(res.size, data=upd)
+        out = solver.vmult_with_residual_update(r, u, factor)
+        oout, ores, oupd = orc.vmult_with_residual_update(res, upd, factor)
+        tol = 2e-4 if vf else 1e-9
+        np.testing.assert_allclose(out, oout[:2], rtol=tol)
+        assert rel(r.download(), ores) < 1e-14
+        assert rel(u.download(), oupd) < tol
+    its, red = solver.solve_cg()
+    err = solver.compute_l2_error()
+    fits, fred = solver.solve_cg_fused()
+    ferr = solver.compute_l2_error()
+    oits, ored = orc.solve_cg()
+    assert fits == its == oits
+    assert fred == pytest.approx(red, rel=1e-3 if vf else 1e-6)
+    assert ferr == pytest.approx(err, rel=1e-6)
+    solver.close()
+    cube.close()
+    orc.close()
+
+
 def test_readme_known_answers_on_gpu(ctx):
     """README.md:143 (512 cells): the GPU path itself reproduces the reference's printed numbers."""
     cube = mg.Cube(4, 1, 3)
