@@ -100,7 +100,9 @@ int mgx_rccl_unique_id(void *id_out);
 int mgx_context_set_rccl(mgx_context_t ctx, int rank, int size, const void *id);
 int mgx_context_use_rccl(mgx_context_t ctx, int enable);
 
-/* exchange plan of one level vector layout (host lists, copied) */
+/* exchange plan of one level vector layout (host lists, copied).  Only unconstrained DoFs are
+ * exchanged: a Dirichlet DoF on a rank interface is an identity row on every rank that holds it and
+ * must not appear in index[] / shared[] (mgx_operator_create rejects such a plan). */
 typedef struct
 {
   int                    plan_id;       /* caller's identifier, passed back to exchange() */

@@ -64,12 +64,10 @@ namespace
 
   inline size_t number_size(int number) { return number == MGX_F64 ? 8 : 4; }
 
-  // MGX_TRACE=1 prints the host-side control flow to stderr (debugging aid)
-  bool trace_on()
-  {
-    static const bool on = std::getenv("MGX_TRACE") != nullptr;
-    return on;
-  }
+  // MGX_TRACE=1 prints the host-side control flow to stderr (debugging aid); set by the first
+  // context created with it
+  bool g_trace = false;
+  bool trace_on() { return g_trace; }
 #define MGX_TRACE(...)                  \
   do                                    \
     {                                   \
@@ -82,6 +80,35 @@ namespace
     }                                   \
   while (0)
 } // namespace
+
+mgx::Tunables mgx::Tunables::from_environment()
+{
+  Tunables t;
+  auto     flag = [](const char *name) { return std::getenv(name) != nullptr; };
+  auto     num  = [](const char *name, uint32_t dflt) {
+    const char *e = std::getenv(name);
+    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
+  };
+  t.trace               = flag("MGX_TRACE");
+  t.general_kernel      = flag("MGX_GENERAL_KERNEL");
+  t.no_bricks           = flag("MGX_NO_BRICKS");
+  t.brick_min           = num("MGX_BRICK_MIN", t.brick_min);
+  t.overlap_min         = num("MGX_OVERLAP_MIN_BRICKS", t.overlap_min);
+  t.cells_form          = std::getenv("MGX_BRICK_FORM") && std::string(std::getenv("MGX_BRICK_FORM")) == "cells";
+  t.wide_max            = num("MGX_BRICK_WIDE_MAX", t.wide_max);
+  t.macro_wg_x16        = num("MGX_MACRO_WG_PER_CU_X16", 0);
+  t.no_diag_table       = flag("MGX_NO_DIAG_TABLE");
+  t.no_fused_init       = flag("MGX_NO_FUSED_INIT");
+  t.no_fused_restrict   = flag("MGX_NO_FUSED_RESTRICT");
+  t.transfer_v1         = flag("MGX_TRANSFER_V1");
+  t.restrict_atomic     = flag("MGX_RESTRICT_ATOMIC");
+  t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
+  t.exchange_unfused    = flag("MGX_EXCHANGE_UNFUSED");
+  t.no_graph            = flag("MGX_NO_GRAPH");
+  t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
+  t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
+  return t;
+}
 
 struct ExchangePlan
 {
@@ -159,6 +186,7 @@ static RcclApi &rccl_api()
 struct mgx_context_s
 {
   int         device = 0;
+  Tunables    tun; // environment switches, read once in mgx_context_create
   hipStream_t stream = nullptr;
   // interface exchange overlapped with the interior bricks: side stream and the two events that
   // order it against `stream` (created with the communicator)
@@ -274,22 +302,38 @@ namespace
 
   // x.y over the DoFs this rank owns, summed over the ranks (Vector::operator* / l2_norm with
   // MPI_Allreduce in the reference).  The exchange plan is looked up by the vector length.
-  int dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *out)
+  // plan: the ownership plan of the operator the vectors belong to.  nullptr on a decomposed
+  // context: looked up by the vector length among the registered operators, which must be
+  // unambiguous (the public mgx_dot / mgx_l2_norm take no operator).
+  int dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *out,
+          const ExchangePlan *plan = nullptr)
   {
     launch_dot(ctx->stream, number, x, y, n, ctx->partial_dev, ctx->result_dev);
     MGX_TRY(read_result(ctx, out));
     if (!ctx->has_comm)
       return MGX_OK;
-    for (auto &pr : ctx->plans)
-      if (pr.first == n && pr.second->n_not_owned > 0)
-        {
-          double dup = 0;
-          launch_dot_list(ctx->stream, number, x, y, pr.second->not_owned_dev, pr.second->n_not_owned,
-                          ctx->partial_dev, ctx->result_dev);
-          MGX_TRY(read_result(ctx, &dup));
-          *out -= dup;
-          break;
-        }
+    if (!plan)
+      {
+        for (auto &pr : ctx->plans)
+          if (pr.first == n)
+            {
+              if (plan && (plan->n_not_owned != pr.second->n_not_owned || plan->plan_id != pr.second->plan_id))
+                return fail(MGX_ERR_INVALID_ARGUMENT, "dot: two operators of this context have vectors of this length but "
+                                                      "different ownership; reductions need the operator");
+              plan = pr.second;
+            }
+        if (!plan)
+          return fail(MGX_ERR_INVALID_ARGUMENT, "dot: no operator with vectors of this length is registered on this "
+                                                "decomposed context (duplicated interface DoFs could not be discounted)");
+      }
+    if (plan->n_not_owned > 0)
+      {
+        double dup = 0;
+        launch_dot_list(ctx->stream, number, x, y, plan->not_owned_dev, plan->n_not_owned, ctx->partial_dev,
+                        ctx->result_dev);
+        MGX_TRY(read_result(ctx, &dup));
+        *out -= dup;
+      }
     return comm_allreduce(ctx, out, 1);
   }
 
@@ -553,6 +597,8 @@ int mgx_context_create(mgx_context_t *out, int device)
   MGX_HIP(hipSetDevice(device));
   auto ctx    = new mgx_context_s;
   ctx->device = device;
+  ctx->tun    = Tunables::from_environment();
+  g_trace     = g_trace || ctx->tun.trace;
   MGX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   MGX_HIP(hipMalloc((void **)&ctx->partial_dev, sizeof(double) * kDotBlocks));
   MGX_HIP(hipMalloc((void **)&ctx->result_dev, sizeof(double) * 4));
@@ -643,7 +689,7 @@ int mgx_context_set_rccl(mgx_context_t ctx, int rank, int size, const void *id12
   MGX_HIP(hipMalloc((void **)&ctx->ar_dev, 8 * sizeof(double)));
   ctx->rccl_rank = rank;
   ctx->rccl_size = size;
-  ctx->has_comm  = size > 1 || std::getenv("MGX_RCCL_SELFTEST") != nullptr;
+  ctx->has_comm  = size > 1 || ctx->tun.rccl_selftest;
   if (ctx->has_comm)
     MGX_TRY(ensure_side_stream(ctx));
   ctx->use_rccl  = true;
@@ -942,7 +988,11 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   };
   // the separable fast path needs the symmetry A[a][b] = A[n-1-a][n-1-b] of M and K (true for
   // any symmetric node/quadrature set); MGX_GENERAL_KERNEL=1 forces the quadrature-point form
-  d.separable = !std::getenv("MGX_GENERAL_KERNEL");
+  const Tunables &tun = ctx->tun;
+  d.separable        = !tun.general_kernel;
+  d.cells_form       = tun.cells_form;
+  d.wide_max         = tun.wide_max;
+  d.macro_wg_x16     = tun.macro_wg_x16;
   for (int a = 0; a < n && d.separable; ++a)
     for (int bb = 0; bb < n; ++bb)
       if (std::fabs(M1[a * n + bb] - M1[(n - 1 - a) * n + n - 1 - bb]) > 1e-12 ||
@@ -965,7 +1015,7 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   MGX_HIP(hipMalloc(&d.inv_diag, number_size(d.number) * d.n_dofs));
   // brick schedule for the atomic-free cell loop (mgx_brick.hip); MGX_NO_BRICKS=1 keeps the
   // per-cell kernel (A/B measurements)
-  if (!std::getenv("MGX_NO_BRICKS") && (p <= 4 || d.separable))
+  if (!tun.no_bricks && (p <= 4 || d.separable))
     {
       BrickHost   bh;
       std::string why;
@@ -973,13 +1023,12 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       // A colour launch needs a few hundred bricks to fill 256 CUs; below that the per-cell kernel
       // (all cells of the level in one launch, atomic scatter) is faster.  Measured cross-over on
       // MI355X: between 512 and 4096 bricks for p = 4 and p = 8 (tools/vcycle_levels.py).
-      const uint32_t brick_min   = std::getenv("MGX_BRICK_MIN") ? (uint32_t)std::atoi(std::getenv("MGX_BRICK_MIN")) : 2048u;
+      const uint32_t brick_min   = tun.brick_min;
       const uint32_t brick_cells = p <= 4 ? 64u : 8u;
       // Decomposed mesh: from this many bricks per rank on, the bricks on the rank interface are
       // launched first and the exchange overlaps with the interior bricks.  The split costs one
       // small (latency-bound) launch per colour; DESIGN.md 6 has the measured break-even.
-      const uint32_t overlap_min =
-        std::getenv("MGX_OVERLAP_MIN_BRICKS") ? (uint32_t)std::atol(std::getenv("MGX_OVERLAP_MIN_BRICKS")) : 16384u;
+      const uint32_t overlap_min = tun.overlap_min;
       if (desc->n_dofs >= 0x3FFFFFFFu)
         MGX_TRACE("operator_create: per-cell kernel (%u DoFs do not fit the 30-bit entity index)", desc->n_dofs);
       else if (desc->n_cells / brick_cells < brick_min)
@@ -1050,7 +1099,7 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       const size_t es = number_size(d.number);
       const int    my_rank = (ctx->nccl && !ctx->comm.exchange) ? ctx->rccl_rank : ctx->comm.rank;
       // MGX_RCCL_SELFTEST: a one-rank communicator may name itself as neighbour (tools/rccl_selftest.py)
-      const bool   selftest = std::getenv("MGX_RCCL_SELFTEST") != nullptr;
+      const bool   selftest = tun.rccl_selftest;
       for (int k = 0; k < e.n_neighbors; ++k)
         {
           MGX_REQUIRE(selftest ||
@@ -1088,6 +1137,22 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       for (uint32_t i = 0; i < e.n_shared; ++i)
         if (e.shared[i] >= desc->n_dofs)
           return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: shared index out of range");
+      {
+        // Dirichlet DoFs are never exchanged: their rows are the identity on every rank, and the
+        // interface post-operations assume the two lists to be disjoint (mgx.h, mgx_exchange_desc)
+        std::vector<uint8_t> is_constrained(desc->n_dofs, 0);
+        for (uint32_t i = 0; i < desc->n_constrained; ++i)
+          is_constrained[desc->constrained[i]] = 1;
+        for (uint32_t i = 0; i < e.n_shared; ++i)
+          if (is_constrained[e.shared[i]])
+            return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: a constrained DoF is listed as shared; leave "
+                                                  "Dirichlet DoFs out of the exchange plan");
+        for (int k = 0; k < e.n_neighbors; ++k)
+          for (uint32_t i = 0; i < e.count[k]; ++i)
+            if (is_constrained[e.index[k][i]])
+              return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: a constrained DoF is listed for exchange; "
+                                                    "leave Dirichlet DoFs out of the exchange plan");
+      }
       P->n_shared    = e.n_shared;
       P->n_not_owned = e.n_not_owned;
       MGX_HIP(hipMalloc((void **)&P->shared_dev, sizeof(uint32_t) * (e.n_shared + 1)));
@@ -1098,7 +1163,7 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       if (e.n_not_owned)
         MGX_HIP(hipMemcpy(P->not_owned_dev, e.not_owned, sizeof(uint32_t) * e.n_not_owned, hipMemcpyHostToDevice));
       // fused pack / ordered unpack tables
-      if (e.n_neighbors <= 32 && e.n_neighbors < 255 && !std::getenv("MGX_EXCHANGE_UNFUSED"))
+      if (e.n_neighbors <= 32 && e.n_neighbors < 255 && !tun.exchange_unfused)
         {
           P->start.assign(e.n_neighbors + 1, 0);
           for (int k = 0; k < e.n_neighbors; ++k)
@@ -1346,10 +1411,10 @@ int mgx_vmult_with_cg_update(mgx_operator_t op, double alpha, double beta, const
     }
   else
     {
-      MGX_TRY(dot(ctx, num, q, p, n, &sums[0]));
-      MGX_TRY(dot(ctx, num, r, r, n, &sums[1]));
-      MGX_TRY(dot(ctx, num, q, r, n, &sums[2]));
-      MGX_TRY(dot(ctx, num, q, q, n, &sums[3]));
+      MGX_TRY(dot(ctx, num, q, p, n, &sums[0], op->plan.get()));
+      MGX_TRY(dot(ctx, num, r, r, n, &sums[1], op->plan.get()));
+      MGX_TRY(dot(ctx, num, q, r, n, &sums[2], op->plan.get()));
+      MGX_TRY(dot(ctx, num, q, q, n, &sums[3], op->plan.get()));
     }
   MGX_HIP(hipGetLastError());
   return MGX_OK;
@@ -1391,7 +1456,7 @@ int mgx_compute_diagonal(mgx_operator_t op)
       MGX_HIP(hipFree(op->d.diag_items));
       op->d.diag_items = nullptr;
     }
-  if (op->d.bricks.item_map && op->d.separable && !std::getenv("MGX_NO_DIAG_TABLE"))
+  if (op->d.bricks.item_map && op->d.separable && !op->ctx->tun.no_diag_table)
     {
       const uint32_t nb = op->d.p <= 4 ? 4 : 2, g = nb * op->d.p + 1, npts = g * g * g;
       void          *table = nullptr;
@@ -1456,7 +1521,7 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
   MGX_HIP(hipMemsetAsync(x, 0, bytes, s));
   std::vector<double> diag, off;
   double              res = 0, rz = 0, rz_old = 0, alpha = 0, alpha_old = 0, beta = 0;
-  MGX_TRY(dot(ctx, num, r, r, n, &res));
+  MGX_TRY(dot(ctx, num, r, r, n, &res, op->plan.get()));
   res    = std::sqrt(res);
   int it = 0;
   MGX_TRACE("smoother_create: n=%zu eig_its=%d res0=%g", n, eig_cg_n_iterations, res);
@@ -1466,7 +1531,7 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
       rz_old = rz;
       launch_jacobi_dot(s, num, z, op->d.inv_diag, r, n, ctx->partial_dev, ctx->result_dev);
       if (ctx->has_comm)
-        MGX_TRY(dot(ctx, num, r, z, n, &rz));
+        MGX_TRY(dot(ctx, num, r, z, n, &rz, op->plan.get()));
       else
         MGX_TRY(read_result(ctx, &rz));
       if (it > 1)
@@ -1479,11 +1544,11 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
       alpha_old = alpha;
       MGX_TRY(mgx_vmult(op, h, d));
       double dh = 0;
-      MGX_TRY(dot(ctx, num, d, h, n, &dh));
+      MGX_TRY(dot(ctx, num, d, h, n, &dh, op->plan.get()));
       alpha = rz / dh;
       launch_cg_update(s, num, x, r, d, h, alpha, n, ctx->partial_dev, ctx->result_dev);
       if (ctx->has_comm)
-        MGX_TRY(dot(ctx, num, r, r, n, &res)); // duplicated interface DoFs must count once
+        MGX_TRY(dot(ctx, num, r, r, n, &res, op->plan.get())); // duplicated interface DoFs must count once
       else
         MGX_TRY(read_result(ctx, &res));
       res = std::sqrt(res);
@@ -1621,7 +1686,7 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
   const bool three_term = I.degree >= 2 && std::fabs(I.delta) >= 1e-40;
   const int  n_loop     = three_term ? I.degree - 1 : 0; // iterations of the three-term recurrence
   void      *X = x, *Y = sm->x_old;
-  if (!is_step && n_loop >= 1 && op->d.separable && !std::getenv("MGX_NO_FUSED_INIT"))
+  if (!is_step && n_loop >= 1 && op->d.separable && !op->ctx->tun.no_fused_init)
     {
       // Zero initial guess: x_1 = (1/theta) D^-1 b is not stored.  The first loop iteration
       // evaluates it while gathering (mode 5), the second one again as its x_old (mode 6); from the
@@ -1727,6 +1792,7 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   tr->coarse = coarse;
   tr->fine   = fine;
   tr->d.coarse = &coarse->d;
+  tr->d.colour_min = coarse->ctx->tun.restrict_colour_min;
   tr->d.fine   = &fine->d;
   MGX_HIP(hipMalloc((void **)&tr->d.children, sizeof(uint32_t) * 8 * (size_t)npar));
   MGX_HIP(hipMemcpy(tr->d.children, desc->children, sizeof(uint32_t) * 8 * (size_t)npar, hipMemcpyHostToDevice));
@@ -1793,7 +1859,7 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
     // patch table of the pipelined kernels (mgx_transfer.hip): the 5^3 mesh entities of the
     // children patch of every parent.  Patch entity layer 0..4 along a direction = (child 0:
     // codes 0,1,2 ; child 1: codes 0,1,2) with child 0's code 2 and child 1's code 0 coinciding.
-    if (fine->d.n_dofs < (1u << 29) && !std::getenv("MGX_TRANSFER_V1"))
+    if (fine->d.n_dofs < (1u << 29) && !coarse->ctx->tun.transfer_v1)
       {
         std::vector<uint32_t> patch(125 * (size_t)npar);
         bool                  consistent = true;
@@ -1843,7 +1909,7 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
             tr->d.n_cus = (uint32_t)std::max(1, cus);
             // colouring of the coarse cells by index mod 8 (the parity colouring of a Morton-ordered
             // mesh): valid if no two cells of one colour share a mesh entity
-            if (npar % 8 == 0 && !std::getenv("MGX_RESTRICT_ATOMIC"))
+            if (npar % 8 == 0 && !coarse->ctx->tun.restrict_atomic)
               {
                 std::vector<uint32_t> idxc(27 * (size_t)npar);
                 MGX_HIP(hipMemcpy(idxc.data(), coarse->d.idx27_plain, sizeof(uint32_t) * idxc.size(), hipMemcpyDeviceToHost));
@@ -1889,7 +1955,7 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   // schedule in its separable form, children in forest order (cell c is child c % 8 of parent
   // c / 8, so that a brick's cells are the children of PB^3 sibling parents) and a single rank.
   if (fine->d.bricks.available() && fine->d.separable && !fine->plan && !coarse->plan &&
-      !std::getenv("MGX_NO_FUSED_RESTRICT"))
+      !coarse->ctx->tun.no_fused_restrict)
     {
       bool forest = true;
       for (size_t i = 0; i < 8 * (size_t)npar && forest; ++i)
@@ -2133,10 +2199,9 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
                                     &sm)); // :282-284
       S->smooth.push_back(sm);
     }
-  if (!std::getenv("MGX_NO_GRAPH"))
+  if (!ctx->tun.no_graph)
     {
-      const char    *e = std::getenv("MGX_GRAPH_MAX_DOFS");
-      const uint32_t graph_max = e ? (uint32_t)std::atol(e) : 600000u;
+      const uint32_t graph_max = ctx->tun.graph_max_dofs;
       for (int l = 0; l < nl; ++l)
         if (S->matrix[l]->d.n_dofs <= graph_max)
           S->graph_level = l;
@@ -2385,17 +2450,17 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
       ++it;
       MGX_TRY(mgx_solver_vmult(S, z, r));
       rz_old = rz;
-      MGX_TRY(dot(ctx, MGX_F64, r, z, n, &rz));
+      MGX_TRY(dot(ctx, MGX_F64, r, z, n, &rz, A->plan.get()));
       if (it > 1)
         launch_xpby(s, MGX_F64, d, z, rz / rz_old, n);
       else
         launch_copy_cast(s, d, MGX_F64, z, MGX_F64, n);
       MGX_TRY(mgx_vmult(A, h, d));
       double dh = 0;
-      MGX_TRY(dot(ctx, MGX_F64, d, h, n, &dh));
+      MGX_TRY(dot(ctx, MGX_F64, d, h, n, &dh, A->plan.get()));
       launch_cg_update(s, MGX_F64, x, r, d, h, rz / dh, n, ctx->partial_dev, ctx->result_dev);
       if (ctx->has_comm)
-        MGX_TRY(dot(ctx, MGX_F64, r, r, n, &res));
+        MGX_TRY(dot(ctx, MGX_F64, r, r, n, &res, A->plan.get()));
       else
         MGX_TRY(read_result(ctx, &res));
       res = std::sqrt(res);

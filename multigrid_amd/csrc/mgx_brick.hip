@@ -816,12 +816,6 @@ namespace mgx
       }
   }
 
-  // ------------------------------------------------------------------------------------------
-  static uint32_t wide_max_bricks()
-  {
-    const char *e = std::getenv("MGX_BRICK_WIDE_MAX");
-    return e ? (uint32_t)std::atol(e) : 1024u;
-  }
 
   template <int P, typename T, int MODE>
   static void brick_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post, int g0, int g1)
@@ -837,7 +831,7 @@ namespace mgx
           {
             // few bricks per launch (< 4 per CU): the launch lasts one workgroup's latency, which the
             // 512-thread form roughly halves; with the chip full the 256-thread form is faster
-            if (P <= 4 && count < wide_max_bricks())
+            if (P <= 4 && count < op.wide_max)
               hipLaunchKernelGGL((brick_sep_kernel<P, T, MODE, true>), dim3(count), dim3(BCfg<P, true>::THREADS), 0,
                                  s, src, first, bd.ent_base, bd.ent_flags, (const Basis1D<T> *)op.basis,
                                  (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], post);
@@ -909,10 +903,9 @@ namespace mgx
       old = out;
     if (!src)
       src = (const void *)a; // kChebInit: never dereferenced, but keep the pointer valid
-    // separable operator: macro-element form (mgx_macro.hip); MGX_BRICK_FORM=cells keeps the
+    // separable operator: macro-element form (mgx_macro.hip); Tunables::cells_form keeps the
     // cell-by-cell form below (A/B measurements, and the reference point of the consistency tests)
-    static const bool cells_form = std::getenv("MGX_BRICK_FORM") && std::string(std::getenv("MGX_BRICK_FORM")) == "cells";
-    if (op.separable && op.bricks.item_map && !cells_form)
+    if (op.separable && op.bricks.item_map && !op.cells_form)
       {
         const bool done = op.number == 1
                             ? launch_macro_loop_f64(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1)

@@ -13,6 +13,34 @@ namespace mgx
   constexpr int      kMaxN    = 10; // p <= 9
   constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
+  // Every switch the library takes from the environment, read ONCE when a context is created
+  // (mgx_context_create) and carried by the objects built on that context -- no getenv on any hot
+  // path, and two contexts of one process can differ (the tests compare code paths that way).
+  // All of them select between numerically equivalent code paths or set thresholds; none changes
+  // what is computed.  Defaults in brackets.
+  struct Tunables
+  {
+    bool     trace            = false; // MGX_TRACE            host control flow on stderr
+    bool     general_kernel   = false; // MGX_GENERAL_KERNEL   quadrature-point form instead of the separable one
+    bool     no_bricks        = false; // MGX_NO_BRICKS        per-cell kernel on every level
+    uint32_t brick_min        = 2048;  // MGX_BRICK_MIN        bricks per level from which the brick loop is used
+    uint32_t overlap_min      = 16384; // MGX_OVERLAP_MIN_BRICKS  bricks per rank from which interface bricks run first
+    bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
+    uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads
+    uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
+    bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
+    bool     no_fused_init    = false; // MGX_NO_FUSED_INIT    store the first Chebyshev iterate
+    bool     no_fused_restrict = false; // MGX_NO_FUSED_RESTRICT  separate residual and restriction kernels
+    bool     transfer_v1      = false; // MGX_TRANSFER_V1      first-version transfer kernels
+    bool     restrict_atomic  = false; // MGX_RESTRICT_ATOMIC  one-launch restriction with atomics on every level
+    uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour
+    bool     exchange_unfused = false; // MGX_EXCHANGE_UNFUSED one pack / unpack launch per neighbour
+    bool     no_graph         = false; // MGX_NO_GRAPH         no HIP-graph replay of the coarse levels
+    uint32_t graph_max_dofs   = 600000; // MGX_GRAPH_MAX_DOFS  largest level inside the replayed graph
+    bool     rccl_selftest    = false; // MGX_RCCL_SELFTEST    one-rank communicator may name itself as neighbour
+    static Tunables from_environment();
+  };
+
   // 1D data of the element in the operator's number type, resident in device memory and read
   // through wave-uniform (scalar) loads.
   // Even-odd (Appendix B of SURVEY.md, matrix_vector_kernel.h:47-113) form of a symmetric and
@@ -72,6 +100,9 @@ namespace mgx
     void     *inv_diag      = nullptr; // device, number type
     double    coef[6]       = {0, 0, 0, 0, 0, 0};
     BrickData bricks;
+    bool      cells_form    = false; // Tunables::cells_form of the context the operator was created on
+    uint32_t  wide_max      = 1024;  // Tunables::wide_max
+    uint32_t  macro_wg_x16  = 0;     // Tunables::macro_wg_x16
     bool      separable     = true; // Cartesian constant-coefficient fast path of the brick loop
     // inverse diagonal per brick item ((NB p + 1)^3 values in item order) if it is the same for
     // every brick (uniform mesh), else nullptr: the macro-element kernel then reads it from
@@ -97,6 +128,7 @@ namespace mgx
     mutable uint32_t    pipe_grid[4] = {0, 0, 0, 0}; // persistent grid of prolongate(add), prolongate, restrict x2
     bool                coarse_coloured = false; // coarse cells c and c' with c % 8 == c' % 8 share no DoF
     uint32_t            n_cus = 256;
+    uint32_t            colour_min = 16384; // Tunables::restrict_colour_min
   };
 
   void launch_prolongate_pipe(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,

@@ -880,17 +880,17 @@ namespace mgx
   }
 
   // ------------------------------------------------------------------------------------------
-  static uint32_t macro_cus()
+  // workgroups of a persistent launch per resident slot: the CUs of the device (x WGS per CU);
+  // Tunables::macro_wg_x16 scales it (tuning aid)
+  static uint32_t macro_cus(const OperatorData &op)
   {
-    static const uint32_t n = [] {
-      int dev = 0, cus = 256;
+    static const int cus = [] {
+      int dev = 0, n = 256;
       if (hipGetDevice(&dev) == hipSuccess)
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (const char *e = std::getenv("MGX_MACRO_WG_PER_CU_X16")) // tuning aid: grid = value/16 workgroups per CU
-        return (uint32_t)std::max(1, cus * std::atoi(e) / 16);
-      return (uint32_t)std::max(1, cus);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return std::max(1, n);
     }();
-    return n;
+    return op.macro_wg_x16 ? std::max<uint32_t>(1u, (uint32_t)cus * op.macro_wg_x16 / 16u) : (uint32_t)cus;
   }
 
   template <int P, typename T, int MODE>
@@ -905,7 +905,7 @@ namespace mgx
           continue;
         // persistent workgroups: as many as are resident at once (WGS per CU), each walks over
         // count / grid bricks
-        const uint32_t grid = std::min<uint32_t>(count, (uint32_t)C::WGS * macro_cus());
+        const uint32_t grid = std::min<uint32_t>(count, (uint32_t)(op.macro_wg_x16 ? 1 : C::WGS) * macro_cus(op));
         constexpr bool kUsesDiag = MODE >= kCheb && MODE <= kChebOldInit;
         if (kUsesDiag && op.diag_items)
           {
@@ -1042,7 +1042,7 @@ namespace mgx
           const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
           if (count == 0)
             continue;
-          const uint32_t grid = std::min<uint32_t>(count, (uint32_t)C::WGS * macro_cus());
+          const uint32_t grid = std::min<uint32_t>(count, (uint32_t)(op.macro_wg_x16 ? 1 : C::WGS) * macro_cus(op));
           if (used + grid > capacity)
             return false;
           post.sums = partials + 4 * (size_t)used;

@@ -482,13 +482,6 @@ namespace mgx
       }
   }
 
-  // smallest coarse level restricted colour by colour (8 launches); below it one launch with
-  // atomics is cheaper.  MGX_RESTRICT_COLOUR_MIN overrides (the tests set 8).
-  static uint32_t coloured_min_cells()
-  {
-    const char *e = std::getenv("MGX_RESTRICT_COLOUR_MIN");
-    return e ? (uint32_t)std::atol(e) : 16384u;
-  }
 
   // ------------------------------------------------------------------------------------------
   template <int P, typename T>
@@ -522,7 +515,7 @@ namespace mgx
                              0, s, (T *)fine, (const T *)coarse_in, t.patch, idx_c, c.n_cells,
                              (const Basis1D<T> *)c.basis);
       }
-    else if (t.coarse_coloured && c.n_cells >= coloured_min_cells())
+    else if (t.coarse_coloured && c.n_cells >= t.colour_min)
       {
         // 8 launches, one per colour (parent index mod 8): atomic-free and deterministic
         const uint32_t g = std::min<uint32_t>(c.n_cells / 8u, grid_of(3, (const void *)restrict_pipe_kernel<P, T, true>));

@@ -107,17 +107,19 @@ def test_c2_full_solve_reaches_the_readme_accuracy(big):
 
 
 FALLBACKS = {"MGX_NO_FUSED_RESTRICT": "1", "MGX_NO_FUSED_INIT": "1", "MGX_TRANSFER_V1": "1",
-             "MGX_RESTRICT_ATOMIC": "1", "MGX_BRICK_WIDE_MAX": "0", "MGX_NO_GRAPH": "1"}
+             "MGX_RESTRICT_ATOMIC": "1", "MGX_BRICK_WIDE_MAX": "0", "MGX_NO_GRAPH": "1", "MGX_BRICK_FORM": "cells",
+             "MGX_NO_DIAG_TABLE": "1"}
 
 
 @pytest.mark.parametrize("p,ns,nr", [(4, 3, 5), (2, 1, 7), (3, 1, 6), (5, 1, 5), (8, 1, 5), (1, 1, 7)])
 def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     """Meshes the oracle cannot run in seconds (4 - 17 M DoFs; production thresholds, i.e. without
-    the test overrides of conftest.py): the default V-cycle -- fused residual + restriction, first
-    Chebyshev iterate formed on the fly, pipelined colour-by-colour transfers, 512-thread bricks on
-    small launches, graph replay -- against the same solver built with every one of those switched
-    off (first-version transfer kernels, separate residual and restriction, stored first iterate).
-    The two differ in summation order only."""
+    the test overrides of conftest.py): the default V-cycle -- macro-element brick loop with the
+    inverse diagonal in registers, fused residual + restriction, first Chebyshev iterate formed on
+    the fly, pipelined colour-by-colour transfers, graph replay -- against the same solver on a
+    context created with every one of those switched off (cell-by-cell brick kernel, streamed
+    diagonal, first-version transfer kernels, separate residual and restriction, stored first
+    iterate).  The two differ in summation order only."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
     ctx = mg.Context(0)
@@ -131,9 +133,11 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     solver.vmult(a, x)  # second call: coarse levels replayed from the graph
     for k, v in FALLBACKS.items():
         monkeypatch.setenv(k, v)
-    plain = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    ctx2 = mg.Context(0)  # the switches are read when a context is created
+    plain = mg.MultigridSolver(ctx2, cube, 3, 3, 1, mg.F64)
     b = ctx.vector(n)
     plain.vmult(b, x)
+    ctx2.sync()
     nb = ctx.l2_norm(b)
     mg.check(ctx.lib.mgx_sadd(ctx.h, mg.F64, b.ptr, 1.0, -1.0, a.ptr, n))
     assert ctx.l2_norm(b) < 1e-11 * nb
@@ -145,6 +149,7 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     for v in (x, a, b):
         v.free()
     plain.close()
+    ctx2.close()
     solver.close()
     cube.close()
     ctx.close()

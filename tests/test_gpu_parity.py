@@ -53,10 +53,14 @@ def test_vmult_and_residual(ctx, p, ns, nr):
 
 
 @pytest.mark.parametrize("p,ns,nr", [(4, 1, 3), (2, 1, 3), (3, 3, 2)])
-def test_narrow_brick_kernel(ctx, monkeypatch, p, ns, nr):
-    """Launches with few bricks use the 512-thread form of the brick kernel (all small cases above);
-    MGX_BRICK_WIDE_MAX=0 forces the 256-thread form the full-size levels run."""
-    monkeypatch.setenv("MGX_BRICK_WIDE_MAX", "0")
+@pytest.mark.parametrize("wide_max", ["0", "100000"])
+def test_cell_by_cell_brick_kernel(monkeypatch, p, ns, nr, wide_max):
+    """The cell-by-cell form of the brick loop (MGX_BRICK_FORM=cells; production: the macro-element
+    form, which every other test runs), in its 256-thread (MGX_BRICK_WIDE_MAX=0) and its
+    512-thread form.  The switches are read when the context is created."""
+    monkeypatch.setenv("MGX_BRICK_FORM", "cells")
+    monkeypatch.setenv("MGX_BRICK_WIDE_MAX", wide_max)
+    ctx = mg.Context(0)
     cube = mg.Cube(p, ns, nr)
     orc = oracle_for(cube, p, ns, nr, degree=3)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
@@ -79,6 +83,7 @@ def test_narrow_brick_kernel(ctx, monkeypatch, p, ns, nr):
     solver.close()
     cube.close()
     orc.close()
+    ctx.close()
 
 
 @pytest.mark.parametrize("p,nr", [(4, 2), (4, 3), (2, 4)])
@@ -223,11 +228,12 @@ def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
     orc.close()
 
 
-def test_default_brick_threshold(ctx, monkeypatch):
+def test_default_brick_threshold(monkeypatch):
     """With the production threshold (bricks from 2048 per level on) small levels use the per-cell
     kernel and the finest level of a 64^3 mesh (4096 bricks) the brick loop; same results."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
+    ctx = mg.Context(0)  # thresholds are read when the context is created
     p, nr = 2, 6
     cube = mg.Cube(p, 1, nr)
     orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1)
@@ -241,15 +247,17 @@ def test_default_brick_threshold(ctx, monkeypatch):
     solver.close()
     cube.close()
     orc.close()
+    ctx.close()
 
 
-def test_production_thresholds_p4_against_oracle(ctx, monkeypatch):
+def test_production_thresholds_p4_against_oracle(monkeypatch):
     """FE_Q(4) on 64^3 cells (16 974 593 DoFs, 4096 bricks on the finest level): the production
     configuration -- default brick / colour thresholds, macro-element brick loop on the fine levels,
     per-cell kernel and graph replay on the coarse ones -- against the oracle, not against another
     path of the same library."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
+    ctx = mg.Context(0)  # thresholds are read when the context is created
     p, nr = 4, 6
     cube = mg.Cube(p, 1, nr)
     orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1)
@@ -276,6 +284,7 @@ def test_production_thresholds_p4_against_oracle(ctx, monkeypatch):
     solver.close()
     cube.close()
     orc.close()
+    ctx.close()
 
 
 def test_level_errors_of_the_analysed_solve(ctx):
