@@ -32,7 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (datasheet); tools/microbench.hip sustains 60.5
-FLOP_PER_DOF_P4 = 105.0   # executed by the separable brick kernel at p = 4 (dense 12-sweep form: 270)
+# executed by the macro-element brick kernel at p = 4: 289 lines x 628 fp64 instructions (ISA count of
+# the three sweeps: 158 + 279 + 191, ~80 % of them FMA = 2 flop) per 4096-DoF brick (dense 12-sweep form: 270)
+FLOP_PER_DOF_P4 = 80.0
+TRAFFIC_FILE = "r02_pmc_traffic_128cube_p4.json"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
 
 
@@ -314,19 +317,25 @@ def main():
         # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (they
         # cannot run inside this timed process) and committed under profiles/; it is reported here
         # for the configuration it was measured on
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01g_pmc_traffic_128cube_p4.json")
-        if args.degree == 4 and args.cells == 128 and vnum == mg.F64 and os.path.exists(pmc_file):
-            k = json.load(open(pmc_file))["kernels"].get(NAMES[form])
-            if k:
+        traffic, traffic_note = None, None
+        pmc_file = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if args.degree == 4 and args.cells == 128 and vnum == mg.F64 and world == 1 and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from make_traffic_json import kernel_source_sha
+            k = pmc["kernels"].get(NAMES[form])
+            if pmc.get("kernel_source_sha16") != kernel_source_sha():
+                traffic_note = "profiles/%s was measured on other kernel sources: not attached" % TRAFFIC_FILE
+            elif k:
                 traffic = k["traffic_bytes_per_launch"]
         per_launch_bytes = ALG[form] * n_dofs / n_col
         ach = per_launch_bytes / (avg * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "mgx::brick_sep_kernel<%d,double,%s> (finest level, per colour launch)"
+        return {"bound": "hbm", "kernel": "mgx::brick_macro_kernel<%d,double,%s> (finest level, per colour launch)"
                 % (args.degree, NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01g_pmc_traffic_128cube_p4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                  "separate passes, FETCH_SIZE x2 per the gfx950 correction)" if traffic else None,
+                "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 "
+                                   "per the gfx950 correction; same kernel sources as this build)" % TRAFFIC_FILE)
+                if traffic else traffic_note,
                 "launches": launches, "avg_launch_ms": avg,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_bytes_per_dof": ALG[form],
                 # co-limiter asked for by SURVEY.md 8d: fp64 vector throughput of the cell loop.  Executed

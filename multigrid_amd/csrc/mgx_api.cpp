@@ -100,6 +100,7 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.no_diag_table       = flag("MGX_NO_DIAG_TABLE");
   t.no_fused_init       = flag("MGX_NO_FUSED_INIT");
   t.no_fused_restrict   = flag("MGX_NO_FUSED_RESTRICT");
+  t.no_fused_prolong    = flag("MGX_NO_FUSED_PROLONG");
   t.transfer_v1         = flag("MGX_TRANSFER_V1");
   t.restrict_atomic     = flag("MGX_RESTRICT_ATOMIC");
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
@@ -317,7 +318,8 @@ namespace
         for (auto &pr : ctx->plans)
           if (pr.first == n)
             {
-              if (plan && (plan->n_not_owned != pr.second->n_not_owned || plan->plan_id != pr.second->plan_id))
+              // (operators of one level in two number types share the lists: same sizes)
+              if (plan && (plan->n_not_owned != pr.second->n_not_owned || plan->n_shared != pr.second->n_shared))
                 return fail(MGX_ERR_INVALID_ARGUMENT, "dot: two operators of this context have vectors of this length but "
                                                       "different ownership; reductions need the operator");
               plan = pr.second;
@@ -1638,7 +1640,8 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 //   out <- cur + f1 (cur - out) + f2 D^-1 (b - A cur);  mode 2 general, 3 without the f1 term,
 //   4 with out == 0 on entry.  sm->tmp carries the partial sums of brick-surface DoFs.
 static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, const void *old, void *out,
-                                const void *b, double f1, double f2, double f0 = 0.)
+                                const void *b, double f1, double f2, double f0 = 0., const void *coarse = nullptr,
+                                const uint32_t *coarse_blocks = nullptr)
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
@@ -1646,7 +1649,8 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
   MGX_TRY(brick_loop_with_exchange(
     op, mode, sm->tmp,
     [&](hipStream_t st, int g0, int g1) {
-      launch_brick_loop(st, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old, f0, nullptr, nullptr, g0, g1);
+      launch_brick_loop(st, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old, f0, const_cast<void *>(coarse),
+                        coarse_blocks, g0, g1);
     },
     [&](hipStream_t st) {
       launch_cheb_constrained(st, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
@@ -1665,7 +1669,10 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
 // LAST iterate lands in X: no pointer swap (deal.II swaps solution/solution_old) and no copy, and
 // all pointers stay fixed from call to call (which lets the coarse part of the V-cycle be
 // replayed as a HIP graph).
-static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_step)
+// prolong_coarse / prolong_blocks (step only): the coarse-grid correction P x_coarse is added to x on
+// the fly by the first iteration (mode 9) instead of by a prolongation kernel before the call
+static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_step, const void *prolong_coarse = nullptr,
+                          const uint32_t *prolong_blocks = nullptr)
 {
   const mgx_smoother_info &I  = sm->info;
   mgx_operator_t           op = sm->op;
@@ -1740,7 +1747,8 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
       else
         out = k == 1 ? Y : (k == 2 ? Z : (k == 3 ? X : ((cur == X) ? Y : X)));
       if (k == 1)
-        MGX_TRY(cheb_fused_iteration(sm, 3, cur, nullptr, out, b, 0., 1. / I.theta));
+        MGX_TRY(cheb_fused_iteration(sm, prolong_blocks ? 9 : 3, cur, nullptr, out, b, 0., 1. / I.theta, 0., prolong_coarse,
+                                     prolong_blocks));
       else
         {
           const double rhokp = 1. / (2. * sigma - rhok);
@@ -2310,15 +2318,30 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
           }
         }
       MGX_TRY(v_cycle(S, level - 1, 1)); // :671
-      {
-        Stopwatch sw(S, level, 2);
-        MGX_TRY(mgx_prolongate(S->transfer[level], S->solution_update[level], S->solution_update[level - 1], 1,
-                               1)); // :674
-      }
-      {
-        Stopwatch sw(S, level, 5);
-        MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true)); // :678
-      }
+      // :674 + :678.  On one rank with the macro-element brick loop the prolongation is not a kernel of
+      // its own: the first post-smoothing iteration forms x + P x_coarse while it gathers x
+      mgx_operator_t Af = S->matrix[level];
+      const bool     fused_prolong = S->transfer[level]->d.coarse_blocks && Af->d.bricks.item_map && !Af->d.cells_form &&
+                                 Af->d.separable && !S->ctx->tun.no_fused_prolong && S->smooth[level]->info.degree >= 1 &&
+                                 (uint64_t)Af->d.n_dofs * number_size(Af->d.number) < 0xFFFFFFF0ull;
+      if (fused_prolong)
+        {
+          Stopwatch sw(S, level, 5);
+          MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true,
+                                 S->solution_update[level - 1], S->transfer[level]->d.coarse_blocks));
+        }
+      else
+        {
+          {
+            Stopwatch sw(S, level, 2);
+            MGX_TRY(mgx_prolongate(S->transfer[level], S->solution_update[level], S->solution_update[level - 1], 1,
+                                   1)); // :674
+          }
+          {
+            Stopwatch sw(S, level, 5);
+            MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true)); // :678
+          }
+        }
     }
   return MGX_OK;
 }

@@ -59,7 +59,13 @@ namespace mgx
     // fused PCG step (vmult_with_cg_update, laplace_operator.h:638-719; macro-element kernel only):
     // the gather forms p_new = f2 p + q (f1 == 0: p_new = q); at completion x += f1 p_old,
     // p = p_new, q = A p_new, and q.p, r.r, q.r, q.q are accumulated per workgroup
-    kCgUpdate = 8
+    kCgUpdate = 8,
+    // first post-smoothing iteration of the V-cycle with the coarse-grid correction formed on the
+    // fly (multigrid_solver.h:674-678; macro-element kernel only): the gather adds the prolongated
+    // coarse values to x (prolong_brick), the iteration is kChebFirst on the corrected x, which is
+    // also written back at completion (it is x_old of the next iteration).  coarse / coarse_blocks
+    // as for kResidualRestrict.
+    kChebFirstProlong = 9
   };
 
   template <typename T>
@@ -240,18 +246,135 @@ namespace mgx
         int ex, ey, ox, oy, nx, ny;
         layer(x, ex, ox, nx);
         layer(y, ey, oy, ny);
+        // read-modify-write of the CN coarse values of this line: all loads first, then all stores
+        // (a load behind a store to the same vector would wait for it: CN dependent round trips)
+        T  *cp[CN];
+        T   cv[CN];
+        bool ok[CN];
 #pragma unroll
         for (int j = 0; j < CN; ++j)
           {
             int ez, oz, nz;
             layer(j, ez, oz, nz);
             const uint32_t w = ctab[(ez * CE1 + ey) * CE1 + ex];
-            if (w != kInvalid)
-              {
-                T *c = coarse + w + (uint32_t)((oz * ny + oy) * nx + ox);
-                *c += o[j];
-              }
+            ok[j]            = w != kInvalid;
+            cp[j]            = coarse + (ok[j] ? w + (uint32_t)((oz * ny + oy) * nx + ox) : 0u);
+            cv[j]            = *cp[j];
+          }
+#pragma unroll
+        for (int j = 0; j < CN; ++j)
+          if (ok[j])
+            *cp[j] = cv[j] + o[j];
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Prolongation of the coarse values of a brick's parents onto the brick array (kChebFirstProlong):
+  // cv = the (PB p + 1)^3 coarse values in registers (thread tid holds coarse points tid + k NT),
+  // acc receives P cv on the G^3 points of the brick.  Exact embedding: every fine point takes the
+  // value of the coarse finite-element function (MGTransferMatrixFree::prolongate).
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T>
+  __device__ __forceinline__ void prolong_line(const T *__restrict__ p1, const T (&c)[(BCfg<P>::NB / 2) * P + 1],
+                                               T (&f)[BCfg<P>::G])
+  {
+    constexpr int N = P + 1, M = 2 * P + 1, PB = BCfg<P>::NB / 2;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+      {
+#pragma unroll
+        for (int a = (pb == 0 ? 0 : 1); a < M; ++a)
+          {
+            T s = p1[a * N] * c[pb * P];
+#pragma unroll
+            for (int i = 1; i < N; ++i)
+              s = fma(p1[a * N + i], c[pb * P + i], s);
+            f[pb * 2 * P + a] = s;
           }
       }
+  }
+
+  template <int P>
+  __device__ __forceinline__ void coarse_point(int l, int &slot, uint32_t &off, int &pnt)
+  {
+    using C           = BCfg<P>;
+    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1;
+    const int     x = l % CN, y = (l / CN) % CN, z = l / (CN * CN);
+    auto          layer = [](int a, int &e, int &o, int &n) {
+      const int q = a / P, rr = a - q * P;
+      e           = 2 * q + (rr != 0);
+      o           = rr ? rr - 1 : 0;
+      n           = rr ? P - 1 : 1;
+    };
+    int ex, ey, ez, ox, oy, oz, nx, ny, nz;
+    layer(x, ex, ox, nx);
+    layer(y, ey, oy, ny);
+    layer(z, ez, oz, nz);
+    slot = (ez * CE1 + ey) * CE1 + ex;
+    off  = (uint32_t)((oz * ny + oy) * nx + ox);
+    pnt  = (z * G + y) * G + x;
+  }
+
+  template <int P, typename T, int NT>
+  __device__ __forceinline__ void prolong_brick(int tid, T *acc, const T *__restrict__ p1,
+                                                const T (&cv)[((BCfg<P>::NB / 2) * P + 1) * ((BCfg<P>::NB / 2) * P + 1) *
+                                                                ((BCfg<P>::NB / 2) * P + 1) / NT + 1])
+  {
+    using C           = BCfg<P>;
+    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, NC = CN * CN * CN, NCV = NC / NT + 1;
+#pragma unroll
+    for (int k = 0; k < NCV; ++k)
+      {
+        const int l = tid + k * NT;
+        if (l < NC)
+          {
+            int      slot, pnt;
+            uint32_t off;
+            coarse_point<P>(l, slot, off, pnt);
+            acc[pnt] = cv[k];
+          }
+      }
+    __syncthreads();
+    // z: lines (x, y) with x, y < CN
+    for (int l = tid; l < CN * CN; l += NT)
+      {
+        const int x = l % CN, y = l / CN;
+        T         c[CN], f[G];
+#pragma unroll
+        for (int i = 0; i < CN; ++i)
+          c[i] = acc[(i * G + y) * G + x];
+        prolong_line<P, T>(p1, c, f);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          acc[(i * G + y) * G + x] = f[i];
+      }
+    __syncthreads();
+    // y: lines (x < CN, z)
+    for (int l = tid; l < CN * G; l += NT)
+      {
+        const int x = l % CN, z = l / CN;
+        T         c[CN], f[G];
+#pragma unroll
+        for (int i = 0; i < CN; ++i)
+          c[i] = acc[(z * G + i) * G + x];
+        prolong_line<P, T>(p1, c, f);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          acc[(z * G + i) * G + x] = f[i];
+      }
+    __syncthreads();
+    // x: lines (y, z)
+    for (int l = tid; l < G * G; l += NT)
+      {
+        T c[CN], f[G];
+#pragma unroll
+        for (int i = 0; i < CN; ++i)
+          c[i] = acc[l * G + i];
+        prolong_line<P, T>(p1, c, f);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          acc[l * G + i] = f[i];
+      }
+    __syncthreads();
   }
 } // namespace mgx

@@ -217,6 +217,12 @@ namespace mgx
   __device__ __forceinline__ uint32_t item_point(uint32_t m) { return (m >> 10) & 8191u; }
   __device__ __forceinline__ uint32_t item_offset(uint32_t m) { return m >> 23; }
 
+  // the fused Chebyshev forms (they use the inverse diagonal and keep the source value)
+  __host__ __device__ constexpr bool is_cheb_mode(int mode)
+  {
+    return (mode >= kCheb && mode <= kChebOldInit) || mode == kChebFirstProlong;
+  }
+
   // Vector access through buffer descriptors: address = (scalar base) + (32-bit byte offset in one
   // VGPR), no 64-bit address arithmetic and no VGPR pair per access in flight; offsets at or beyond
   // the vector's size are out of range: such a load returns zero and such a store is dropped
@@ -314,7 +320,7 @@ namespace mgx
       ld(R.partial, op, o.pv);
     if (MODE != kPlain)
       ld(R.a, ol, o.av);
-    if (MODE >= kCheb && MODE <= kChebOldInit && !DTAB)
+    if (is_cheb_mode(MODE) && !DTAB)
       ld(R.b, ol, o.bv);
     if (MODE == kCheb || MODE == kCgUpdate)
       ld(R.old, ol, o.ov);
@@ -372,7 +378,7 @@ namespace mgx
     constexpr int N = P + 1, NB = C::NB;
     constexpr int REM    = LINES - NT;            // lines beyond the thread count (cell-split pass)
     // the fused Chebyshev forms need the source value again at write-out time
-    constexpr bool kKeepX = (MODE >= kCheb && MODE <= kChebOldInit) || MODE == kCgUpdate;
+    constexpr bool kKeepX = is_cheb_mode(MODE) || MODE == kCgUpdate;
     constexpr int  NG     = ((MODE == kChebInit && !DTAB) || MODE == kCgUpdate) ? 2 : 1; // operands gathered per value
     // two arrays of G^3 values and nothing else: 78.6 kB in fp64 at G = 17, two workgroups per CU.
     // The entity table of a brick has no LDS of its own: it is needed before the first sweep (gather)
@@ -430,7 +436,7 @@ namespace mgx
     const rsrc_t      rsrc = make_rsrc(src, vec_bytes);
     const PostRsrc<T> R{make_rsrc(post.a, vec_bytes),   make_rsrc(post.b, vec_bytes),       make_rsrc(post.old, vec_bytes),
                         make_rsrc(post.out, vec_bytes), make_rsrc(post.partial, vec_bytes), rsrc,
-                        make_rsrc(MODE == kCgUpdate ? post.src_w : post.out, vec_bytes),
+                        make_rsrc((MODE == kCgUpdate || MODE == kChebFirstProlong) ? post.src_w : post.out, vec_bytes),
                         make_rsrc(MODE == kCgUpdate ? post.x_w : post.out, vec_bytes)};
     double cg[4] = {0., 0., 0., 0.}; // kCgUpdate: q.p, r.r, q.r, q.q over the DoFs this workgroup completes
     const EOMat<T>   &M = B->mass, &K = B->lapl;
@@ -456,8 +462,31 @@ namespace mgx
     };
     // read_dof_values_compressed through the entity table E: issues the loads of this thread's
     // items (constrained entity: out of range, reads zero -- vector_access_reduced.h:174-179)
+    // kChebFirstProlong: the (PB p + 1)^3 coarse values of the brick's parents, loaded with the gather
+    constexpr bool kProlong = MODE == kChebFirstProlong;
+    constexpr int  CNP = (C::NB / 2) * P + 1, NCV = CNP * CNP * CNP / NT + 1, CE3 = (C::NB + 1) * (C::NB + 1) * (C::NB + 1);
+    T              cvv[NCV];
     T    g[NG][IT];
-    auto gather_issue = [&](const uint32_t *E) {
+    auto gather_issue = [&](const uint32_t *E, uint32_t brick) {
+      if (kProlong)
+        {
+          const uint32_t *ctab = post.coarse_blocks + (size_t)(brick_first + brick) * CE3;
+#pragma unroll
+          for (int k = 0; k < NCV; ++k)
+            {
+              const int l = tid + k * NT;
+              cvv[k]      = T(0);
+              if (l < CNP * CNP * CNP)
+                {
+                  int      slot, pnt;
+                  uint32_t off;
+                  coarse_point<P>(l, slot, off, pnt);
+                  const uint32_t w = ctab[slot];
+                  const T        v = post.coarse[w != kInvalid ? w + off : 0u];
+                  cvv[k]           = w != kInvalid ? v : T(0); // constrained coarse DoF: zero
+                }
+            }
+        }
       const rsrc_t r0 = MODE == kChebInit ? (DTAB ? R.a : R.b) : rsrc;
       const rsrc_t r1 = MODE == kCgUpdate ? R.b : R.a; // second operand
 #pragma unroll
@@ -505,13 +534,31 @@ namespace mgx
         }
     };
 
+    // kChebFirstProlong: x += P x_coarse on the brick array and in the registers (W is free here)
+    auto add_correction = [&]() {
+      if (kProlong)
+        {
+          __syncthreads(); // the entity table parked in W (prologue) has been read by everyone
+          prolong_brick<P, T, NT>(tid, W, B->P1, cvv);
+#pragma unroll
+          for (int it = 0; it < IT; ++it)
+            if (live(it))
+              {
+                const uint32_t pnt = item_point(mw[it]);
+                xs[kKeepX ? it : 0] += W[pnt];
+                U[pnt] = xs[kKeepX ? it : 0];
+              }
+        }
+    };
+
     // ---- prologue: table and source of the first brick ----
     table_load(b, ec);
     table_store(reinterpret_cast<uint32_t *>(W), ec);
     __syncthreads();
     MGX_STAMP(1);
-    gather_issue(reinterpret_cast<const uint32_t *>(W));
+    gather_issue(reinterpret_cast<const uint32_t *>(W), b);
     gather_land();
+    add_correction();
     MGX_STAMP(2);
     __syncthreads();
 
@@ -696,7 +743,7 @@ namespace mgx
         // write-out, its gather is issued afterwards)
         constexpr bool kPipeGather = (MODE != kChebInit || DTAB) && MODE != kCgUpdate;
         if (has_next && kPipeGather)
-          gather_issue(E2);
+          gather_issue(E2, bn);
         MGX_STAMP_IT(7);
 
         // ---- write-out with the fused post-operation, same item -> thread mapping as the gather.
@@ -819,6 +866,8 @@ namespace mgx
                           st(R.out, last ? off : kOob);
                           if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
                             st(R.partial, last ? kOob : off);
+                          if (MODE == kChebFirstProlong) // the corrected x is x_old of the next iteration
+                            buf_st(R.srcw, last ? off : kOob, xs[kKeepX ? v0 : 0]);
                         }
                     }
                 }
@@ -836,12 +885,13 @@ namespace mgx
         if (!has_next)
           break;
         if (!kPipeGather)
-          gather_issue(E2);
+          gather_issue(E2, bn);
         __syncthreads(); // everyone is done with the parked tables and with W
 #pragma unroll
         for (int j = 0; j < NEW; ++j)
           ec[j] = en[j];
         gather_land();
+        add_correction();
         MGX_STAMP_IT(9);
         __syncthreads();
         MGX_STAMP_IT(10);
@@ -906,7 +956,7 @@ namespace mgx
         // persistent workgroups: as many as are resident at once (WGS per CU), each walks over
         // count / grid bricks
         const uint32_t grid = std::min<uint32_t>(count, (uint32_t)(op.macro_wg_x16 ? 1 : C::WGS) * macro_cus(op));
-        constexpr bool kUsesDiag = MODE >= kCheb && MODE <= kChebOldInit;
+        constexpr bool kUsesDiag = is_cheb_mode(MODE);
         if (kUsesDiag && op.diag_items)
           {
             BrickPost<T> pt = post;
@@ -936,6 +986,7 @@ namespace mgx
         case kChebInit: macro_launch<P, T, kChebInit>(s, op, src, post, g0, g1); break;
         case kChebOldInit: macro_launch<P, T, kChebOldInit>(s, op, src, post, g0, g1); break;
         case kResidualRestrict: macro_launch<P, T, kResidualRestrict>(s, op, src, post, g0, g1); break;
+        case kChebFirstProlong: macro_launch<P, T, kChebFirstProlong>(s, op, src, post, g0, g1); break;
         default: break;
       }
   }
@@ -1089,7 +1140,8 @@ namespace mgx
                                                      const uint32_t *coarse_blocks, int g0, int g1)
   {
     using T = MGX_MACRO_T;
-    if (mode < kPlain || mode > kResidualRestrict || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
+    if (mode < kPlain || (mode > kResidualRestrict && mode != kChebFirstProlong) || MGX_MACRO_PAIRS * (mode == kChebFirstProlong) ||
+        (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
       return false;
     BrickPost<T> post;
     post.a             = (const T *)a;
@@ -1102,6 +1154,7 @@ namespace mgx
     post.f0            = (T)f0;
     post.coarse        = (T *)coarse;
     post.coarse_blocks = coarse_blocks;
+    post.src_w         = (T *)const_cast<void *>(src); // kChebFirstProlong writes the corrected x back
     switch (op.p)
       {
 #ifdef MGX_MACRO_ONLY_P

@@ -108,7 +108,7 @@ def test_c2_full_solve_reaches_the_readme_accuracy(big):
 
 FALLBACKS = {"MGX_NO_FUSED_RESTRICT": "1", "MGX_NO_FUSED_INIT": "1", "MGX_TRANSFER_V1": "1",
              "MGX_RESTRICT_ATOMIC": "1", "MGX_BRICK_WIDE_MAX": "0", "MGX_NO_GRAPH": "1", "MGX_BRICK_FORM": "cells",
-             "MGX_NO_DIAG_TABLE": "1"}
+             "MGX_NO_DIAG_TABLE": "1", "MGX_NO_FUSED_PROLONG": "1"}
 
 
 @pytest.mark.parametrize("p,ns,nr", [(4, 3, 5), (2, 1, 7), (3, 1, 6), (5, 1, 5), (8, 1, 5), (1, 1, 7)])

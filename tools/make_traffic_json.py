@@ -3,7 +3,20 @@ tools/matvec_loop.py <cells> <n> cheb.  usage: make_traffic_json.py fetch.csv wr
 
 Streaming kernels of the same run with known byte counts calibrate the counters (gfx950:
 FETCH_SIZE reports 1/2 for 8-B-per-lane reads, WRITE_SIZE is exact)."""
-import csv, json, sys, collections
+import csv, hashlib, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["multigrid_amd/csrc/mgx_macro.hip", "multigrid_amd/csrc/mgx_brick_device.hpp",
+                  "multigrid_amd/csrc/mgx_brick.hip", "multigrid_amd/csrc/mgx_bricks.cpp"]
+
+
+def kernel_source_sha():
+    """fingerprint of the brick-kernel sources: bench.py attaches the measured traffic to its
+    roofline only while the kernels are the ones that were measured"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(path):
@@ -24,6 +37,7 @@ def main():
            "workload": "poisson_cube FE_Q(4) %d^3 cells, %d DoFs, fp64, finest level, per colour launch" % (cells, n),
            "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
                     "(gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md 'HBM')",
+           "kernel_source_sha16": kernel_source_sha(), "kernel_sources": KERNEL_SOURCES,
            "calibration": {}, "kernels": {}}
     known = {"void mgx::k_copy_cast<double, double>": (8 * n, 8 * n), "void mgx::k_xpby<double>": (16 * n, 8 * n),
              "void mgx::k_dot_partial<double>": (16 * n, 0)}
@@ -38,10 +52,14 @@ def main():
     names = {0: ("kPlain", 16), 1: ("kResidual", 24), 2: ("kCheb", 40), 3: ("kChebFirst", 32), 4: ("kChebZeroOld", 32),
              5: ("kChebInit", 24), 6: ("kChebOldInit", 32), 7: ("kResidualRestrict", 18)}
     for mode, (nm, alg) in names.items():
-        k = "void mgx::brick_sep_kernel<4, double, %d, false>" % mode  # 256-thread form (full launches)
-        if k not in fe:
-            k = "void mgx::brick_sep_kernel<4, double, %d>" % mode     # builds before the 512-thread form
-        if k not in fe or k not in wr:
+        # macro-element form (production; fused Chebyshev forms with the inverse diagonal in registers
+        # when the diagonal is uniform), else the cell-by-cell form
+        for k in ("void mgx::brick_macro_kernel<4, double, %d, true>" % mode,
+                  "void mgx::brick_macro_kernel<4, double, %d, false>" % mode,
+                  "void mgx::brick_sep_kernel<4, double, %d, false>" % mode):
+            if k in fe and k in wr:
+                break
+        else:
             continue
         big = max(fe[k].keys())
         f = sum(fe[k][big]) / len(fe[k][big])
