@@ -178,7 +178,9 @@ typedef struct
   const uint32_t *constrained;
   uint32_t        n_constrained;
   /* merged_coefficient of the affine / constant-coefficient branch, [xx,yy,zz,xy,xz,yz]
-   * (laplace_operator.h:127, 374-387); the quadrature weight is applied per point (:456-457) */
+   * (laplace_operator.h:127, 374-387); the quadrature weight is applied per point (:456-457).
+   * Off-diagonal entries (non-Cartesian affine cells, :473-486) select the quadrature-point
+   * form of the cell loop. */
   double coef[6];
   /* 1D data of FEEvaluation<3,p,p+1>, row-major (p+1)x(p+1):
    * shape_values[q*(p+1)+i] = GLL-Lagrange basis i at Gauss point q;
@@ -201,6 +203,14 @@ typedef struct
   const uint32_t *global_index;
   /* Optional, may be NULL: interface exchange plan of a decomposed mesh */
   const mgx_exchange_desc *exchange;
+  /* Optional, may be NULL: merged_coefficient of the general branch -- variable coefficient and / or
+   * non-affine geometry -- one symmetric tensor per cell and quadrature point with the weight
+   * folded in (evaluate_coefficient laplace_operator.h:388-430, applied :493-522).  Layout
+   * component-major per cell: coef_q[(cell*6 + c)*(p+1)^3 + q], c over [xx,yy,zz,xy,xz,yz], q
+   * lexicographic with x fastest (the reference stores Tensor<1,6> per point; the shim
+   * transposes).  Host pointer, copied (in the operator's number type).  When given, coef[] is
+   * ignored. */
+  const double *coef_q;
 } mgx_operator_desc;
 
 /* LaplaceOperator::initialize + evaluate_coefficient (laplace_operator.h:184-220, 357-432) */

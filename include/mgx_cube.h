@@ -59,8 +59,27 @@ typedef struct
   int    procs[3];
   int    rank;
   int    numbering; /* MGX_CUBE_NUMBERING_* */
+  int    geometry;  /* MGX_CUBE_GEOMETRY_*: map of the reference box to physical space */
+  int    problem;   /* MGX_CUBE_PROBLEM_*: solution / right-hand side / coefficient */
 } mgx_cube_box_desc;
+/* Mapped meshes and variable coefficients (poisson_shell, BASELINE config 4).  With a geometry other
+ * than CARTESIAN or the SHELL problem every level carries the per-(cell, q) merged coefficient of
+ * evaluate_coefficient's general branch (laplace_operator.h:388-430), the cell geometry being the
+ * degree-p interpolant of the map (MappingQ, multigrid_solver.h:139):
+ *   SHEARED       a constant non-symmetric matrix close to the identity (affine cells, full tensor)
+ *   SHELL_SECTOR  one of the six blocks of GridGenerator::hyper_shell(0, 0.5, 1.0, 6)
+ *                 (poisson_shell/program.cc:425) as an equiangular cube-sphere sector: curved cells
+ *   PROBLEM_SHELL u = sin(2 pi (x+y)), a = 1 + 1e6 prod_e cos^2(2 pi x_e + 0.1 e), f = -div(a grad u)
+ *                 (poisson_shell/program.cc:97-137, 157-200, 219-225)
+ * The six-block shell itself (unstructured block connectivity) is not provided. */
+#define MGX_CUBE_GEOMETRY_CARTESIAN 0
+#define MGX_CUBE_GEOMETRY_SHEARED 1
+#define MGX_CUBE_GEOMETRY_SHELL_SECTOR 2
+#define MGX_CUBE_PROBLEM_CUBE 0
+#define MGX_CUBE_PROBLEM_SHELL 1
 int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
+/* [n_cells][6][(p+1)^3] merged coefficient of a mapped level (NULL on the Cartesian cube) */
+const double *mgx_cube_coef_q(mgx_cube_t cube, int level);
 int mgx_cube_rank(mgx_cube_t cube);
 int mgx_cube_size(mgx_cube_t cube);
 void mgx_cube_cells_per_dim3(mgx_cube_t cube, int level, uint32_t local[3], uint32_t global[3]);

@@ -300,9 +300,11 @@ class Cube:
     """Host-side discretisation of poisson_cube (include/mgx_cube.h): what deal.II supplies."""
 
     NUMBERING = {"brick": 0, "cell": 1}
+    GEOMETRY = {"cartesian": 0, "sheared": 1, "shell_sector": 2}
+    PROBLEM = {"cube": 0, "shell": 1}
 
     def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0, numbering="brick",
-                 origin=-1.0, h0=1.9):
+                 origin=-1.0, h0=1.9, geometry="cartesian", problem="cube"):
         """box=None: the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction.
         box=(sx,sy,sz): a box of sx x sy x sz cubic coarse cells of size h0 from (origin,)*3,
         optionally distributed over the process grid `procs`; this rank owns box[d]/procs[d] coarse
@@ -310,6 +312,8 @@ class Cube:
         doubling-mesh family (program.cc:509-529: one coarse cube per rank = weak scaling);
         box=(n,n,n), origin=-0.9, h0=1.9/n is the square mesh of poisson_cube with n_subdiv = n,
         block-split over the ranks (strong scaling of one problem).
+        geometry / problem (box form only): mapped meshes and the variable coefficient of
+        poisson_shell, MGX_CUBE_GEOMETRY_* / MGX_CUBE_PROBLEM_* in mgx_cube.h.
         numbering: "brick" (default, grouped for the device cell loop) or "cell" (the
         plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h."""
         self.lib = _lib.load()
@@ -318,7 +322,8 @@ class Cube:
         if box is None:
             check(self.lib.mgx_cube_create_numbered(degree, n_subdiv, n_refine, num, C.byref(h)))
         else:
-            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), origin, h0, (C.c_int * 3)(*procs), rank, num)
+            d = _lib.CubeBoxDesc(degree, n_refine, (C.c_int * 3)(*box), origin, h0, (C.c_int * 3)(*procs), rank, num,
+                                 self.GEOMETRY[geometry], self.PROBLEM[problem])
             check(self.lib.mgx_cube_create_box(C.byref(d), C.byref(h)))
         self.h = h
         self.rank, self.size = self.lib.mgx_cube_rank(h), self.lib.mgx_cube_size(h)
@@ -362,6 +367,15 @@ class Cube:
 
     def constrained(self, l):
         return self._arr("mgx_cube_constrained", (self.n_constrained(l),), l)
+
+    def coef_q(self, l):
+        """[n_cells, 6, (p+1)^3] merged coefficient of a mapped level (None on the Cartesian cube)"""
+        self.lib.mgx_cube_coef_q.restype = C.POINTER(C.c_double)
+        self.lib.mgx_cube_coef_q.argtypes = [C.c_void_p, C.c_int]
+        ptr = self.lib.mgx_cube_coef_q(self.h, l)
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(ptr, shape=(self.n_cells(l), 6, (self.degree + 1) ** 3)).copy()
 
     def children(self, l):
         return self._arr("mgx_cube_children", (self.n_cells(l - 1), 8), l)

@@ -39,7 +39,8 @@ class CommDesc(C.Structure):
 
 class CubeBoxDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("n_refine", C.c_int), ("roots", C.c_int * 3), ("origin", C.c_double),
-                ("h0", C.c_double), ("procs", C.c_int * 3), ("rank", C.c_int), ("numbering", C.c_int)]
+                ("h0", C.c_double), ("procs", C.c_int * 3), ("rank", C.c_int), ("numbering", C.c_int),
+                ("geometry", C.c_int), ("problem", C.c_int)]
 
 
 class OperatorDesc(C.Structure):
@@ -47,7 +48,7 @@ class OperatorDesc(C.Structure):
                 ("idx27", u32p), ("idx27_plain", u32p), ("constrained", u32p), ("n_constrained", C.c_uint32),
                 ("coef", C.c_double * 6), ("shape_values", f64p), ("colloc_grad", f64p), ("qweights", f64p),
                 ("brick_colour", C.POINTER(C.c_uint8)), ("global_index", u32p),
-                ("exchange", C.POINTER(ExchangeDesc))]
+                ("exchange", C.POINTER(ExchangeDesc)), ("coef_q", f64p)]
 
 
 class SmootherInfo(C.Structure):

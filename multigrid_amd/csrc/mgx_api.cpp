@@ -869,9 +869,6 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   MGX_REQUIRE(desc->idx27 && desc->shape_values && desc->colloc_grad && desc->qweights,
               "mgx_operator_create: missing table");
   MGX_REQUIRE(desc->n_constrained == 0 || desc->constrained, "mgx_operator_create: missing constrained list");
-  if (desc->coef[3] != 0. || desc->coef[4] != 0. || desc->coef[5] != 0.)
-    return fail(MGX_ERR_UNSUPPORTED, "mgx_operator_create: off-diagonal merged coefficient (non-Cartesian affine "
-                                     "geometry) is not implemented yet");
   const int    p = desc->degree, n = p + 1;
   const size_t n_entries = 27 * (size_t)desc->n_cells;
   // host-side validation of operand shapes before any kernel can touch them
@@ -991,7 +988,9 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   // the separable fast path needs the symmetry A[a][b] = A[n-1-a][n-1-b] of M and K (true for
   // any symmetric node/quadrature set); MGX_GENERAL_KERNEL=1 forces the quadrature-point form
   const Tunables &tun = ctx->tun;
-  d.separable        = !tun.general_kernel;
+  d.full_tensor      = !desc->coef_q && (desc->coef[3] != 0. || desc->coef[4] != 0. || desc->coef[5] != 0.);
+  const bool general = d.full_tensor || desc->coef_q; // quadrature-point operation with the full tensor
+  d.separable        = !tun.general_kernel && !general;
   d.cells_form       = tun.cells_form;
   d.wide_max         = tun.wide_max;
   d.macro_wg_x16     = tun.macro_wg_x16;
@@ -1015,9 +1014,46 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       MGX_HIP(hipMemcpy(d.basis, &b, sizeof(b), hipMemcpyHostToDevice));
     }
   MGX_HIP(hipMalloc(&d.inv_diag, number_size(d.number) * d.n_dofs));
+  if (general)
+    {
+      // G = D S for the diagonal of the general cell matrix; the per-point coefficient in the
+      // operator's number type
+      std::vector<double> G((size_t)n * n);
+      for (int q = 0; q < n; ++q)
+        for (int i = 0; i < n; ++i)
+          {
+            double g = 0;
+            for (int r = 0; r < n; ++r)
+              g += op->D[q * n + r] * op->S[r * n + i];
+            G[q * n + i] = g;
+          }
+      const size_t nq = desc->coef_q ? (size_t)desc->n_cells * 6 * n * n * n : 0;
+      if (d.number == MGX_F64)
+        {
+          MGX_HIP(hipMalloc(&d.grad_1d, sizeof(double) * n * n));
+          MGX_HIP(hipMemcpy(d.grad_1d, G.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+          if (nq)
+            {
+              MGX_HIP(hipMalloc(&d.coef_q, sizeof(double) * nq));
+              MGX_HIP(hipMemcpy(d.coef_q, desc->coef_q, sizeof(double) * nq, hipMemcpyHostToDevice));
+            }
+        }
+      else
+        {
+          std::vector<float> Gf(G.begin(), G.end());
+          MGX_HIP(hipMalloc(&d.grad_1d, sizeof(float) * n * n));
+          MGX_HIP(hipMemcpy(d.grad_1d, Gf.data(), sizeof(float) * n * n, hipMemcpyHostToDevice));
+          if (nq)
+            {
+              std::vector<float> cf(desc->coef_q, desc->coef_q + nq);
+              MGX_HIP(hipMalloc(&d.coef_q, sizeof(float) * nq));
+              MGX_HIP(hipMemcpy(d.coef_q, cf.data(), sizeof(float) * nq, hipMemcpyHostToDevice));
+            }
+        }
+    }
   // brick schedule for the atomic-free cell loop (mgx_brick.hip); MGX_NO_BRICKS=1 keeps the
   // per-cell kernel (A/B measurements)
-  if (!tun.no_bricks && (p <= 4 || d.separable))
+  if (!tun.no_bricks && !general && (p <= 4 || d.separable))
     {
       BrickHost   bh;
       std::string why;
@@ -1266,6 +1302,8 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.constrained);
   (void)hipFree(op->d.basis);
   (void)hipFree(op->d.inv_diag);
+  (void)hipFree(op->d.coef_q);
+  (void)hipFree(op->d.grad_1d);
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);

@@ -159,6 +159,11 @@ namespace
     std::vector<uint32_t> bc_index;
     std::vector<Neighbor> neighbors;    // domain decomposition: interface exchange lists
     std::vector<uint32_t> shared, not_owned; // union of the lists; those owned by a lower rank
+    // mapped mesh / variable coefficient (evaluate_coefficient's general branch): per cell and
+    // quadrature point the merged coefficient, component-major [cell][6][n_q] with the weight
+    // folded in, det(J) w_q and the physical quadrature point; empty on the Cartesian
+    // constant-coefficient mesh
+    std::vector<double>   coef_q, jxw, xq;
   };
 
   inline uint32_t compact3(uint32_t m)
@@ -169,14 +174,50 @@ namespace
     return r;
   }
 
-  double u_exact(double x, double y, double z) // poisson_cube/program.cc:98-104
+  // problem sets: MGX_CUBE_PROBLEM_CUBE poisson_cube/program.cc:98-104, 140-144, 266;
+  // MGX_CUBE_PROBLEM_SHELL poisson_shell/program.cc:97-137 (solution), 157-200 (coefficient), 219-225 (rhs)
+  struct Problem
   {
-    return std::sin(kPi * x * 3.) * std::sin(kPi * y * 3.) * std::sin(kPi * z * 3.);
-  }
-  double f_rhs(double x, double y, double z) // :140-144
-  {
-    return 3. * kPi * 3. * kPi * 3. * u_exact(x, y, z);
-  }
+    int id = MGX_CUBE_PROBLEM_CUBE;
+    double u(double x, double y, double z) const
+    {
+      if (id == MGX_CUBE_PROBLEM_SHELL)
+        return std::sin(2. * kPi * (x + y));
+      return std::sin(kPi * x * 3.) * std::sin(kPi * y * 3.) * std::sin(kPi * z * 3.);
+    }
+    double a(const double *x) const
+    {
+      if (id != MGX_CUBE_PROBLEM_SHELL)
+        return 1.;
+      double prod = 1.;
+      for (int e = 0; e < 3; ++e)
+        {
+          const double cs = std::cos(2. * kPi * x[e] + 0.1 * e);
+          prod *= cs * cs;
+        }
+      return 1. + 1.0e6 * prod;
+    }
+    double f(double x, double y, double z) const
+    {
+      if (id != MGX_CUBE_PROBLEM_SHELL)
+        return 3. * kPi * 3. * kPi * 3. * u(x, y, z);
+      const double X[3]  = {x, y, z};
+      const double arg   = 2. * kPi * (x + y);
+      const double lap_u = -8. * kPi * kPi * std::sin(arg), du = 2. * kPi * std::cos(arg); // du/dx = du/dy
+      double       grad_a_xy = 0.; // (grad a)_x + (grad a)_y: grad u has no z component
+      for (int d = 0; d < 2; ++d)
+        {
+          double prod = 1.0e6;
+          for (int e = 0; e < 3; ++e)
+            {
+              const double ang = 2. * kPi * X[e] + 0.1 * e, cs = std::cos(ang);
+              prod *= (e == d) ? -4. * kPi * cs * std::sin(ang) : cs * cs;
+            }
+          grad_a_xy += prod;
+        }
+      return -(lap_u * a(X) + grad_a_xy * du);
+    }
+  };
 } // namespace
 
 struct mgx_cube_s
@@ -187,7 +228,37 @@ struct mgx_cube_s
   int                pcoord[3] = {0, 0, 0}, rank = 0, size = 1;
   int                lroots[3] = {1, 1, 1}, roff[3] = {0, 0, 0}; // this rank's coarse cells and offset
   double             origin = -0.9, h0 = 1.9;
+  int                geometry = MGX_CUBE_GEOMETRY_CARTESIAN;
+  Problem            problem;
   bool               brick_numbering = false;
+  bool               mapped() const { return geometry != MGX_CUBE_GEOMETRY_CARTESIAN || problem.id != MGX_CUBE_PROBLEM_CUBE; }
+  // reference box -> physical space
+  void map(const double *X, double *x) const
+  {
+    if (geometry == MGX_CUBE_GEOMETRY_SHEARED)
+      {
+        x[0] = X[0] + 0.1 * (X[1] + 0.5 * X[2]);
+        x[1] = X[1] + 0.1 * (0.3 * X[0] + X[2]);
+        x[2] = X[2] + 0.1 * (0.2 * X[0] + 0.4 * X[1]);
+      }
+    else if (geometry == MGX_CUBE_GEOMETRY_SHELL_SECTOR)
+      {
+        // one block of hyper_shell(0, 0.5, 1, 6): equiangular cube-sphere sector around +z
+        const double sx = (X[0] - origin) / (groots[0] * h0), sy = (X[1] - origin) / (groots[1] * h0),
+                     sz = (X[2] - origin) / (groots[2] * h0);
+        const double tx = std::tan((2. * sx - 1.) * kPi / 4.), ty = std::tan((2. * sy - 1.) * kPi / 4.);
+        const double r  = (0.5 + 0.5 * sz) / std::sqrt(tx * tx + ty * ty + 1.);
+        x[0]            = r * tx;
+        x[1]            = r * ty;
+        x[2]            = r;
+      }
+    else
+      {
+        x[0] = X[0];
+        x[1] = X[1];
+        x[2] = X[2];
+      }
+  }
   Basis              basis;
   std::vector<Level> levels;
 };
@@ -527,6 +598,83 @@ namespace
         }
   }
 
+  // evaluate_coefficient, general branch (laplace_operator.h:388-430) for a mapped mesh: the cell
+  // geometry is the degree-p interpolant of the map at the GLL support points (MappingQ of
+  // multigrid_solver.h:139); per quadrature point JxW = det J w_q and coef = a(x_q) JxW J^-1 J^-T
+  void build_geometry(const mgx_cube_s &C, Level &L)
+  {
+    const int    p = C.p, n = p + 1, n3 = n * n * n;
+    const Basis &B = C.basis;
+    L.coef_q.assign((size_t)L.n_cells * 6 * n3, 0.);
+    L.jxw.assign((size_t)L.n_cells * n3, 0.);
+    L.xq.assign((size_t)L.n_cells * n3 * 3, 0.);
+#pragma omp parallel
+    {
+      std::vector<double> buf(14 * (size_t)n3);
+      double *nodes = buf.data(), *val = nodes + 3 * n3, *tmp = val + n3, *dx = tmp + n3; // dx: 9 n3 (d x_a / d xi_b)
+#pragma omp for schedule(static)
+      for (uint32_t c = 0; c < L.n_cells; ++c)
+        {
+          const double X0[3] = {C.origin + L.h * (L.off[0] + L.coords[3 * (size_t)c]),
+                                C.origin + L.h * (L.off[1] + L.coords[3 * (size_t)c + 1]),
+                                C.origin + L.h * (L.off[2] + L.coords[3 * (size_t)c + 2])};
+          for (int k = 0, i3 = 0; k < n; ++k)
+            for (int j = 0; j < n; ++j)
+              for (int i = 0; i < n; ++i, ++i3)
+                {
+                  const double Xr[3] = {X0[0] + L.h * B.gll[i], X0[1] + L.h * B.gll[j], X0[2] + L.h * B.gll[k]};
+                  double       xp[3];
+                  C.map(Xr, xp);
+                  nodes[i3] = xp[0];
+                  nodes[n3 + i3] = xp[1];
+                  nodes[2 * n3 + i3] = xp[2];
+                }
+          for (int a = 0; a < 3; ++a)
+            {
+              apply_1d(n, 0, B.S, false, nodes + a * n3, val, false);
+              apply_1d(n, 1, B.S, false, val, tmp, false);
+              apply_1d(n, 2, B.S, false, tmp, val, false);
+              for (int q = 0; q < n3; ++q)
+                L.xq[((size_t)c * n3 + q) * 3 + a] = val[q];
+              for (int b = 0; b < 3; ++b)
+                apply_1d(n, b, B.D, false, val, dx + (3 * a + b) * n3, false);
+            }
+          for (int k = 0, q = 0; k < n; ++k)
+            for (int j = 0; j < n; ++j)
+              for (int i = 0; i < n; ++i, ++q)
+                {
+                  double F[9], inv[9]; // F[3a+b] = d x_a / d xi_b
+                  for (int m = 0; m < 9; ++m)
+                    F[m] = dx[m * n3 + q];
+                  const double c00 = F[4] * F[8] - F[5] * F[7], c01 = F[5] * F[6] - F[3] * F[8], c02 = F[3] * F[7] - F[4] * F[6];
+                  const double det = F[0] * c00 + F[1] * c01 + F[2] * c02;
+                  // inverse by cofactors: inv[3b+a] = d xi_b / d x_a
+                  inv[0] = c00 / det;
+                  inv[3] = c01 / det;
+                  inv[6] = c02 / det;
+                  inv[1] = (F[2] * F[7] - F[1] * F[8]) / det;
+                  inv[4] = (F[0] * F[8] - F[2] * F[6]) / det;
+                  inv[7] = (F[1] * F[6] - F[0] * F[7]) / det;
+                  inv[2] = (F[1] * F[5] - F[2] * F[4]) / det;
+                  inv[5] = (F[2] * F[3] - F[0] * F[5]) / det;
+                  inv[8] = (F[0] * F[4] - F[1] * F[3]) / det;
+                  const double  jxw = det * B.gw[i] * B.gw[j] * B.gw[k];
+                  const double *xp  = &L.xq[((size_t)c * n3 + q) * 3];
+                  const double  s   = C.problem.a(xp) * jxw;
+                  double       *Cq  = &L.coef_q[(size_t)c * 6 * n3];
+                  auto          dotr = [&](int e, int f) { return inv[3 * e] * inv[3 * f] + inv[3 * e + 1] * inv[3 * f + 1] + inv[3 * e + 2] * inv[3 * f + 2]; };
+                  Cq[q]          = s * dotr(0, 0);
+                  Cq[n3 + q]     = s * dotr(1, 1);
+                  Cq[2 * n3 + q] = s * dotr(2, 2);
+                  Cq[3 * n3 + q] = s * dotr(0, 1);
+                  Cq[4 * n3 + q] = s * dotr(0, 2);
+                  Cq[5 * n3 + q] = s * dotr(1, 2);
+                  L.jxw[(size_t)c * n3 + q] = jxw;
+                }
+        }
+    }
+  }
+
   // boundary values + rhs (multigrid_solver.h:225-261, laplace_operator.h:804-845)
   void build_rhs(const mgx_cube_s &C, Level &L)
   {
@@ -576,7 +724,12 @@ namespace
                       const size_t gx = X * p + (cx == 0 ? 0 : (cx == 2 ? p : 1 + ox));
                       const size_t gy = Y * p + (cy == 0 ? 0 : (cy == 2 ? p : 1 + oy));
                       const size_t gz = Z * p + (cz == 0 ? 0 : (cz == 2 ? p : 1 + oz));
-                      bc_full[base + (uint32_t)((oz * ny + oy) * nx + ox)] = u_exact(xd[0][gx], xd[1][gy], xd[2][gz]);
+                      {
+                        const double Xr[3] = {xd[0][gx], xd[1][gy], xd[2][gz]};
+                        double       xp[3];
+                        C.map(Xr, xp);
+                        bc_full[base + (uint32_t)((oz * ny + oy) * nx + ox)] = C.problem.u(xp[0], xp[1], xp[2]);
+                      }
                     }
             }
         }
@@ -608,6 +761,18 @@ namespace
           const double x0 = C.origin + h * (L.off[0] + L.coords[3 * (size_t)c]),
                        y0 = C.origin + h * (L.off[1] + L.coords[3 * (size_t)c + 1]),
                        z0 = C.origin + h * (L.off[2] + L.coords[3 * (size_t)c + 2]);
+          if (!L.coef_q.empty()) // general branch: full tensor per quadrature point
+            for (int q = 0; q < n3; ++q)
+              {
+                const double *Cq = &L.coef_q[(size_t)c * 6 * n3];
+                const double  a = gx[q], b = gy[q], cc = gz[q];
+                gx[q] = Cq[q] * a + Cq[3 * n3 + q] * b + Cq[4 * n3 + q] * cc;
+                gy[q] = Cq[3 * n3 + q] * a + Cq[n3 + q] * b + Cq[5 * n3 + q] * cc;
+                gz[q] = Cq[4 * n3 + q] * a + Cq[5 * n3 + q] * b + Cq[2 * n3 + q] * cc;
+                const double *xp = &L.xq[((size_t)c * n3 + q) * 3];
+                t0[q]            = C.problem.f(xp[0], xp[1], xp[2]) * L.jxw[(size_t)c * n3 + q];
+              }
+          else
           for (int k = 0, q = 0; k < n; ++k)
             for (int j = 0; j < n; ++j)
               for (int i = 0; i < n; ++i, ++q)
@@ -616,7 +781,7 @@ namespace
                   gx[q] *= h * w; // merged coefficient diag(h,h,h) times w_q
                   gy[q] *= h * w;
                   gz[q] *= h * w;
-                  t0[q] = f_rhs(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]) * h3 * w; // :839
+                  t0[q] = C.problem.f(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]) * h3 * w; // :839
                 }
           apply_1d(n, 0, B.D, true, gx, t0, true);
           apply_1d(n, 1, B.D, true, gy, t0, true);
@@ -681,11 +846,15 @@ static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
     return MGX_ERR_INVALID_ARGUMENT;
   if (bd.numbering != MGX_CUBE_NUMBERING_BRICK && bd.numbering != MGX_CUBE_NUMBERING_CELL)
     return MGX_ERR_INVALID_ARGUMENT;
+  if (bd.geometry < 0 || bd.geometry > MGX_CUBE_GEOMETRY_SHELL_SECTOR || bd.problem < 0 || bd.problem > MGX_CUBE_PROBLEM_SHELL)
+    return MGX_ERR_INVALID_ARGUMENT;
   omp_set_num_threads(effective_threads());
   auto C    = std::make_unique<mgx_cube_s>();
   C->p      = degree;
   C->origin = bd.origin;
   C->h0     = bd.h0;
+  C->geometry   = bd.geometry;
+  C->problem.id = bd.problem;
   C->rank   = bd.rank;
   C->size   = size;
   int r     = bd.rank;
@@ -706,6 +875,8 @@ static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
       build_level(*C, C->levels[l], l);
       build_dof_grid(*C, C->levels[l]);
       build_interfaces(*C, C->levels[l]);
+      if (C->mapped())
+        build_geometry(*C, C->levels[l]);
       build_rhs(*C, C->levels[l]);
     }
   *out = C.release();
@@ -722,7 +893,7 @@ int mgx_cube_create_numbered(int degree, int n_subdiv, int n_refine, int numberi
   // "square" mesh: subdivided_hyper_cube(n_subdiv, -0.9, 1.0) (poisson_cube/program.cc:542)
   if (n_subdiv < 1)
     return MGX_ERR_INVALID_ARGUMENT;
-  mgx_cube_box_desc bd;
+  mgx_cube_box_desc bd{};
   bd.degree   = degree;
   bd.n_refine = n_refine;
   bd.origin   = -0.9;
@@ -795,6 +966,11 @@ uint32_t        mgx_cube_bc_count(mgx_cube_t c, int l) { return (uint32_t)c->lev
 const uint32_t *mgx_cube_bc_index(mgx_cube_t c, int l) { return c->levels[l].bc_index.data(); }
 const double   *mgx_cube_bc_value(mgx_cube_t c, int l) { return c->levels[l].bc_value.data(); }
 
+const double *mgx_cube_coef_q(mgx_cube_t c, int l)
+{
+  return (c && l >= 0 && l < (int)c->levels.size() && !c->levels[l].coef_q.empty()) ? c->levels[l].coef_q.data() : nullptr;
+}
+
 int mgx_cube_operator_desc(mgx_cube_t c, int l, int number, mgx_operator_desc *d)
 {
   if (!c || !d || l < 0 || l >= (int)c->levels.size())
@@ -811,6 +987,7 @@ int mgx_cube_operator_desc(mgx_cube_t c, int l, int number, mgx_operator_desc *d
   // merged_coefficient = a JxW J^-T J^-1 = h^3/h^2 on the Cartesian mesh (laplace_operator.h:374-387)
   d->coef[0] = d->coef[1] = d->coef[2] = L.h;
   d->coef[3] = d->coef[4] = d->coef[5] = 0.;
+  d->coef_q       = L.coef_q.empty() ? nullptr : L.coef_q.data(); // general branch (mapped mesh / variable coefficient)
   d->shape_values = c->basis.S;
   d->colloc_grad  = c->basis.D;
   d->qweights     = c->basis.gw;
@@ -878,8 +1055,15 @@ void mgx_cube_l2_error_parts(mgx_cube_t c, int l, const double *sol, double *err
           for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i, ++q)
               {
-                const double JxW = B.gw[i] * B.gw[j] * B.gw[k] * h3;
-                const double d   = t0[q] - u_exact(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]);
+                double JxW = B.gw[i] * B.gw[j] * B.gw[k] * h3, d;
+                if (!L.jxw.empty())
+                  {
+                    const double *xp = &L.xq[((size_t)cell * n3 + q) * 3];
+                    JxW              = L.jxw[(size_t)cell * n3 + q];
+                    d                = t0[q] - c->problem.u(xp[0], xp[1], xp[2]);
+                  }
+                else
+                  d = t0[q] - c->problem.u(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]);
                 err += d * d * JxW;
                 vol += JxW;
               }

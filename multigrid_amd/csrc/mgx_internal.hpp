@@ -100,6 +100,9 @@ namespace mgx
     void     *basis         = nullptr; // device Basis1D<T>
     void     *inv_diag      = nullptr; // device, number type
     double    coef[6]       = {0, 0, 0, 0, 0, 0};
+    bool      full_tensor   = false;   // affine cells with off-diagonal coefficient entries (:473-486)
+    void     *coef_q        = nullptr; // device [n_cells][6][n^3], number type: general branch (:493-522)
+    void     *grad_1d       = nullptr; // device [n*n], number type: G = D S, nodal derivative at the quadrature points
     BrickData bricks;
     bool      cells_form    = false; // Tunables::cells_form of the context the operator was created on
     uint32_t  wide_max      = 1024;  // Tunables::wide_max

@@ -267,6 +267,226 @@ namespace mgx
       }
   }
 
+  // ------------------------------------------------------------------------------------------
+  // General quadrature-point operation (do_quadrature_point_operation, laplace_operator.h:436-523):
+  // the full symmetric tensor, either one per mesh times the quadrature weight (affine branch
+  // :447-491, PERQ = false) or one per cell and quadrature point with the weight folded in
+  // (:493-522, PERQ = true; evaluate_coefficient :388-430 -- variable coefficient, curved cells).
+  // All three gradient components are needed at a point at once: the x- and y-derivative arrays
+  // go through LDS to the thread that owns the z-line through the point, which holds the
+  // z-derivative in registers, applies the tensor and hands the x / y parts back the same way.
+  // coef_q is component-major per cell, [cell][6][n^3]: the N^2 threads of a cell read every
+  // component with unit stride.  109.75 B per DoF at p = 4 against 16 B of the vectors:
+  // this kernel is bound by the coefficient stream.
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T, bool PERQ>
+  __global__ void __launch_bounds__(Cfg<P>::THREADS)
+    cell_loop_general_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
+                             uint32_t n_cells, const Basis1D<T> *__restrict__ B, const T *__restrict__ coef_q, T c0,
+                             T c1, T c2, T c3, T c4, T c5)
+  {
+    using C           = Cfg<P>;
+    constexpr int N   = C::N;
+    constexpr int LN  = C::LN;
+    constexpr int PL  = N * LN;
+    constexpr int N3  = N * N * N;
+    __shared__ T U[C::CPB * C::CELL_LDS];  // values at the quadrature points, then the result
+    __shared__ T GX[C::CPB * C::CELL_LDS]; // x-derivative / x part of the flux
+    __shared__ T GY[C::CPB * C::CELL_LDS];
+
+    const int      tid    = threadIdx.x;
+    const int      lc     = tid / C::TPC;
+    const int      t      = tid - lc * C::TPC;
+    const int      a      = t % N;
+    const int      b      = t / N;
+    const uint32_t cell   = blockIdx.x * C::CPB + lc;
+    const bool     active = (lc < C::CPB) && (cell < n_cells);
+    const int      slot   = lc < C::CPB ? lc : 0;
+    T             *Uc = U + slot * C::CELL_LDS, *Xc = GX + slot * C::CELL_LDS, *Yc = GY + slot * C::CELL_LDS;
+    const int      xl = (b * N + a) * LN, yl = b * PL + a, zl = b * LN + a;
+    T              r[N], q[N], gz[N];
+    LineIndex<P>   L;
+    if (active) // nodal -> quadrature along x
+      {
+        L = line_index<P>(idx27, cell, a, b);
+        gather_line<P, T>(src, L, r);
+        mv<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[xl + i] = q[i];
+      }
+    __syncthreads();
+    if (active) // along y
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[yl + i * LN];
+        mv<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[yl + i * LN] = q[i];
+      }
+    __syncthreads();
+    if (active) // along z; z-derivative of this z-line in registers
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[zl + i * PL];
+        mv<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[zl + i * PL] = q[i];
+        mv<N, T>(B->D, q, gz);
+      }
+    __syncthreads();
+    if (active) // x- and y-derivatives, to the z-line owners through LDS
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          q[i] = Uc[xl + i];
+        mv<N, T>(B->D, q, r);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Xc[xl + i] = r[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          q[i] = Uc[yl + i * LN];
+        mv<N, T>(B->D, q, r);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Yc[yl + i * LN] = r[i];
+      }
+    __syncthreads();
+    if (active) // the tensor at the N points of this z-line: (i, j, k) = (a, b, k)
+      {
+        const T *cq = coef_q + (size_t)cell * 6 * N3 + (size_t)(b * N + a);
+        const T  wab = B->w[a] * B->w[b];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          {
+            T t0, t1, t2, t3, t4, t5;
+            if (PERQ)
+              {
+                const T *cp = cq + k * N * N;
+                t0 = cp[0], t1 = cp[N3], t2 = cp[2 * N3], t3 = cp[3 * N3], t4 = cp[4 * N3], t5 = cp[5 * N3];
+              }
+            else
+              {
+                const T w = wab * B->w[k]; // :456-457
+                t0 = c0 * w, t1 = c1 * w, t2 = c2 * w, t3 = c3 * w, t4 = c4 * w, t5 = c5 * w;
+              }
+            const T gx = Xc[zl + k * PL], gy = Yc[zl + k * PL], g = gz[k];
+            Xc[zl + k * PL] = t0 * gx + t3 * gy + t4 * g; // :473-486 / :505-518
+            Yc[zl + k * PL] = t3 * gx + t1 * gy + t5 * g;
+            gz[k]           = t4 * gx + t5 * gy + t2 * g;
+          }
+        mvT<N, T>(B->D, gz, q); // integrate the z part along z
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          gz[i] = q[i];
+      }
+    __syncthreads();
+    if (active) // transposed x-derivative
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Xc[xl + i];
+        mvT<N, T>(B->D, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[xl + i] = q[i];
+      }
+    __syncthreads();
+    if (active) // transposed y-derivative, accumulated
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Yc[yl + i * LN];
+        mvT<N, T>(B->D, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[yl + i * LN] += q[i];
+      }
+    __syncthreads();
+    if (active) // add the z part, quadrature -> nodal along z
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[zl + i * PL] + gz[i];
+        mvT<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[zl + i * PL] = q[i];
+      }
+    __syncthreads();
+    if (active) // along y
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[yl + i * LN];
+        mvT<N, T>(B->S, r, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          Uc[yl + i * LN] = q[i];
+      }
+    __syncthreads();
+    if (active) // along x, scatter-add
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = Uc[xl + i];
+        mvT<N, T>(B->S, r, q);
+        scatter_add_line<P, T>(dst, L, q);
+      }
+  }
+
+  // Diagonal of the general cell matrix (local_compute_diagonal :770-800, restated in closed form):
+  // d_i = sum_q C(q) : grad phi_i(q) grad phi_i(q) with grad phi_i(q) from the 1D values S and
+  // nodal derivatives G = D S at the quadrature points.  One thread per cell DoF line (j, k).
+  template <int P, typename T, bool PERQ>
+  __global__ void __launch_bounds__(256)
+    cell_diagonal_general_kernel(T *__restrict__ diag, const uint32_t *__restrict__ idx27, uint32_t n_cells,
+                                 const Basis1D<T> *__restrict__ B, const T *__restrict__ G1,
+                                 const T *__restrict__ coef_q, T c0, T c1, T c2, T c3, T c4, T c5)
+  {
+    constexpr int  N = P + 1, N3 = N * N * N;
+    const uint32_t gid  = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cell = gid / (N * N);
+    if (cell >= n_cells)
+      return;
+    const int t = gid % (N * N), j = t % N, k = t / N;
+    T         r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      r[i] = T(0);
+    const T *cq = coef_q + (size_t)cell * 6 * N3;
+    for (int qz = 0; qz < N; ++qz)
+      for (int qy = 0; qy < N; ++qy)
+        {
+          const T sy = B->S[qy * N + j], sz = B->S[qz * N + k], gy1 = G1[qy * N + j], gz1 = G1[qz * N + k];
+          for (int qx = 0; qx < N; ++qx)
+            {
+              const int q = (qz * N + qy) * N + qx;
+              T         t0, t1, t2, t3, t4, t5;
+              if (PERQ)
+                t0 = cq[q], t1 = cq[N3 + q], t2 = cq[2 * N3 + q], t3 = cq[3 * N3 + q], t4 = cq[4 * N3 + q], t5 = cq[5 * N3 + q];
+              else
+                {
+                  const T w = B->w[qx] * B->w[qy] * B->w[qz];
+                  t0 = c0 * w, t1 = c1 * w, t2 = c2 * w, t3 = c3 * w, t4 = c4 * w, t5 = c5 * w;
+                }
+#pragma unroll
+              for (int i = 0; i < N; ++i)
+                {
+                  const T dx = G1[qx * N + i] * sy * sz, dy = B->S[qx * N + i] * gy1 * sz, dz = B->S[qx * N + i] * sy * gz1;
+                  r[i] += t0 * dx * dx + t1 * dy * dy + t2 * dz * dz + T(2) * (t3 * dx * dy + t4 * dx * dz + t5 * dy * dz);
+                }
+            }
+        }
+    const LineIndex<P> L = line_index<P>(idx27, cell, j, k);
+    scatter_add_line<P, T>(diag, L, r);
+  }
+
   // diagonal of the cell matrix (local_compute_diagonal, laplace_operator.h:770-800).  For the
   // affine constant-coefficient tensor the unit-vector applications collapse to
   //   d_i = c0 a[ix] m[iy] m[iz] + c1 m[ix] a[iy] m[iz] + c2 m[ix] m[iy] a[iz]
@@ -522,9 +742,18 @@ namespace mgx
   {
     using C            = Cfg<P>;
     const uint32_t nb  = (op.n_cells + C::CPB - 1) / C::CPB;
-    hipLaunchKernelGGL((cell_loop_kernel<P, T>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
-                       op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
-                       (T)op.coef[2]);
+    if (op.coef_q)
+      hipLaunchKernelGGL((cell_loop_general_kernel<P, T, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                         op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (const T *)op.coef_q, (T)0, (T)0, (T)0, (T)0,
+                         (T)0, (T)0);
+    else if (op.full_tensor)
+      hipLaunchKernelGGL((cell_loop_general_kernel<P, T, false>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                         op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (const T *)nullptr, (T)op.coef[0],
+                         (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5]);
+    else
+      hipLaunchKernelGGL((cell_loop_kernel<P, T>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                         op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
+                         (T)op.coef[2]);
   }
 
   void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src)
@@ -551,8 +780,17 @@ namespace mgx
       }
     const uint64_t nthreads = (uint64_t)op.n_cells * N * N;
     const uint32_t nb       = (uint32_t)((nthreads + 255) / 256);
-    hipLaunchKernelGGL((cell_diagonal_kernel<P, T>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, op.n_cells,
-                       d1, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2]);
+    if (op.coef_q)
+      hipLaunchKernelGGL((cell_diagonal_general_kernel<P, T, true>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27,
+                         op.n_cells, (const Basis1D<T> *)op.basis, (const T *)op.grad_1d, (const T *)op.coef_q, (T)0, (T)0,
+                         (T)0, (T)0, (T)0, (T)0);
+    else if (op.full_tensor)
+      hipLaunchKernelGGL((cell_diagonal_general_kernel<P, T, false>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27,
+                         op.n_cells, (const Basis1D<T> *)op.basis, (const T *)op.grad_1d, (const T *)nullptr, (T)op.coef[0],
+                         (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5]);
+    else
+      hipLaunchKernelGGL((cell_diagonal_kernel<P, T>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, op.n_cells,
+                         d1, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2]);
   }
 
   void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m)

@@ -45,6 +45,11 @@ def lib():
     L.orc_create.argtypes = [C.c_int] * 6
     L.orc_create_box.restype = vp
     L.orc_create_box.argtypes = [C.c_int] * 8
+    L.orc_create_mapped.restype = vp
+    L.orc_create_mapped.argtypes = [C.c_int] * 4 + [C.c_double, C.c_double] + [C.c_int] * 6
+    L.orc_set_affine_coef.argtypes = [vp, C.c_int, _f64p]
+    L.orc_coef_q.restype = C.POINTER(C.c_double)
+    L.orc_coef_q.argtypes = [vp, C.c_int]
     L.orc_cells_per_dim3.argtypes = [vp, C.c_int, C.POINTER(C.c_int * 3)]
     L.orc_destroy.argtypes = [vp]
     for name in ("orc_n_levels", "orc_degree"):
@@ -103,11 +108,20 @@ def _p(a):
 class Oracle:
     """MultigridSolver<3,p,Number,double> of the reference, restated on the CPU."""
 
-    def __init__(self, p, n_subdiv=1, n_refine=3, degree=3, n_cycles=1, vfloat=False, box=None):
+    GEOMETRY = {"cartesian": 0, "sheared": 1, "shell_sector": 2}
+    PROBLEM = {"cube": 0, "shell": 1}
+
+    def __init__(self, p, n_subdiv=1, n_refine=3, degree=3, n_cycles=1, vfloat=False, box=None, geometry=None,
+                 problem="cube", origin=-0.9, h0=None):
         """box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1));
         otherwise the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction"""
         self.L = lib()
-        if box is not None:
+        if geometry is not None:
+            # mapped mesh / variable coefficient (poisson_shell): box of `box` (default n_subdiv^3) coarse cells
+            b = box if box is not None else (n_subdiv,) * 3
+            self.h = self.L.orc_create_mapped(p, b[0], b[1], b[2], origin, 1.9 / b[0] if h0 is None else h0, n_refine,
+                                              degree, n_cycles, int(vfloat), self.GEOMETRY[geometry], self.PROBLEM[problem])
+        elif box is not None:
             self.h = self.L.orc_create_box(p, box[0], box[1], box[2], n_refine, degree, n_cycles, int(vfloat))
         else:
             self.h = self.L.orc_create(p, n_subdiv, n_refine, degree, n_cycles, int(vfloat))
@@ -267,6 +281,17 @@ class Oracle:
         out = np.zeros(3)
         self.L.orc_vmult_with_residual_update(self.h, _p(residual), _p(update), factor, _p(out))
         return out
+
+    def set_affine_coef(self, l, coef6):
+        self.L.orc_set_affine_coef(self.h, l, _p(np.ascontiguousarray(coef6, dtype=np.float64)))
+
+    def coef_q(self, l):
+        """[n_cells, (p+1)^3, 6] merged coefficient of the general branch (None on the affine branch)"""
+        ptr = self.L.orc_coef_q(self.h, l)
+        if not ptr:
+            return None
+        n3 = (self.p + 1) ** 3
+        return np.ctypeslib.as_array(ptr, shape=(self.n_cells(l), n3, 6)).copy()
 
     def solve(self, analyze=False):
         trace = np.zeros(4 * self.n_levels)

@@ -228,6 +228,10 @@ typedef struct
   uint32_t *colour_cells;
   uint32_t *children_of_parent; /* [n_cells(level-1)*8] -> cell index on this level */
   double    h, coef[6];
+  /* general branch (laplace_operator.h:388-430): per (cell, q) merged coefficient with the weight
+   * folded in [cell][q][xx,yy,zz,xy,xz,yz]; JxW and the physical quadrature points.  NULL on the
+   * Cartesian constant-coefficient mesh (affine branch, one tensor per mesh). */
+  double   *coef_q, *jxw, *xq;
 } orc_level;
 
 struct orc_problem
@@ -236,6 +240,8 @@ struct orc_problem
   int        roots[3];  /* coarse cells per direction */
   double     origin;    /* lower corner of the domain (all directions) */
   double     h0;        /* size of a coarse cell */
+  int        geometry;  /* ORC_GEOM_* */
+  int        problem;   /* ORC_PROBLEM_* */
   orc_basis  basis;
   orc_level *levels;
   void      *Bd, *Bf; /* basis_d / basis_f  */
@@ -391,6 +397,9 @@ static void level_free(orc_level *L)
   free(L->dof_grid);
   free(L->colour_cells);
   free(L->children_of_parent);
+  free(L->coef_q);
+  free(L->jxw);
+  free(L->xq);
 }
 
 /* number-type instantiations */
@@ -418,14 +427,80 @@ typedef struct
 #define BD(P) ((const basis_d *)(P)->Bd)
 #define BF(P) ((const basis_f *)(P)->Bf)
 
-/* Problem definition: poisson_cube/program.cc:98-104 (solution), :140-144 (rhs) */
+/* Problem definitions.
+ * ORC_PROBLEM_CUBE : poisson_cube/program.cc:98-104 (solution), :140-144 (rhs), coefficient 1 (:266)
+ * ORC_PROBLEM_SHELL: poisson_shell/program.cc:97-137 (u = sin(2 pi (x+y))), :157-200 (coefficient
+ *                    1 + 1e6 prod_e cos^2(2 pi x_e + 0.1 e) and its gradient), :219-225 (rhs =
+ *                    -(lap u * a + grad a . grad u)) */
+static int g_problem = 0; /* set by create_impl for the functions below (one problem per process) */
+static double coefficient_a(const double x[3])
+{
+  if (g_problem != ORC_PROBLEM_SHELL)
+    return 1.;
+  double prod = 1.;
+  for (int e = 0; e < 3; ++e)
+    {
+      const double cc = cos(2. * M_PI * x[e] + 0.1 * e);
+      prod *= cc * cc;
+    }
+  return 1. + 1.0e6 * prod;
+}
 static double u_exact(double x, double y, double z)
 {
+  if (g_problem == ORC_PROBLEM_SHELL)
+    return sin(2. * M_PI * (x + y));
   return sin(M_PI * x * 3.) * sin(M_PI * y * 3.) * sin(M_PI * z * 3.);
 }
 static double f_rhs(double x, double y, double z)
 {
+  if (g_problem == ORC_PROBLEM_SHELL)
+    {
+      const double X[3] = {x, y, z};
+      const double lap  = -2. * 2. * M_PI * 2. * M_PI * sin(2. * M_PI * (x + y));
+      const double gu   = 2. * M_PI * cos(2. * M_PI * (x + y)); /* d/dx = d/dy, d/dz = 0 */
+      double       ga[3];
+      for (int d = 0; d < 3; ++d)
+        {
+          double prod = 1.;
+          for (int e = 0; e < 3; ++e)
+            {
+              const double cc = cos(2. * M_PI * X[e] + 0.1 * e);
+              prod *= e == d ? -4. * M_PI * cc * sin(2. * M_PI * X[e] + 0.1 * e) : cc * cc;
+            }
+          ga[d] = 1.0e6 * prod;
+        }
+      return -(lap * coefficient_a(X) + (ga[0] + ga[1]) * gu);
+    }
   return 3. * M_PI * 3. * M_PI * 3. * u_exact(x, y, z);
+}
+
+/* Geometry: the reference box [origin, origin + roots h0]^3 mapped to physical space.
+ * ORC_GEOM_CARTESIAN: identity.  ORC_GEOM_SHEARED: a constant (non-symmetric) matrix, affine cells
+ * with a full merged-coefficient tensor.  ORC_GEOM_SHELL_SECTOR: one of the six blocks of
+ * GridGenerator::hyper_shell(0, 0.5, 1.0, 6) (poisson_shell/program.cc:425) as an equiangular
+ * cube-sphere sector, s in [0,1]^3 -> (0.5 + 0.5 s_z) (tan a, tan b, 1)/|.| with a, b = (2 s - 1) pi/4. */
+static void map_point(const orc_problem *P, const double X[3], double x[3])
+{
+  if (P->geometry == ORC_GEOM_SHEARED)
+    {
+      static const double S[3][3] = {{0., 1., 0.5}, {0.3, 0., 1.}, {0.2, 0.4, 0.}};
+      for (int d = 0; d < 3; ++d)
+        x[d] = X[d] + 0.1 * (S[d][0] * X[0] + S[d][1] * X[1] + S[d][2] * X[2]);
+    }
+  else if (P->geometry == ORC_GEOM_SHELL_SECTOR)
+    {
+      double s[3];
+      for (int d = 0; d < 3; ++d)
+        s[d] = (X[d] - P->origin) / (P->roots[d] * P->h0);
+      const double a = (2. * s[0] - 1.) * M_PI / 4., b = (2. * s[1] - 1.) * M_PI / 4.;
+      const double v[3] = {tan(a), tan(b), 1.}, r = 0.5 + 0.5 * s[2];
+      const double nv   = sqrt(v[0] * v[0] + v[1] * v[1] + 1.);
+      for (int d = 0; d < 3; ++d)
+        x[d] = r * v[d] / nv;
+    }
+  else
+    for (int d = 0; d < 3; ++d)
+      x[d] = X[d];
 }
 
 static void grid_to_xyz(const orc_problem *P, const orc_level *L, uint32_t gid, double xyz[3])
@@ -443,6 +518,8 @@ static void grid_to_xyz(const orc_problem *P, const orc_level *L, uint32_t gid, 
         }
       xyz[d] = P->origin + L->h * ((double)cell + P->basis.gll[loc]);
     }
+  const double X[3] = {xyz[0], xyz[1], xyz[2]};
+  map_point(P, X, xyz);
 }
 
 /* LaplaceOperator::compute_residual (laplace_operator.h:804-845): dst = int f phi - int C grad
@@ -477,6 +554,17 @@ static void compute_rhs(const orc_problem *P, const orc_level *L, double *dst, c
             const double x0 = P->origin + L->h * L->cell_coords[3 * (size_t)c],
                          y0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 1],
                          z0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 2];
+            if (L->coef_q) /* general branch: full coefficient per q, JxW and x_q from the mapping */
+              for (int q = 0; q < n3; ++q)
+                {
+                  const double *C = L->coef_q + ((size_t)c * n3 + q) * 6, *xq = L->xq + ((size_t)c * n3 + q) * 3;
+                  const double  a = gx[q], b = gy[q], cc = gz[q];
+                  gx[q] = C[0] * a + C[3] * b + C[4] * cc;
+                  gy[q] = C[3] * a + C[1] * b + C[5] * cc;
+                  gz[q] = C[4] * a + C[5] * b + C[2] * cc;
+                  t0[q] = f_rhs(xq[0], xq[1], xq[2]) * L->jxw[(size_t)c * n3 + q];
+                }
+            else
             for (int k = 0, q = 0; k < n; ++k)
               for (int j = 0; j < n; ++j)
                 for (int i = 0; i < n; ++i, ++q)
@@ -545,7 +633,7 @@ static int effective_threads(void)
 }
 
 static orc_problem *create_impl(int p, const int roots[3], double origin, double h0, int n_refine, int degree,
-                                int n_cycles, int vfloat);
+                                int n_cycles, int vfloat, int geometry, int problem);
 
 orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cycles, int vfloat)
 {
@@ -553,7 +641,7 @@ orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cyc
   const int roots[3] = {n_subdiv, n_subdiv, n_subdiv};
   if (n_subdiv < 1)
     return NULL;
-  return create_impl(p, roots, -0.9, 1.9 / n_subdiv, n_refine, degree, n_cycles, vfloat);
+  return create_impl(p, roots, -0.9, 1.9 / n_subdiv, n_refine, degree, n_cycles, vfloat, ORC_GEOM_CARTESIAN, ORC_PROBLEM_CUBE);
 }
 
 orc_problem *orc_create_box(int p, int sx, int sy, int sz, int n_refine, int degree, int n_cycles, int vfloat)
@@ -563,12 +651,106 @@ orc_problem *orc_create_box(int p, int sx, int sy, int sz, int n_refine, int deg
   const int roots[3] = {sx, sy, sz};
   if (sx < 1 || sy < 1 || sz < 1)
     return NULL;
-  return create_impl(p, roots, -1.0, 1.9, n_refine, degree, n_cycles, vfloat);
+  return create_impl(p, roots, -1.0, 1.9, n_refine, degree, n_cycles, vfloat, ORC_GEOM_CARTESIAN, ORC_PROBLEM_CUBE);
+}
+
+orc_problem *orc_create_mapped(int p, int sx, int sy, int sz, double origin, double h0, int n_refine, int degree,
+                               int n_cycles, int vfloat, int geometry, int problem)
+{
+  const int roots[3] = {sx, sy, sz};
+  if (sx < 1 || sy < 1 || sz < 1 || !(h0 > 0) || geometry < 0 || geometry > 2 || problem < 0 || problem > 1)
+    return NULL;
+  return create_impl(p, roots, origin, h0, n_refine, degree, n_cycles, vfloat, geometry, problem);
+}
+
+const double *orc_coef_q(const orc_problem *P, int l) { return P->levels[l].coef_q; }
+
+/* affine branch with a full tensor (laplace_operator.h:374-387, 473-486): replaces the merged
+ * coefficient of a level of a Cartesian problem (tests of the off-diagonal entries) */
+void orc_set_affine_coef(orc_problem *P, int l, const double *coef)
+{
+  for (int i = 0; i < 6; ++i)
+    P->levels[l].coef[i] = coef[i];
+}
+
+/* evaluate_coefficient, general branch (laplace_operator.h:388-430): per cell and quadrature point
+ * coef = a(x_q) JxW J^-T J^-1 with JxW = det J w_q.  The geometry is isoparametric of degree p:
+ * the GLL support points of a cell are mapped exactly, Jacobians come from the interpolant. */
+static void level_geometry(const orc_problem *P, orc_level *L)
+{
+  const int        p = P->p, n = p + 1, n3 = n * n * n;
+  const orc_basis *b = &P->basis;
+  L->coef_q          = (double *)malloc(sizeof(double) * (size_t)L->n_cells * n3 * 6);
+  L->jxw             = (double *)malloc(sizeof(double) * (size_t)L->n_cells * n3);
+  L->xq              = (double *)malloc(sizeof(double) * (size_t)L->n_cells * n3 * 3);
+  const basis_d *B   = BD(P);
+#pragma omp parallel
+  {
+    double *xn = (double *)malloc(sizeof(double) * n3 * 16), *t0 = xn + 3 * n3, *t1 = t0 + n3, *J = t1 + n3; /* J: 9 n3 */
+#pragma omp for schedule(static)
+    for (uint32_t c = 0; c < L->n_cells; ++c)
+      {
+        for (int k = 0, i3 = 0; k < n; ++k)
+          for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i, ++i3)
+              {
+                const double X[3] = {P->origin + L->h * (L->cell_coords[3 * (size_t)c] + b->gll[i]),
+                                     P->origin + L->h * (L->cell_coords[3 * (size_t)c + 1] + b->gll[j]),
+                                     P->origin + L->h * (L->cell_coords[3 * (size_t)c + 2] + b->gll[k])};
+                double       x[3];
+                map_point(P, X, x);
+                for (int d = 0; d < 3; ++d)
+                  xn[d * n3 + i3] = x[d];
+              }
+        for (int d = 0; d < 3; ++d)
+          {
+            sweep_d(n, 0, B->S, xn + d * n3, t0, 0);
+            sweep_d(n, 1, B->S, t0, t1, 0);
+            sweep_d(n, 2, B->S, t1, t0, 0); /* t0 = x_d at the quadrature points */
+            for (int q = 0; q < n3; ++q)
+              L->xq[((size_t)c * n3 + q) * 3 + d] = t0[q];
+            for (int e = 0; e < 3; ++e) /* J[d][e] = d x_d / d xi_e */
+              sweep_d(n, e, B->D, t0, J + (3 * d + e) * n3, 0);
+          }
+        for (int k = 0, q = 0; k < n; ++k)
+          for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i, ++q)
+              {
+                double Jm[3][3], Ji[3][3];
+                for (int d = 0; d < 3; ++d)
+                  for (int e = 0; e < 3; ++e)
+                    Jm[d][e] = J[(3 * d + e) * n3 + q];
+                const double det = Jm[0][0] * (Jm[1][1] * Jm[2][2] - Jm[1][2] * Jm[2][1]) -
+                                   Jm[0][1] * (Jm[1][0] * Jm[2][2] - Jm[1][2] * Jm[2][0]) +
+                                   Jm[0][2] * (Jm[1][0] * Jm[2][1] - Jm[1][1] * Jm[2][0]);
+                /* Ji = Jm^-1 : d xi_e / d x_d at [e][d] */
+                Ji[0][0] = (Jm[1][1] * Jm[2][2] - Jm[1][2] * Jm[2][1]) / det;
+                Ji[0][1] = (Jm[0][2] * Jm[2][1] - Jm[0][1] * Jm[2][2]) / det;
+                Ji[0][2] = (Jm[0][1] * Jm[1][2] - Jm[0][2] * Jm[1][1]) / det;
+                Ji[1][0] = (Jm[1][2] * Jm[2][0] - Jm[1][0] * Jm[2][2]) / det;
+                Ji[1][1] = (Jm[0][0] * Jm[2][2] - Jm[0][2] * Jm[2][0]) / det;
+                Ji[1][2] = (Jm[0][2] * Jm[1][0] - Jm[0][0] * Jm[1][2]) / det;
+                Ji[2][0] = (Jm[1][0] * Jm[2][1] - Jm[1][1] * Jm[2][0]) / det;
+                Ji[2][1] = (Jm[0][1] * Jm[2][0] - Jm[0][0] * Jm[2][1]) / det;
+                Ji[2][2] = (Jm[0][0] * Jm[1][1] - Jm[0][1] * Jm[1][0]) / det;
+                const double  jxw = det * b->gw[i] * b->gw[j] * b->gw[k];
+                const double *xq  = L->xq + ((size_t)c * n3 + q) * 3;
+                const double  a   = coefficient_a(xq) * jxw;
+                double       *C   = L->coef_q + ((size_t)c * n3 + q) * 6;
+                static const int pe[6] = {0, 1, 2, 0, 0, 1}, pf[6] = {0, 1, 2, 1, 2, 2};
+                for (int m = 0; m < 6; ++m) /* (J^-1 J^-T)[e][f] = sum_d Ji[e][d] Ji[f][d] */
+                  C[m] = a * (Ji[pe[m]][0] * Ji[pf[m]][0] + Ji[pe[m]][1] * Ji[pf[m]][1] + Ji[pe[m]][2] * Ji[pf[m]][2]);
+                L->jxw[(size_t)c * n3 + q] = jxw;
+              }
+      }
+    free(xn);
+  }
 }
 
 static orc_problem *create_impl(int p, const int roots[3], double origin, double h0, int n_refine, int degree,
-                                int n_cycles, int vfloat)
+                                int n_cycles, int vfloat, int geometry, int problem)
 {
+  g_problem = problem;
 #ifdef _OPENMP
   omp_set_num_threads(effective_threads());
 #endif
@@ -582,6 +764,8 @@ static orc_problem *create_impl(int p, const int roots[3], double origin, double
   P->roots[2]    = roots[2];
   P->origin      = origin;
   P->h0          = h0;
+  P->geometry    = geometry;
+  P->problem     = problem;
   P->n_levels    = n_refine + 1;
   P->degree      = degree;
   P->n_cycles    = n_cycles;
@@ -593,7 +777,11 @@ static orc_problem *create_impl(int p, const int roots[3], double origin, double
   basis_init_f((basis_f *)P->Bf, &P->basis);
   P->levels = (orc_level *)calloc(P->n_levels, sizeof(orc_level));
   for (int l = 0; l < P->n_levels; ++l)
-    level_init(&P->levels[l], p, P->roots, P->h0, l);
+    {
+      level_init(&P->levels[l], p, P->roots, P->h0, l);
+      if (geometry != ORC_GEOM_CARTESIAN || problem != ORC_PROBLEM_CUBE)
+        level_geometry(P, &P->levels[l]);
+    }
   P->solution = (double **)calloc(P->n_levels, sizeof(double *));
   P->rhs      = (double **)calloc(P->n_levels, sizeof(double *));
   P->residual = (double **)calloc(P->n_levels, sizeof(double *));
@@ -983,9 +1171,15 @@ double orc_l2_error(orc_problem *P, int level)
           for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i, ++q)
               {
-                const double JxW = B->w[i] * B->w[j] * B->w[k] * L->h * L->h * L->h;
-                const double d   = t0[q] - u_exact(x0 + L->h * P->basis.gq[i], y0 + L->h * P->basis.gq[j],
-                                                   z0 + L->h * P->basis.gq[k]);
+                double JxW = B->w[i] * B->w[j] * B->w[k] * L->h * L->h * L->h, d;
+                if (L->coef_q) /* mapped mesh: JxW and x_q from the mapping */
+                  {
+                    const double *xq = L->xq + ((size_t)c * n3 + q) * 3;
+                    JxW              = L->jxw[(size_t)c * n3 + q];
+                    d                = t0[q] - u_exact(xq[0], xq[1], xq[2]);
+                  }
+                else
+                  d = t0[q] - u_exact(x0 + L->h * P->basis.gq[i], y0 + L->h * P->basis.gq[j], z0 + L->h * P->basis.gq[k]);
                 err += d * d * JxW;
                 vol += JxW;
               }

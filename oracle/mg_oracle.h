@@ -41,6 +41,20 @@ orc_problem *orc_create(int p, int n_subdiv, int n_refine, int degree, int n_cyc
 /* "doubling" mesh family (poisson_cube/program.cc:509-529): box of sx x sy x sz cubic coarse cells
  * of size 1.9 with lower corner (-1,-1,-1), refined n_refine times */
 orc_problem *orc_create_box(int p, int sx, int sy, int sz, int n_refine, int degree, int n_cycles, int vfloat);
+/* Mapped meshes and variable coefficients (poisson_shell; laplace_operator.h:388-430, 493-522): the
+ * reference box of sx x sy x sz coarse cells of size h0 from (origin,)*3, mapped by `geometry`
+ * (isoparametric of degree p, as MappingQ(min(p,10)) multigrid_solver.h:139), problem = solution /
+ * rhs / coefficient set */
+#define ORC_GEOM_CARTESIAN 0
+#define ORC_GEOM_SHEARED 1
+#define ORC_GEOM_SHELL_SECTOR 2
+#define ORC_PROBLEM_CUBE 0
+#define ORC_PROBLEM_SHELL 1
+orc_problem *orc_create_mapped(int p, int sx, int sy, int sz, double origin, double h0, int n_refine, int degree,
+                               int n_cycles, int vfloat, int geometry, int problem);
+/* [n_cells][(p+1)^3][6] merged coefficient of the general branch (NULL on the affine branch) */
+const double *orc_coef_q(const orc_problem *P, int level);
+void          orc_set_affine_coef(orc_problem *P, int level, const double *coef6);
 void orc_cells_per_dim3(const orc_problem *P, int level, int out[3]);
 void orc_destroy(orc_problem *P);
 

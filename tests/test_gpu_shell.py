@@ -1,0 +1,120 @@
+"""poisson_shell slice on the GPU (BASELINE config 4): the quadrature-point operation with the full
+symmetric tensor -- one per mesh (affine cells, laplace_operator.h:473-486) or one per cell and
+quadrature point (variable coefficient, curved cells, :493-522) -- and the multigrid solver on it,
+against the oracle.  Tolerances as in test_gpu_parity.py; the 1e6 coefficient contrast of the shell
+problem enters the operator's scale, not the relative accuracy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+mg = pytest.importorskip("multigrid_amd")
+from oracle import Oracle  # noqa: E402
+from oracle_view import oracle_for  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mg.Context(0)
+    yield c
+    c.close()
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("geometry,problem", [("sheared", "cube"), ("shell_sector", "shell"), ("sheared", "shell")])
+@pytest.mark.parametrize("p,nr", [(2, 3), (4, 2), (5, 2), (8, 1)])
+def test_mapped_operator(ctx, geometry, problem, p, nr):
+    cube = mg.Cube(p, n_refine=nr, box=(1, 1, 1), origin=-0.9, h0=1.9, geometry=geometry, problem=problem)
+    orc = oracle_for(cube, p, 1, nr, geometry=geometry, problem=problem, origin=-0.9, h0=1.9)
+    for l in range(cube.n_levels):
+        for number, tol in ((mg.F64, 1e-12), (mg.F32, 2e-5)):
+            op = mg.LaplaceOperator.from_cube(ctx, cube, l, number)
+            x, b = cube.seeded_vector(l, 1), cube.seeded_vector(l, 2)
+            src, rhs, dst = ctx.vector(x.size, number, x), ctx.vector(x.size, number, b), ctx.vector(x.size, number)
+            x_in = x.astype(np.float32).astype(np.float64) if number == mg.F32 else x
+            b_in = b.astype(np.float32).astype(np.float64) if number == mg.F32 else b
+            op.vmult(dst, src)
+            assert rel(dst.download().astype(np.float64), orc.vmult(l, x_in)) < tol
+            op.vmult_residual(rhs, src, dst)
+            assert rel(dst.download().astype(np.float64), orc.vmult_residual(l, b_in, x_in)) < tol
+            if number == mg.F64:
+                op.compute_diagonal()
+                assert rel(op.get_matrix_diagonal_inverse().download(), orc.inv_diag(l)) < 1e-12
+            op.clear()
+    cube.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("geometry,problem", [("sheared", "cube"), ("shell_sector", "shell")])
+def test_mapped_multigrid_solver(ctx, geometry, problem):
+    p, nr = 4, 2
+    cube = mg.Cube(p, n_refine=nr, box=(1, 1, 1), origin=-0.9, h0=1.9, geometry=geometry, problem=problem)
+    orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1, geometry=geometry, problem=problem, origin=-0.9, h0=1.9)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    l = cube.max_level
+    for lev in range(cube.n_levels):
+        gi, oi = solver.smoother(lev).info(), orc.cheb_info(lev)
+        assert gi["degree"] == oi["degree"] and gi["cg_its"] == oi["cg_its"]
+        assert gi["lambda_max"] == pytest.approx(oi["lambda_max"], rel=1e-8)
+    x = cube.seeded_vector(l, 5)
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    solver.vmult(dst, src)
+    assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    rate, trace = solver.solve(True)
+    orate, otrace = orc.solve(True)
+    assert rate == pytest.approx(orate, rel=1e-6)
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-7)
+    its, red = solver.solve_cg()
+    oits, ored = orc.solve_cg()
+    assert its == oits
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-7)
+    solver.close()
+    cube.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("p", [2, 4, 7])
+def test_affine_full_tensor(ctx, p):
+    """affine cells with off-diagonal coefficient entries (laplace_operator.h:473-486): the tensor is
+    the operator descriptor's coef[6], the weight is applied per point"""
+    nr = 2
+    orc = Oracle(p, 1, nr)
+    l = nr
+    coef = np.array([1.3, 0.9, 1.1, 0.25, -0.15, 0.2]) * orc.cell_size(l)
+    orc.set_affine_coef(l, coef)
+    idx = np.ascontiguousarray(orc.idx27(l)).ravel()
+    plain = np.ascontiguousarray(orc.idx27_plain(l)).ravel()
+    cons = orc.constrained(l)
+    S, D, w = orc.shape_values().ravel(), orc.colloc_grad().ravel(), orc.qweights()
+    d = mg._lib.OperatorDesc()
+    d.degree, d.number, d.n_cells, d.n_dofs = p, mg.F64, orc.n_cells(l), orc.n_dofs(l)
+    d.idx27 = idx.ctypes.data_as(mg._lib.u32p)
+    d.idx27_plain = plain.ctypes.data_as(mg._lib.u32p)
+    d.constrained = cons.ctypes.data_as(mg._lib.u32p)
+    d.n_constrained = cons.size
+    for i, v in enumerate(coef):
+        d.coef[i] = v
+    d.shape_values = S.ctypes.data_as(mg._lib.f64p)
+    d.colloc_grad = D.ctypes.data_as(mg._lib.f64p)
+    d.qweights = w.ctypes.data_as(mg._lib.f64p)
+    op = mg.LaplaceOperator(ctx, d)
+    x = np.random.default_rng(3).uniform(-1, 1, orc.n_dofs(l))
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    op.vmult(dst, src)
+    assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+    # diagonal: (A e_i)_i of the oracle for a sample of DoFs (its stored diagonal predates the tensor)
+    op.compute_diagonal()
+    inv = op.get_matrix_diagonal_inverse().download()
+    free = np.setdiff1d(np.arange(orc.n_dofs(l)), cons)
+    for i in np.random.default_rng(5).choice(free, 40, replace=False):
+        e = np.zeros(orc.n_dofs(l))
+        e[i] = 1.0
+        assert inv[i] == pytest.approx(1.0 / orc.vmult(l, e)[i], rel=1e-12)
+    assert np.array_equal(inv[cons], np.ones(cons.size))
+    op.clear()
+    orc.close()
