@@ -59,6 +59,8 @@ const char *mgx_version(void);
 int mgx_context_create(mgx_context_t *ctx, int device);
 int mgx_context_destroy(mgx_context_t ctx);
 int mgx_sync(mgx_context_t ctx);
+/* free and total bytes of the context's device (hipMemGetInfo) */
+int mgx_device_memory_info(mgx_context_t ctx, size_t *free_bytes, size_t *total_bytes);
 /* raw HIP stream (hipStream_t) the context enqueues on, for callers that time with HIP events */
 void *mgx_context_stream(mgx_context_t ctx);
 

@@ -65,6 +65,13 @@ namespace multigrid
     Context &operator=(const Context &) = delete;
     mgx_context_t handle() const { return h_; }
     void          sync() const { check(mgx_sync(h_)); }
+    // device memory in use on the context's GPU (all processes), in MB
+    double device_memory_used_mb() const
+    {
+      size_t free_b = 0, total_b = 0;
+      check(mgx_device_memory_info(h_, &free_b, &total_b));
+      return (double)(total_b - free_b) / (1024. * 1024.);
+    }
 
   private:
     mgx_context_t h_ = nullptr;

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mgx_context_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "mgx_context_destroy": (C.c_int, [vp]),
     "mgx_sync": (C.c_int, [vp]),
+    "mgx_device_memory_info": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mgx_context_stream": (vp, [vp]),
     "mgx_context_set_comm": (C.c_int, [vp, C.POINTER(CommDesc)]),
     "mgx_rccl_unique_id": (C.c_int, [vp]),

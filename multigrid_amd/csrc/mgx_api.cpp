@@ -644,6 +644,14 @@ int mgx_sync(mgx_context_t ctx)
   return MGX_OK;
 }
 
+int mgx_device_memory_info(mgx_context_t ctx, size_t *free_bytes, size_t *total_bytes)
+{
+  MGX_REQUIRE(ctx && free_bytes && total_bytes, "mgx_device_memory_info: null argument");
+  MGX_HIP(hipSetDevice(ctx->device));
+  MGX_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return MGX_OK;
+}
+
 void *mgx_context_stream(mgx_context_t ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int mgx_context_set_comm(mgx_context_t ctx, const mgx_comm_desc *comm)

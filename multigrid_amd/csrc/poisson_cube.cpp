@@ -7,8 +7,10 @@
 // same output lines and final table (:360-362, :382-388, :580-606) -- written against the
 // classes of multigrid_shim.hpp instead of deal.II.
 //
-// Difference: the V-cycle number type is a run-time choice (8th argument: f32 = reference default,
-// f64).  The analysed solve prints the reference's four lines per level (error start / residual
+// Differences: the V-cycle number type is a run-time choice (8th argument: f32 = reference default,
+// f64); the per-level wall times (print_wall_times) cover the analysed solve only -- the level
+// timers synchronise the stream, which the seven timed solves must not pay for (the reference's
+// CPU timers run through all eight).  The analysed solve prints the reference's four lines per level (error start / residual
 // start / residual end / error end, multigrid_solver.h:420-473).
 #include "../../include/multigrid_shim.hpp"
 
@@ -44,6 +46,20 @@ namespace
     MultigridSolver<3, degree, vcycle_number, double> solver(ctx, disc, n_pre, n_post, n_mg_cycles);
     ctx.sync();
     std::cout << "Time setup solver (rhs, smoother, device upload): " << seconds_since(t_setup) << std::endl;
+    {
+      // program.cc:273-279 (one process: min = avg = max); the device footprint next to it
+      double rss_mb = 0;
+      if (FILE *f = std::fopen("/proc/self/status", "r"))
+        {
+          char line[256];
+          while (std::fgets(line, sizeof(line), f))
+            if (std::strncmp(line, "VmRSS:", 6) == 0)
+              rss_mb = std::atof(line + 6) / 1024.;
+          std::fclose(f);
+        }
+      std::cout << "Memory stats [MB]: " << rss_mb << " [p0] " << rss_mb << " " << rss_mb << " [p0]   device: "
+                << ctx.device_memory_used_mb() << std::endl;
+    }
     double best_time = 1e10, tot_time = 0;
     for (unsigned int i = 0; i < 7; ++i) // program.cc:285-293
       {

@@ -1,0 +1,27 @@
+"""Variable-coefficient / curved-geometry matvec (poisson_shell slice, BASELINE config 4): DoFs/s and the
+fraction of the HBM roofline at 16 + 48 ((p+1)/p)^3 B per DoF (109.75 B at p = 4)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multigrid_amd as mg
+p = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+nr = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+t = time.time()
+ctx = mg.Context(0)
+cube = mg.Cube(p, n_refine=nr, box=(1, 1, 1), origin=-0.9, h0=1.9, geometry="shell_sector", problem="shell")
+l = cube.max_level
+n = cube.n_dofs(l)
+op = mg.LaplaceOperator.from_cube(ctx, cube, l)
+print("setup %.1f s, %d cells, %d DoFs" % (time.time() - t, cube.n_cells(l), n))
+x, y = ctx.vector(n, data=cube.seeded_vector(l, 1)), ctx.vector(n)
+for _ in range(3):
+    op.vmult(y, x)
+ctx.sync()
+t = time.perf_counter()
+reps = 20
+for _ in range(reps):
+    op.vmult(y, x)
+ctx.sync()
+dt = (time.perf_counter() - t) / reps
+bpd = 16 + 48 * ((p + 1) / p) ** 3
+print("shell sector p=%d: vmult %.3f ms, %.3e DoFs/s, %.1f B/DoF algorithmic -> %.2f TB/s = %.3f of 8 TB/s"
+      % (p, dt * 1e3, n / dt, bpd, bpd * n / dt / 1e12, bpd * n / dt / 8e12))
