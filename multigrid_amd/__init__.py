@@ -370,8 +370,6 @@ class Cube:
 
     def coef_q(self, l):
         """[n_cells, 6, (p+1)^3] merged coefficient of a mapped level (None on the Cartesian cube)"""
-        self.lib.mgx_cube_coef_q.restype = C.POINTER(C.c_double)
-        self.lib.mgx_cube_coef_q.argtypes = [C.c_void_p, C.c_int]
         ptr = self.lib.mgx_cube_coef_q(self.h, l)
         if not ptr:
             return None

@@ -176,6 +176,7 @@ SIGNATURES = {
     "mgx_cube_gll": (f64p, [vp]),
     "mgx_cube_prolong_1d": (f64p, [vp]),
     "mgx_cube_rhs": (f64p, [vp, C.c_int]),
+    "mgx_cube_coef_q": (f64p, [vp, C.c_int]),
     "mgx_cube_bc_count": (C.c_uint32, [vp, C.c_int]),
     "mgx_cube_bc_index": (u32p, [vp, C.c_int]),
     "mgx_cube_bc_value": (f64p, [vp, C.c_int]),
