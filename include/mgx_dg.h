@@ -1,0 +1,97 @@
+/*
+ * mgx_dg.h -- C ABI of the MI355X-native DG (symmetric interior penalty) Laplace operator with the
+ * merged Chebyshev update (libmgx.so); BASELINE config 5, first slice: one GPU, affine mesh.
+ *
+ * Reference interface replaced (paths relative to the reference root):
+ *     multigrid::LaplaceOperatorCompactCombine<3,p,Number,type>  common/laplace_operator_dg.h:350-2024
+ *     multigrid::JacobiTransformed<3,p,Number,type>              common/laplace_operator_dg.h:2028-2256
+ * as driven by matvec_dg_cheby/program.cc:40-200.  Conventions as in mgx.h (status codes, device
+ * pointers, the context's stream, no CPU fallback).
+ *
+ * Vector layout: the reference's DG numbering -- (p+1)^3 contiguous coefficients per cell, x
+ * fastest (laplace_operator_dg.h:1141-1146 reads a cell as one contiguous block) -- cells in the
+ * order of the neighbour table handed to mgx_dg_operator_create.
+ */
+#ifndef MGX_DG_H
+#define MGX_DG_H
+
+#include "mgx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* `type` template parameter of LaplaceOperatorCompactCombine (laplace_operator_dg.h:343-348) */
+#define MGX_DG_HERMITE 0       /* FE_DGQHermite: neighbour access of two node layers only */
+#define MGX_DG_GAUSS_LOBATTO 1 /* FE_DGQ */
+#define MGX_DG_GAUSS 2         /* FE_DGQArbitraryNodes(QGauss): collocation, no basis change */
+
+#define MGX_DG_BOUNDARY (-1)   /* neighbour entry of a (homogeneous Dirichlet) boundary face */
+
+typedef struct mgx_dg_operator_s *mgx_dg_operator_t;
+
+typedef struct
+{
+  int      degree;             /* 1 .. MGX_MAX_DEGREE */
+  int      basis;              /* MGX_DG_* */
+  int      number;             /* MGX_F32 (matvec_dg_cheby/program.cc:88) or MGX_F64 */
+  uint32_t n_cells;
+  /* [n_cells][6] cell behind face 2d+s (direction d, lower s = 0 / upper s = 1 side) or
+   * MGX_DG_BOUNDARY; replaces start_indices_on_neighbor / dirichlet_faces
+   * (laplace_operator_dg.h:453-459, 480-560).  Host memory, copied. */
+  const int32_t *neighbours;
+  /* the one cell Jacobian dx/dxi, row-major [real][reference]; the reference asserts a single
+   * Jacobian for the whole mesh as well (laplace_operator_dg.h:749-750) */
+  double jacobian[9];
+} mgx_dg_operator_desc;
+
+/* LaplaceOperatorCompactCombine::reinit (:361-771) + JacobiTransformed::JacobiTransformed
+ * (:2031-2038, local_compute_diagonals :2099-2233): 1D basis data, penalty and normal factors,
+ * eigenvector basis and the inverse transformed diagonals (one set per combination of Dirichlet
+ * faces -- at most 64 -- instead of one per cell). */
+int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, mgx_dg_operator_t *op);
+int mgx_dg_operator_destroy(mgx_dg_operator_t op);
+
+/* LaplaceOperatorCompactCombine::m (:796-800) */
+uint64_t mgx_dg_operator_n_dofs(mgx_dg_operator_t op);
+
+/* LaplaceOperatorCompactCombine::vmult (:802-806, action 0).  dst must not alias src. */
+int mgx_dg_vmult(mgx_dg_operator_t op, void *dst, const void *src);
+
+/* vmult_with_merged_ops<4> (:962-966, epilogue :1812-1818): dst = rhs - A src */
+int mgx_dg_vmult_residual(mgx_dg_operator_t op, void *dst, const void *rhs, const void *src);
+
+/* JacobiTransformed::vmult (:2046-2084): dst = T D^-1 T^T src per cell.  dst may alias src. */
+int mgx_dg_jacobi_vmult(mgx_dg_operator_t op, void *dst, const void *src);
+
+/* LaplaceOperatorCompactCombine::vmult_with_chebyshev_update (:910-955, epilogue :1839-1860).
+ *   iteration_index == 0:  solution = factor2 P^-1 rhs
+ *   iteration_index == 1:  new = factor2 P^-1 (rhs - A solution) + (1 + factor1) solution
+ *   iteration_index >= 2:  new = ... - factor1 solution_old
+ * For iteration_index >= 1 `new` is written over solution_old; the reference then swaps the two
+ * vectors (:931) -- with raw pointers that swap is the caller's (the Python binding and
+ * tools/matvec_dg_cheby.py do it).  solution and solution_old must not alias. */
+int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, unsigned iteration_index,
+                                       double factor1, double factor2, void *solution, void *solution_old);
+
+/* 1D data of the operator for inspection: hermite_derivative_on_face (:408-409), the penalty
+ * parameters get_penalty(face 2d) (:789-793) and the 1D generalised eigenvalues (:207-208).
+ * Any pointer may be NULL. */
+int mgx_dg_operator_info(mgx_dg_operator_t op, double *hermite_derivative_on_face, double penalty[3],
+                         double eigenvalues_1d[MGX_MAX_DEGREE + 1]);
+
+/* ---- mesh helpers (stand in for GridGenerator + DoFHandler of the harness) ---- */
+
+/* matvec_dg_cheby/program.cc:55-77: cells per direction and the cell Jacobian of the sheared box
+ * after n_cell_steps refinement steps */
+int mgx_dg_cheby_mesh(int n_cell_steps, int cells[3], double jacobian[9]);
+
+/* neighbour table of a box of cells[0] x cells[1] x cells[2] cells, all outer faces Dirichlet.
+ * ordering 0: lexicographic, x fastest; 1: z-order (space-filling curve, as p4est gives the
+ * reference).  cell_ijk (optional) receives the (i, j, k) position of every cell. */
+int mgx_dg_box_neighbours(const int cells[3], int ordering, int32_t *neighbours, int32_t *cell_ijk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -5,6 +5,8 @@ for the poisson_cube path on top of the C ABI in include/mgx.h:
 
     LaplaceOperator  <-> multigrid::LaplaceOperator   common/laplace_operator.h:56-164
     MultigridSolver  <-> multigrid::MultigridSolver   common/multigrid_solver.h:96-782
+    DGLaplaceOperator <-> multigrid::LaplaceOperatorCompactCombine + JacobiTransformed
+                                                       common/laplace_operator_dg.h:350-2256
     Cube             <-> the deal.II mesh / DoFHandler / MatrixFree data of poisson_cube/program.cc
 
 All numerical work runs in hand-written HIP kernels inside libmgx.so; nothing here computes.
@@ -18,7 +20,8 @@ from . import _lib
 from ._lib import F32, F64, INVALID_INDEX, MgxError, check
 
 __all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
-           "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError"]
+           "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError", "DGLaplaceOperator", "dg_cheby_mesh",
+           "dg_box_neighbours", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS"]
 
 
 def process_grid(size):
@@ -676,4 +679,82 @@ class MultigridSolver:
     def close(self):
         if getattr(self, "h", None):
             self.lib.mgx_cube_solver_destroy(C.byref(self.s))
+            self.h = None
+
+
+# ---------------------------------------------------------------------------------------------
+# DG path (include/mgx_dg.h)
+DG_HERMITE, DG_GAUSS_LOBATTO, DG_GAUSS = 0, 1, 2
+
+
+def dg_cheby_mesh(n_cell_steps):
+    """cells per direction and cell Jacobian of matvec_dg_cheby/program.cc:55-77"""
+    cells, jac = (C.c_int * 3)(), (C.c_double * 9)()
+    check(_lib.load().mgx_dg_cheby_mesh(n_cell_steps, C.byref(cells), C.byref(jac)))
+    return tuple(cells), np.array(jac).reshape(3, 3)
+
+
+def dg_box_neighbours(cells, ordering="z"):
+    """(neighbour table [n, 6], cell positions [n, 3]) of a box of cells, all outer faces Dirichlet"""
+    c = (C.c_int * 3)(*cells)
+    n = int(np.prod(cells))
+    nb = np.empty((n, 6), dtype=np.int32)
+    ijk = np.empty((n, 3), dtype=np.int32)
+    i32p = C.POINTER(C.c_int32)
+    check(_lib.load().mgx_dg_box_neighbours(C.byref(c), 1 if ordering == "z" else 0, nb.ctypes.data_as(i32p),
+                                            ijk.ctypes.data_as(i32p)))
+    return nb, ijk
+
+
+class DGLaplaceOperator:
+    """multigrid::LaplaceOperatorCompactCombine<3,p,Number,type> with its JacobiTransformed
+    preconditioner (common/laplace_operator_dg.h:350-2256) on an affine mesh."""
+
+    def __init__(self, ctx, degree, basis, neighbours, jacobian, number=F32):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.degree, self.basis, self.number = degree, basis, number
+        nb = np.ascontiguousarray(neighbours, dtype=np.int32).reshape(-1, 6)
+        d = _lib.DGOperatorDesc()
+        d.degree, d.basis, d.number, d.n_cells = degree, basis, number, nb.shape[0]
+        d.neighbours = nb.ctypes.data_as(C.POINTER(C.c_int32))
+        d.jacobian = (C.c_double * 9)(*np.asarray(jacobian, dtype=float).ravel())
+        h = C.c_void_p()
+        check(self.lib.mgx_dg_operator_create(ctx.h, C.byref(d), C.byref(h)))
+        self.h = h
+
+    def m(self):
+        return int(self.lib.mgx_dg_operator_n_dofs(self.h))
+
+    def initialize_dof_vector(self, data=None):
+        return self.ctx.vector(self.m(), self.number, data)
+
+    def vmult(self, dst, src):
+        check(self.lib.mgx_dg_vmult(self.h, dst.ptr, src.ptr))
+
+    def vmult_residual(self, dst, rhs, src):
+        check(self.lib.mgx_dg_vmult_residual(self.h, dst.ptr, rhs.ptr, src.ptr))
+
+    def jacobi_vmult(self, dst, src):
+        check(self.lib.mgx_dg_jacobi_vmult(self.h, dst.ptr, src.ptr))
+
+    def vmult_with_chebyshev_update(self, rhs, iteration_index, factor1, factor2, solution, solution_old):
+        """as the reference (laplace_operator_dg.h:910-955): on return `solution` holds the new
+        iterate and `solution_old` the previous one (the two vectors trade their storage)"""
+        check(self.lib.mgx_dg_vmult_with_chebyshev_update(self.h, rhs.ptr, iteration_index, factor1, factor2,
+                                                          solution.ptr, solution_old.ptr))
+        if iteration_index > 0:
+            solution.ptr, solution_old.ptr = solution_old.ptr, solution.ptr
+            solution.owned, solution_old.owned = solution_old.owned, solution.owned
+
+    def info(self):
+        hd = C.c_double()
+        pen = (C.c_double * 3)()
+        ev = (C.c_double * 10)()
+        check(self.lib.mgx_dg_operator_info(self.h, C.byref(hd), pen, ev))
+        return dict(hermite_derivative_on_face=hd.value, penalty=np.array(pen),
+                    eigenvalues_1d=np.array(ev)[:self.degree + 1])
+
+    def clear(self):
+        if getattr(self, "h", None):
+            self.lib.mgx_dg_operator_destroy(self.h)
             self.h = None

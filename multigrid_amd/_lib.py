@@ -1,4 +1,4 @@
-"""ctypes declarations for libmgx.so (include/mgx.h, include/mgx_cube.h).
+"""ctypes declarations for libmgx.so (include/mgx.h, include/mgx_cube.h, include/mgx_dg.h).
 
 The library is built in-tree by `__graft_entry__.build()` / `make -C multigrid_amd/csrc`.
 There is no CPU fallback: a missing library raises, and so does a missing HIP device at
@@ -49,6 +49,11 @@ class OperatorDesc(C.Structure):
                 ("coef", C.c_double * 6), ("shape_values", f64p), ("colloc_grad", f64p), ("qweights", f64p),
                 ("brick_colour", C.POINTER(C.c_uint8)), ("global_index", u32p),
                 ("exchange", C.POINTER(ExchangeDesc)), ("coef_q", f64p)]
+
+
+class DGOperatorDesc(C.Structure):
+    _fields_ = [("degree", C.c_int), ("basis", C.c_int), ("number", C.c_int), ("n_cells", C.c_uint32),
+                ("neighbours", C.POINTER(C.c_int32)), ("jacobian", C.c_double * 9)]
 
 
 class SmootherInfo(C.Structure):
@@ -185,6 +190,17 @@ SIGNATURES = {
     "mgx_cube_seeded_vector": (C.c_int, [vp, C.c_int, C.c_uint64, f64p]),
     "mgx_cube_solver_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(CubeSolver)]),
     "mgx_cube_solver_destroy": (C.c_int, [C.POINTER(CubeSolver)]),
+    # include/mgx_dg.h
+    "mgx_dg_operator_create": (C.c_int, [vp, C.POINTER(DGOperatorDesc), C.POINTER(vp)]),
+    "mgx_dg_operator_destroy": (C.c_int, [vp]),
+    "mgx_dg_operator_n_dofs": (C.c_uint64, [vp]),
+    "mgx_dg_vmult": (C.c_int, [vp, vp, vp]),
+    "mgx_dg_vmult_residual": (C.c_int, [vp, vp, vp, vp]),
+    "mgx_dg_jacobi_vmult": (C.c_int, [vp, vp, vp]),
+    "mgx_dg_vmult_with_chebyshev_update": (C.c_int, [vp, vp, C.c_uint, C.c_double, C.c_double, vp, vp]),
+    "mgx_dg_operator_info": (C.c_int, [vp, f64p, f64p, f64p]),
+    "mgx_dg_cheby_mesh": (C.c_int, [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_double * 9)]),
+    "mgx_dg_box_neighbours": (C.c_int, [C.POINTER(C.c_int * 3), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

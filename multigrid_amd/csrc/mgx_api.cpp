@@ -81,6 +81,8 @@ namespace
   while (0)
 } // namespace
 
+int mgx::report_error(int code, const char *message) { return fail(code, message ? message : ""); }
+
 mgx::Tunables mgx::Tunables::from_environment()
 {
   Tunables t;

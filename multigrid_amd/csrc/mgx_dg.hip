@@ -1,0 +1,1401 @@
+// mgx_dg.hip -- DG (symmetric interior penalty) Laplace operator on an affine mesh with the merged
+// Chebyshev update: C ABI of include/mgx_dg.h, host-side 1D setup and the gfx950 cell kernel.
+//
+// Reference behaviour (not code): common/laplace_operator_dg.h -- LaplaceOperatorCompactCombine
+// :350-2024 (cell-based loop operation_on_cells :1110-1861), JacobiTransformed :2028-2256,
+// LocalBasisTransformer :92-350; 1D line kernel with face values common/matrix_vector_kernel.h
+// :30-216.  The bilinear form is the one of common/laplace_operator_dg_face.h:66-160.
+//
+// Design (MI355X): a workgroup of 256 threads takes CPW = 256 / (p+1)^2 consecutive cells; the
+// (p+1)^2 threads of a cell each own one line of the cell per sweep direction (registers) and one
+// quadrature point of each of the 6 faces.  Per cell the LDS holds the values U in the Gauss
+// points, two gradient components, and four (p+1)^2 arrays per face (own trace, own normal
+// derivative, neighbour trace, neighbour normal derivative), which the face phase turns in place
+// into the two arrays the integration needs.  The traces of a line's two end faces fall out of
+// the sweep that has the line in registers (the `do_dg` idea of matrix_vector_kernel.h:114-141).
+// Neighbour data is read straight from the source vector: two node layers per face for the
+// Hermite-like basis (laplace_operator_dg.h:1359-1457), a contracted full cell otherwise.  The
+// inverse diagonal of the block-Jacobi preconditioner depends only on which faces of a cell are
+// Dirichlet faces: a table of at most 64 x (p+1)^3 values replaces the reference's per-cell
+// stream, so the fused Chebyshev step moves 4 vector accesses per DoF (source, right-hand side,
+// old iterate, new iterate) where the reference's model counts 5 (matvec_dg_cheby/program.cc:178).
+#include "mgx_internal.hpp"
+
+#include "../../include/mgx_dg.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace
+{
+  using mgx::kMaxN;
+
+  // ------------------------------------------------------------------------------------------
+  // device data
+  template <typename T>
+  struct DGConst
+  {
+    T S[kMaxN * kMaxN];  // S[q*n+i]   element basis -> values in the Gauss points
+    T D[kMaxN * kMaxN];  // D[q*n+r]   derivative of the Gauss-point Lagrange basis in the Gauss points
+    T E[kMaxN * kMaxN];  // E[i*n+e]   eigenvector e of (Laplace + penalty, mass) in the element basis
+    T w[kMaxN];          // Gauss weights on [0,1]
+    T b[2][kMaxN], g[2][kMaxN];   // Gauss-point Lagrange basis at x = 0 / 1: value, derivative
+    T fb[2][kMaxN], fg[2][kMaxN]; // element basis at x = 0 / 1: value, derivative
+    T K[6];              // det J * J^-1 J^-T: xx yy zz xy xz yz
+    T cn[3][4];          // cn[d][a] = n_d . grad xi_a, n_d the unit normal towards +xi_d
+    T fw[4];             // face JxW without the quadrature weight, per direction
+    T sigma[4];          // penalty (p+1)^2 |n_d . grad xi_d|
+    T hderiv;            // derivative of the first Hermite-like function at x = 0
+  };
+
+  template <typename T>
+  struct DGArgs
+  {
+    const T          *src;
+    const T          *rhs;
+    T                *dst;
+    const int32_t    *neigh;
+    const DGConst<T> *c;
+    const T          *inv_diag; // [64][(p+1)^3]
+    uint32_t          n_cells;
+    T                 f1, f2;
+    int               iteration_index;
+  };
+
+  enum Action
+  {
+    kVmult     = 0,
+    kChebyshev = 3, // numbering of laplace_operator_dg.h:957-962
+    kResidual  = 4,
+    kJacobi    = 5  // P^-1 only (scaled by f2)
+  };
+
+  template <int P, typename T>
+  struct DGCfg
+  {
+    static constexpr int N    = P + 1;
+    static constexpr int NN2  = N * N;
+    static constexpr int N3   = N * N * N;
+    static constexpr int PX   = (N % 2 == 0) ? N + 1 : N; // odd row pitch: conflict-free x-lines
+    static constexpr int VOL  = N * N * PX;
+    static constexpr int FS   = N * PX;
+    static constexpr int CELL = 3 * VOL + 24 * FS;
+    static constexpr int CPW_T = 256 / NN2;
+    static constexpr int CPW_L = 65536 / (CELL * (int)sizeof(T));
+    static constexpr int CPW   = CPW_T < CPW_L ? CPW_T : CPW_L;
+    static constexpr int THREADS = ((CPW * NN2 + 63) / 64) * 64;
+    static_assert(CPW >= 1, "cell does not fit the LDS");
+  };
+
+  template <int N, typename T>
+  __device__ __forceinline__ void ld_line(const T *a, int base, int stride, T (&r)[N])
+  {
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      r[q] = a[base + q * stride];
+  }
+
+  template <int N, typename T>
+  __device__ __forceinline__ void st_line(T *a, int base, int stride, const T (&r)[N])
+  {
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      a[base + q * stride] = r[q];
+  }
+
+  // out[q] = sum_i M[q*N+i] in[i]   (M wave-uniform: scalar loads)
+  template <int N, typename T>
+  __device__ __forceinline__ void mul(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
+  {
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      {
+        T s = M[q * N] * in[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+          s += M[q * N + i] * in[i];
+        out[q] = s;
+      }
+  }
+
+  // out[i] = sum_q M[q*N+i] in[q]
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_t(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
+  {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      {
+        T s = M[i] * in[0];
+#pragma unroll
+        for (int q = 1; q < N; ++q)
+          s += M[q * N + i] * in[q];
+        out[i] = s;
+      }
+  }
+
+  template <int N, typename T>
+  __device__ __forceinline__ T dot_line(const T *__restrict__ v, const T (&in)[N])
+  {
+    T s = v[0] * in[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i)
+      s += v[i] * in[i];
+    return s;
+  }
+
+  template <int N, typename T>
+  __device__ __forceinline__ void copy_line(const T (&in)[N], T (&out)[N])
+  {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      out[i] = in[i];
+  }
+
+  // block-Jacobi in the eigenvector basis on the x-lines held in registers:  r <- T D^-1 T^T r
+  // (JacobiTransformed::do_local_operation, laplace_operator_dg.h:2086-2097).  U is scratch.
+  template <int P, typename T>
+  __device__ __forceinline__ void jacobi_local(const DGConst<T> *__restrict__ c, const T *__restrict__ inv_diag, T *U,
+                                               bool active, int a, int b, T (&r)[P + 1])
+  {
+    using C         = DGCfg<P, T>;
+    constexpr int N = C::N, PX = C::PX;
+    T             q[N];
+    if (active)
+      {
+        mul_t<N>(c->E, r, q); // out[e] = sum_i E[i][e] r[i]
+        st_line<N>(U, (b * N + a) * PX, 1, q);
+      }
+    __syncthreads();
+    if (active)
+      {
+        ld_line<N>(U, b * N * PX + a, PX, r);
+        mul_t<N>(c->E, r, q);
+        st_line<N>(U, b * N * PX + a, PX, q);
+      }
+    __syncthreads();
+    if (active)
+      {
+        ld_line<N>(U, b * PX + a, N * PX, r);
+        mul_t<N>(c->E, r, q);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          q[k] *= inv_diag[(k * N + b) * N + a];
+        mul<N>(c->E, q, r); // out[i] = sum_e E[i][e] q[e]
+        st_line<N>(U, b * PX + a, N * PX, r);
+      }
+    __syncthreads();
+    if (active)
+      {
+        ld_line<N>(U, b * N * PX + a, PX, q);
+        mul<N>(c->E, q, r);
+        st_line<N>(U, b * N * PX + a, PX, r);
+      }
+    __syncthreads();
+    if (active)
+      {
+        ld_line<N>(U, (b * N + a) * PX, 1, q);
+        mul<N>(c->E, q, r);
+      }
+  }
+
+  template <int P, typename T, int TYPE, int ACTION>
+  __global__ void __launch_bounds__((DGCfg<P, T>::THREADS)) dg_cell_kernel(const DGArgs<T> A)
+  {
+    using C         = DGCfg<P, T>;
+    constexpr int N = C::N, NN2 = C::NN2, N3 = C::N3, PX = C::PX, VOL = C::VOL, FS = C::FS;
+    __shared__ T  lds[C::CPW * C::CELL];
+
+    const DGConst<T> *__restrict__ c = A.c;
+    const int  tid    = threadIdx.x;
+    const int  cw     = tid / NN2;
+    const int  t      = tid - cw * NN2;
+    const int  a      = t % N, b = t / N; // line owner (a, b) = face point (a, b)
+    const bool active = cw < C::CPW;
+    uint32_t   cell   = blockIdx.x * C::CPW + (active ? cw : 0);
+    const bool store  = active && cell < A.n_cells;
+    if (cell >= A.n_cells)
+      cell = A.n_cells - 1;
+
+    T *U  = lds + (active ? cw : 0) * C::CELL;
+    T *GY = U + VOL, *GZ = U + 2 * VOL;
+    T *F  = U + 3 * VOL; // [4][6][FS]: own value / own normal derivative / neighbour value / neighbour normal derivative
+    auto Fo = [&](int f) { return F + f * FS; };
+    auto Fn = [&](int f) { return F + (6 + f) * FS; };
+    auto Fe = [&](int f) { return F + (12 + f) * FS; };
+    auto Fd = [&](int f) { return F + (18 + f) * FS; };
+    const int fidx = b * PX + a;
+
+    const T *__restrict__ src = A.src;
+    const size_t cbase = (size_t)cell * N3;
+    T            xs[N]; // the source x-line: needed again by the Chebyshev update
+    int          nb[6];
+    unsigned     cat = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+      {
+        nb[f] = A.neigh[(size_t)cell * 6 + f];
+        cat |= (nb[f] < 0 ? 1u : 0u) << f;
+      }
+
+    if constexpr (ACTION == kJacobi)
+      {
+        T r[N];
+        if (active)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r[i] = src[cbase + (b * N + a) * N + i];
+          }
+        jacobi_local<P, T>(c, A.inv_diag + (size_t)cat * N3, U, active, a, b, r);
+        if (store)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              A.dst[cbase + (b * N + a) * N + i] = A.f2 * r[i];
+          }
+        return;
+      }
+
+    // ---- 1. source x-line -> Gauss values along x; raw neighbour traces
+    if (active)
+      {
+        T u[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          xs[i] = src[cbase + (b * N + a) * N + i];
+        if constexpr (TYPE != MGX_DG_GAUSS)
+          mul<N>(c->S, xs, u);
+        else
+          copy_line<N>(xs, u);
+        st_line<N>(U, (b * N + a) * PX, 1, u);
+
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+          {
+            const int d = f / 2, s = f % 2;
+            // strides of the normal direction and the two tangential ones (ascending) in a cell
+            const int sd = d == 0 ? 1 : (d == 1 ? N : N * N);
+            const int s1 = d == 0 ? N : 1;
+            const int s2 = d == 2 ? N : N * N;
+            T         ev = 0, ed = 0;
+            if (nb[f] >= 0)
+              {
+                const T *__restrict__ xn = src + (size_t)nb[f] * N3 + a * s1 + b * s2;
+                if constexpr (TYPE == MGX_DG_HERMITE)
+                  {
+                    // the neighbour's face is its upper one for our lower face and vice versa
+                    const T v0 = xn[(s == 0 ? N - 1 : 0) * sd];
+                    const T v1 = xn[(s == 0 ? (N > 1 ? N - 2 : 0) : (N > 1 ? 1 : 0)) * sd];
+                    ev         = v0;
+                    ed         = s == 0 ? c->hderiv * (v1 - v0) : c->hderiv * (v0 - v1);
+                  }
+                else
+                  {
+                    T line[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                      line[i] = xn[i * sd];
+                    ev = dot_line<N>(c->fb[1 - s], line);
+                    ed = dot_line<N>(c->fg[1 - s], line);
+                  }
+              }
+            Fe(f)[fidx] = ev;
+            Fd(f)[fidx] = ed;
+          }
+      }
+    __syncthreads();
+
+    // ---- 2. Gauss values along y; neighbour traces: in-face basis change, first direction
+    if constexpr (TYPE != MGX_DG_GAUSS)
+      {
+        if (active)
+          {
+            T u[N], v[N];
+            ld_line<N>(U, b * N * PX + a, PX, u);
+            mul<N>(c->S, u, v);
+            st_line<N>(U, b * N * PX + a, PX, v);
+            for (int L = t; L < 12 * N; L += NN2)
+              {
+                T *arr = F + (12 + L / N) * FS + (L % N) * PX;
+                ld_line<N>(arr, 0, 1, u);
+                mul<N>(c->S, u, v);
+                st_line<N>(arr, 0, 1, v);
+              }
+          }
+        __syncthreads();
+      }
+
+    // ---- 3. z-lines: Gauss values along z, z-derivative, traces on the z faces; neighbour
+    //         traces second direction
+    if (active)
+      {
+        T u[N], v[N];
+        ld_line<N>(U, b * PX + a, N * PX, u);
+        if constexpr (TYPE != MGX_DG_GAUSS)
+          {
+            mul<N>(c->S, u, v);
+            st_line<N>(U, b * PX + a, N * PX, v);
+          }
+        else
+          copy_line<N>(u, v);
+        mul<N>(c->D, v, u);
+        st_line<N>(GZ, b * PX + a, N * PX, u);
+        Fo(4)[fidx] = dot_line<N>(c->b[0], v);
+        Fo(5)[fidx] = dot_line<N>(c->b[1], v);
+        Fn(4)[fidx] = dot_line<N>(c->g[0], v);
+        Fn(5)[fidx] = dot_line<N>(c->g[1], v);
+        if constexpr (TYPE != MGX_DG_GAUSS)
+          for (int L = t; L < 12 * N; L += NN2)
+            {
+              T *arr = F + (12 + L / N) * FS + (L % N);
+              ld_line<N>(arr, 0, PX, u);
+              mul<N>(c->S, u, v);
+              st_line<N>(arr, 0, PX, v);
+            }
+      }
+    __syncthreads();
+
+    // ---- 4. y-lines: y-derivative and traces on the y faces; x-lines: traces on the x faces
+    if (active)
+      {
+        T u[N], v[N];
+        ld_line<N>(U, b * N * PX + a, PX, u);
+        mul<N>(c->D, u, v);
+        st_line<N>(GY, b * N * PX + a, PX, v);
+        Fo(2)[fidx] = dot_line<N>(c->b[0], u);
+        Fo(3)[fidx] = dot_line<N>(c->b[1], u);
+        Fn(2)[fidx] = dot_line<N>(c->g[0], u);
+        Fn(3)[fidx] = dot_line<N>(c->g[1], u);
+        ld_line<N>(U, (b * N + a) * PX, 1, u);
+        Fo(0)[fidx] = dot_line<N>(c->b[0], u);
+        Fo(1)[fidx] = dot_line<N>(c->b[1], u);
+        Fn(0)[fidx] = dot_line<N>(c->g[0], u);
+        Fn(1)[fidx] = dot_line<N>(c->g[1], u);
+      }
+    __syncthreads();
+
+    // ---- 5. faces.  In the quadrature point: sum and jump of the two traces, sum of the normal
+    // derivatives; a Dirichlet face mirrors the own values (laplace_operator_dg.h:1568-1577).
+    //   Fo <- T_own + T_ext,  Fn <- N_own + N_ext,  Fe <- w * (T_own - T_ext)
+    if (active)
+      {
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+          {
+            const int d  = f / 2;
+            const T   wq = c->w[a] * c->w[b] * c->fw[d];
+            const T   to = Fo(f)[fidx], no = Fn(f)[fidx];
+            const bool dirichlet = nb[f] < 0;
+            const T   te = dirichlet ? to : Fe(f)[fidx];
+            const T   ne = dirichlet ? no : Fd(f)[fidx];
+            Fo(f)[fidx]  = to + te;
+            Fn(f)[fidx]  = no + ne;
+            Fe(f)[fidx]  = wq * (dirichlet ? T(2) * to : to - te);
+          }
+      }
+    __syncthreads();
+    // lines of the first tangential direction: with s = +-1 the side of the face,
+    //   V = sigma wj - s/2 [ w (c_n sumN + c_t1 d_t1 sumT) + c_t1 d_t1^T wj ]      (Fn <- V)
+    // lines of the second one add  - s/2 c_t2 (w d_t2 sumT + d_t2^T wj)
+    if (active)
+      for (int L = t; L < 6 * N; L += NN2)
+        {
+          const int f = L / N, l = L % N, d = f / 2;
+          const int t1 = d == 0 ? 1 : 0;
+          const T   half_s = (f % 2) ? T(0.5) : T(-0.5);
+          const T   cnn = c->cn[d][d], ct = c->cn[d][t1], sg = c->sigma[d];
+          T         st[N], wj[N], sn[N], ds[N], dj[N];
+          ld_line<N>(Fo(f), l * PX, 1, st);
+          ld_line<N>(Fe(f), l * PX, 1, wj);
+          ld_line<N>(Fn(f), l * PX, 1, sn);
+          mul<N>(c->D, st, ds);
+          mul_t<N>(c->D, wj, dj);
+          const T wl = c->w[l] * c->fw[d];
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            sn[i] = sg * wj[i] - half_s * (c->w[i] * wl * (cnn * sn[i] + ct * ds[i]) + ct * dj[i]);
+          st_line<N>(Fn(f), l * PX, 1, sn);
+        }
+    __syncthreads();
+    if (active)
+      for (int L = t; L < 6 * N; L += NN2)
+        {
+          const int f = L / N, l = L % N, d = f / 2;
+          const int t2 = d == 2 ? 1 : 2;
+          const T   half_s = (f % 2) ? T(0.5) : T(-0.5);
+          const T   ct = c->cn[d][t2];
+          T         st[N], wj[N], v[N], ds[N], dj[N];
+          ld_line<N>(Fo(f), l, PX, st);
+          ld_line<N>(Fe(f), l, PX, wj);
+          ld_line<N>(Fn(f), l, PX, v);
+          mul<N>(c->D, st, ds);
+          mul_t<N>(c->D, wj, dj);
+          const T wl = c->w[l] * c->fw[d];
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            v[i] -= half_s * ct * (c->w[i] * wl * ds[i] + dj[i]);
+          st_line<N>(Fn(f), l, PX, v);
+        }
+    __syncthreads();
+
+    // face contributions to a line's integration: value test function V, normal derivative test
+    // function W = -s/2 c_n wj
+    auto add_faces = [&](int d, T(&o)[N]) {
+      const T v0 = Fn(2 * d)[fidx], v1 = Fn(2 * d + 1)[fidx];
+      const T w0 = T(0.5) * c->cn[d][d] * Fe(2 * d)[fidx];
+      const T w1 = T(-0.5) * c->cn[d][d] * Fe(2 * d + 1)[fidx];
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        o[i] += c->b[0][i] * v0 + c->b[1][i] * v1 + c->g[0][i] * w0 + c->g[1][i] * w1;
+    };
+
+    // ---- 6. x-lines: gradient, coefficient (laplace_operator_dg.h:1700-1716), integration along x
+    if (active)
+      {
+        T u[N], gx[N], gy[N], gz[N], o[N];
+        ld_line<N>(U, (b * N + a) * PX, 1, u);
+        mul<N>(c->D, u, gx);
+        ld_line<N>(GY, (b * N + a) * PX, 1, gy);
+        ld_line<N>(GZ, (b * N + a) * PX, 1, gz);
+        const T wab = c->w[a] * c->w[b];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          {
+            const T wq = wab * c->w[i];
+            const T fx = wq * (c->K[0] * gx[i] + c->K[3] * gy[i] + c->K[4] * gz[i]);
+            const T fy = wq * (c->K[3] * gx[i] + c->K[1] * gy[i] + c->K[5] * gz[i]);
+            const T fz = wq * (c->K[4] * gx[i] + c->K[5] * gy[i] + c->K[2] * gz[i]);
+            gx[i]      = fx;
+            gy[i]      = fy;
+            gz[i]      = fz;
+          }
+        st_line<N>(GY, (b * N + a) * PX, 1, gy);
+        st_line<N>(GZ, (b * N + a) * PX, 1, gz);
+        mul_t<N>(c->D, gx, o);
+        add_faces(0, o);
+        st_line<N>(U, (b * N + a) * PX, 1, o);
+      }
+    __syncthreads();
+    // ---- 7. y-lines
+    if (active)
+      {
+        T fy[N], o[N], u[N];
+        ld_line<N>(GY, b * N * PX + a, PX, fy);
+        ld_line<N>(U, b * N * PX + a, PX, u);
+        mul_t<N>(c->D, fy, o);
+        add_faces(1, o);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          o[i] += u[i];
+        st_line<N>(U, b * N * PX + a, PX, o);
+      }
+    __syncthreads();
+    // ---- 8. z-lines, then back to the element basis along z
+    if (active)
+      {
+        T fz[N], o[N], u[N];
+        ld_line<N>(GZ, b * PX + a, N * PX, fz);
+        ld_line<N>(U, b * PX + a, N * PX, u);
+        mul_t<N>(c->D, fz, o);
+        add_faces(2, o);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          o[i] += u[i];
+        if constexpr (TYPE != MGX_DG_GAUSS)
+          {
+            mul_t<N>(c->S, o, u);
+            st_line<N>(U, b * PX + a, N * PX, u);
+          }
+        else
+          st_line<N>(U, b * PX + a, N * PX, o);
+      }
+    __syncthreads();
+    if constexpr (TYPE != MGX_DG_GAUSS)
+      {
+        if (active)
+          {
+            T u[N], v[N];
+            ld_line<N>(U, b * N * PX + a, PX, u);
+            mul_t<N>(c->S, u, v);
+            st_line<N>(U, b * N * PX + a, PX, v);
+          }
+        __syncthreads();
+      }
+    // ---- 10. x-lines: result in the element basis, epilogue of the action
+    T y[N];
+    if (active)
+      {
+        T u[N];
+        ld_line<N>(U, (b * N + a) * PX, 1, u);
+        if constexpr (TYPE != MGX_DG_GAUSS)
+          mul_t<N>(c->S, u, y);
+        else
+          copy_line<N>(u, y);
+      }
+    const size_t lbase = cbase + (b * N + a) * N;
+    if constexpr (ACTION == kVmult)
+      {
+        if (store)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              A.dst[lbase + i] = y[i];
+          }
+      }
+    else if constexpr (ACTION == kResidual)
+      {
+        if (store)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              A.dst[lbase + i] = A.rhs[lbase + i] - y[i];
+          }
+      }
+    else
+      {
+        // laplace_operator_dg.h:1839-1860
+        if (active)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              y[i] = A.rhs[lbase + i] - y[i];
+          }
+        jacobi_local<P, T>(c, A.inv_diag + (size_t)cat * N3, U, active, a, b, y);
+        if (store)
+          {
+            const T f1p = T(1) + A.f1;
+            if (A.iteration_index == 1)
+              {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  A.dst[lbase + i] = A.f2 * y[i] + f1p * xs[i];
+              }
+            else
+              {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  A.dst[lbase + i] = A.f2 * y[i] + f1p * xs[i] - A.f1 * A.dst[lbase + i];
+              }
+          }
+      }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // host: 1D data
+  struct Poly1 // c * prod (x - r_k)
+  {
+    double              c = 1;
+    std::vector<double> r;
+    double val(double x) const
+    {
+      double v = c;
+      for (double rk : r)
+        v *= x - rk;
+      return v;
+    }
+    double der(double x) const
+    {
+      double s = 0;
+      for (size_t m = 0; m < r.size(); ++m)
+        {
+          double v = c;
+          for (size_t k = 0; k < r.size(); ++k)
+            if (k != m)
+              v *= x - r[k];
+          s += v;
+        }
+      return s;
+    }
+    void normalise(double x, double value) { c *= value / val(x); }
+  };
+
+  // eigenvalues (ascending) and eigenvectors (columns of V) of a symmetric matrix, cyclic Jacobi
+  void sym_eig(int n, std::vector<double> A, std::vector<double> &lambda, std::vector<double> &V)
+  {
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+      V[i * n + i] = 1;
+    for (int sweep = 0; sweep < 100; ++sweep)
+      {
+        double off = 0, dia = 0;
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j)
+            (i == j ? dia : off) += A[i * n + j] * A[i * n + j];
+        if (off <= 1e-30 * dia)
+          break;
+        for (int p = 0; p < n - 1; ++p)
+          for (int q = p + 1; q < n; ++q)
+            {
+              if (std::abs(A[p * n + q]) < 1e-300)
+                continue;
+              const double theta = (A[q * n + q] - A[p * n + p]) / (2 * A[p * n + q]);
+              const double tt    = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1));
+              const double cs = 1 / std::sqrt(tt * tt + 1), sn = tt * cs;
+              for (int k = 0; k < n; ++k)
+                {
+                  const double akp = A[k * n + p], akq = A[k * n + q];
+                  A[k * n + p] = cs * akp - sn * akq;
+                  A[k * n + q] = sn * akp + cs * akq;
+                }
+              for (int k = 0; k < n; ++k)
+                {
+                  const double apk = A[p * n + k], aqk = A[q * n + k];
+                  A[p * n + k] = cs * apk - sn * aqk;
+                  A[q * n + k] = sn * apk + cs * aqk;
+                }
+              for (int k = 0; k < n; ++k)
+                {
+                  const double vkp = V[k * n + p], vkq = V[k * n + q];
+                  V[k * n + p] = cs * vkp - sn * vkq;
+                  V[k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+      }
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int i, int j) { return A[i * n + i] < A[j * n + j]; });
+    lambda.resize(n);
+    std::vector<double> Vs((size_t)n * n);
+    for (int e = 0; e < n; ++e)
+      {
+        lambda[e] = A[order[e] * n + order[e]];
+        for (int k = 0; k < n; ++k)
+          Vs[k * n + e] = V[k * n + order[e]];
+      }
+    V.swap(Vs);
+  }
+
+  // roots of the Jacobi polynomial P^(al,al)_m mapped to [0,1]: eigenvalues of the Jacobi matrix
+  std::vector<double> jacobi_roots01(int m, double al)
+  {
+    std::vector<double> out;
+    if (m <= 0)
+      return out;
+    std::vector<double> J((size_t)m * m, 0.0), lam, V;
+    for (int k = 1; k < m; ++k)
+      {
+        const double s = 2 * k + 2 * al;
+        const double bk =
+          2.0 / s * std::sqrt(k * (k + al) * (k + al) * (k + 2 * al) / ((s - 1) * (s + 1)));
+        J[(k - 1) * m + k] = J[k * m + k - 1] = bk;
+      }
+    sym_eig(m, J, lam, V);
+    for (double x : lam)
+      out.push_back(0.5 * (x + 1));
+    return out;
+  }
+
+  void gauss01(int n, std::vector<double> &x, std::vector<double> &w)
+  {
+    x = jacobi_roots01(n, 0.0);
+    w.resize(n);
+    for (int i = 0; i < n; ++i)
+      {
+        // Newton polish on the Legendre polynomial, weight 1 / ((1 - t^2) P_n'(t)^2) on [0,1]
+        double t = 2 * x[i] - 1, dp = 0;
+        for (int it = 0; it < 3; ++it)
+          {
+            double p0 = 1, p1 = t;
+            for (int k = 2; k <= n; ++k)
+              {
+                const double pk = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+                p0 = p1;
+                p1 = pk;
+              }
+            if (n == 1)
+              {
+                p0 = 1;
+                p1 = t;
+              }
+            dp = n * (t * p1 - p0) / (t * t - 1);
+            if (it < 2)
+              t -= p1 / dp;
+          }
+        x[i] = 0.5 * (t + 1);
+        w[i] = 1.0 / ((1 - t * t) * dp * dp);
+      }
+  }
+
+  std::vector<Poly1> lagrange(const std::vector<double> &nodes)
+  {
+    std::vector<Poly1> out(nodes.size());
+    for (size_t i = 0; i < nodes.size(); ++i)
+      {
+        for (size_t k = 0; k < nodes.size(); ++k)
+          if (k != i)
+            out[i].r.push_back(nodes[k]);
+        out[i].normalise(nodes[i], 1.0);
+      }
+    return out;
+  }
+
+  // FE_DGQHermite's 1D functions (deal.II Polynomials::HermiteLikeInterpolation, external, restated
+  // from its documented construction): p_0 is the only function with a value at x = 0, p_0 and p_1
+  // the only ones with a derivative there (mirror image at x = 1), p_0 is L2-orthogonal to p_1, the
+  // inner functions are Lagrange polynomials in the roots of the Jacobi polynomial P^(4,4)_{p-3}
+  // times x^2 (1-x)^2, and all functions sum to one (hence p_1'(0) = -p_0'(0), which
+  // laplace_operator_dg.h:1190-1198 relies on).  Degree 1: hat functions, 2: Bernstein.
+  std::vector<Poly1> hermite_like(int p)
+  {
+    std::vector<Poly1> out(p + 1);
+    if (p == 0)
+      return out;
+    if (p == 1)
+      {
+        out[0].r = {1.0};
+        out[0].c = -1;
+        out[1].r = {0.0};
+        return out;
+      }
+    if (p == 2)
+      {
+        out[0].r = {1.0, 1.0};
+        out[1].r = {0.0, 1.0};
+        out[1].c = -2;
+        out[2].r = {0.0, 0.0};
+        return out;
+      }
+    const std::vector<double> inner = jacobi_roots01(p - 3, 4.0);
+    Poly1                     q0, q1;
+    q0.r = {1.0, 1.0};
+    q1.r = {0.0, 1.0, 1.0};
+    for (double x : inner)
+      {
+        q0.r.push_back(x);
+        q1.r.push_back(x);
+      }
+    std::vector<double> xq, wq;
+    gauss01(p + 2, xq, wq); // exact to degree 2p + 3 >= deg(x q0 q1) = 2p
+    double i0 = 0, i1 = 0;
+    for (size_t k = 0; k < xq.size(); ++k)
+      {
+        i0 += wq[k] * q0.val(xq[k]) * q1.val(xq[k]);
+        i1 += wq[k] * xq[k] * q0.val(xq[k]) * q1.val(xq[k]);
+      }
+    Poly1 p0 = q0;
+    p0.r.push_back(i1 / i0);
+    p0.normalise(0.0, 1.0);
+    Poly1 p1 = q1;
+    p1.c     = -p0.der(0.0) / q1.der(0.0);
+    out[0]   = p0;
+    out[1]   = p1;
+    for (size_t j = 0; j < inner.size(); ++j)
+      {
+        Poly1 f;
+        f.r = {0.0, 0.0, 1.0, 1.0};
+        for (size_t k = 0; k < inner.size(); ++k)
+          if (k != j)
+            f.r.push_back(inner[k]);
+        f.normalise(inner[j], 1.0);
+        out[2 + j] = f;
+      }
+    auto mirror = [](const Poly1 &f) {
+      Poly1 m;
+      m.c = f.c * ((f.r.size() % 2) ? -1.0 : 1.0);
+      for (double r : f.r)
+        m.r.push_back(1.0 - r);
+      return m;
+    };
+    out[p - 1] = mirror(p1);
+    out[p]     = mirror(p0);
+    return out;
+  }
+
+  struct Host1D
+  {
+    int                 n = 0;
+    std::vector<double> xq, wq, S, SD, D, E, lambda;
+    double              b[2][kMaxN], g[2][kMaxN], fb[2][kMaxN], fg[2][kMaxN];
+    double              hderiv = 0;
+    // eigenfunctions: Laplace form, first-derivative form, values and derivatives at the two ends
+    std::vector<double> lt, ct, beta[2], gamma[2];
+  };
+
+  int build_1d(int p, int basis, Host1D &h, std::string &why)
+  {
+    const int n = p + 1;
+    h.n         = n;
+    gauss01(n, h.xq, h.wq);
+    std::vector<Poly1> fe;
+    if (basis == MGX_DG_HERMITE)
+      fe = hermite_like(p);
+    else if (basis == MGX_DG_GAUSS)
+      fe = lagrange(h.xq);
+    else
+      {
+        std::vector<double> nodes{0.0};
+        for (double x : jacobi_roots01(n - 2, 1.0))
+          nodes.push_back(x);
+        nodes.push_back(1.0);
+        fe = lagrange(nodes);
+      }
+    const std::vector<Poly1> col = lagrange(h.xq);
+    h.S.assign(n * n, 0);
+    h.SD.assign(n * n, 0);
+    h.D.assign(n * n, 0);
+    for (int q = 0; q < n; ++q)
+      for (int i = 0; i < n; ++i)
+        {
+          h.S[q * n + i]  = fe[i].val(h.xq[q]);
+          h.SD[q * n + i] = fe[i].der(h.xq[q]);
+          h.D[q * n + i]  = col[i].der(h.xq[q]);
+        }
+    for (int s = 0; s < 2; ++s)
+      for (int i = 0; i < n; ++i)
+        {
+          h.b[s][i]  = col[i].val(s);
+          h.g[s][i]  = col[i].der(s);
+          h.fb[s][i] = fe[i].val(s);
+          h.fg[s][i] = fe[i].der(s);
+        }
+    h.hderiv = fe[0].der(0.0);
+
+    // generalised eigenproblem lapl v = lambda mass v (laplace_operator_dg.h:179-215)
+    std::vector<double> mass(n * n, 0), lapl(n * n, 0), cfirst(n * n, 0);
+    const double        pen = double(n) * n;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        {
+          double m = 0, l = 0, cf = 0;
+          for (int q = 0; q < n; ++q)
+            {
+              m += h.wq[q] * h.S[q * n + i] * h.S[q * n + j];
+              l += h.wq[q] * h.SD[q * n + i] * h.SD[q * n + j];
+              cf += h.wq[q] * h.S[q * n + i] * h.SD[q * n + j];
+            }
+          mass[i * n + j]   = m;
+          cfirst[i * n + j] = cf;
+          l += h.fb[0][i] * h.fb[0][j] * pen + 0.5 * (h.fg[0][i] * h.fb[0][j] + h.fg[0][j] * h.fb[0][i]);
+          l += h.fb[1][i] * h.fb[1][j] * pen - 0.5 * (h.fg[1][i] * h.fb[1][j] + h.fg[1][j] * h.fb[1][i]);
+          lapl[i * n + j] = l;
+        }
+    // Cholesky mass = L L^T
+    std::vector<double> L(n * n, 0);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j <= i; ++j)
+        {
+          double s = mass[i * n + j];
+          for (int k = 0; k < j; ++k)
+            s -= L[i * n + k] * L[j * n + k];
+          if (i == j)
+            {
+              if (s <= 0)
+                {
+                  why = "1D mass matrix is not positive definite";
+                  return MGX_ERR_UNSUPPORTED;
+                }
+              L[i * n + i] = std::sqrt(s);
+            }
+          else
+            L[i * n + j] = s / L[j * n + j];
+        }
+    // C = L^-1 lapl L^-T
+    auto solve_lower = [&](std::vector<double> &B) { // B <- L^-1 B (columns)
+      for (int col_ = 0; col_ < n; ++col_)
+        for (int i = 0; i < n; ++i)
+          {
+            double s = B[i * n + col_];
+            for (int k = 0; k < i; ++k)
+              s -= L[i * n + k] * B[k * n + col_];
+            B[i * n + col_] = s / L[i * n + i];
+          }
+    };
+    std::vector<double> Cm = lapl;
+    solve_lower(Cm);
+    std::vector<double> Ct(n * n);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        Ct[i * n + j] = Cm[j * n + i];
+    solve_lower(Ct);
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j)
+        Ct[i * n + j] = Ct[j * n + i] = 0.5 * (Ct[i * n + j] + Ct[j * n + i]);
+    std::vector<double> Q;
+    sym_eig(n, Ct, h.lambda, Q);
+    // E = L^-T Q
+    h.E.assign(n * n, 0);
+    for (int e = 0; e < n; ++e)
+      for (int i = n - 1; i >= 0; --i)
+        {
+          double s = Q[i * n + e];
+          for (int k = i + 1; k < n; ++k)
+            s -= L[k * n + i] * h.E[k * n + e];
+          h.E[i * n + e] = s / L[i * n + i];
+        }
+    // 1D forms in the eigenvector basis
+    h.lt.assign(n, 0);
+    h.ct.assign(n, 0);
+    for (int s = 0; s < 2; ++s)
+      {
+        h.beta[s].assign(n, 0);
+        h.gamma[s].assign(n, 0);
+      }
+    for (int e = 0; e < n; ++e)
+      {
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j)
+            {
+              double l = 0;
+              for (int q = 0; q < n; ++q)
+                l += h.wq[q] * h.SD[q * n + i] * h.SD[q * n + j];
+              h.lt[e] += h.E[i * n + e] * l * h.E[j * n + e];
+              h.ct[e] += h.E[i * n + e] * cfirst[i * n + j] * h.E[j * n + e];
+            }
+        for (int s = 0; s < 2; ++s)
+          for (int i = 0; i < n; ++i)
+            {
+              h.beta[s][e] += h.E[i * n + e] * h.fb[s][i];
+              h.gamma[s][e] += h.E[i * n + e] * h.fg[s][i];
+            }
+      }
+    return MGX_OK;
+  }
+
+  struct Geometry
+  {
+    double K[6], cn[3][3], fw[3], sigma[3];
+  };
+
+  int build_geometry(const double J[9], int p, Geometry &g, std::string &why)
+  {
+    const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) +
+                       J[2] * (J[3] * J[7] - J[4] * J[6]);
+    if (!(std::abs(det) > 0))
+      {
+        why = "singular cell Jacobian";
+        return MGX_ERR_INVALID_ARGUMENT;
+      }
+    double inv[3][3]; // inv[a][i] = d xi_a / d x_i
+    inv[0][0] = (J[4] * J[8] - J[5] * J[7]) / det;
+    inv[0][1] = (J[2] * J[7] - J[1] * J[8]) / det;
+    inv[0][2] = (J[1] * J[5] - J[2] * J[4]) / det;
+    inv[1][0] = (J[5] * J[6] - J[3] * J[8]) / det;
+    inv[1][1] = (J[0] * J[8] - J[2] * J[6]) / det;
+    inv[1][2] = (J[2] * J[3] - J[0] * J[5]) / det;
+    inv[2][0] = (J[3] * J[7] - J[4] * J[6]) / det;
+    inv[2][1] = (J[1] * J[6] - J[0] * J[7]) / det;
+    inv[2][2] = (J[0] * J[4] - J[1] * J[3]) / det;
+    double G[3][3];
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c)
+        G[a][c] = inv[a][0] * inv[c][0] + inv[a][1] * inv[c][1] + inv[a][2] * inv[c][2];
+    const double ad = std::abs(det);
+    g.K[0] = ad * G[0][0];
+    g.K[1] = ad * G[1][1];
+    g.K[2] = ad * G[2][2];
+    g.K[3] = ad * G[0][1];
+    g.K[4] = ad * G[0][2];
+    g.K[5] = ad * G[1][2];
+    for (int d = 0; d < 3; ++d)
+      {
+        const double nrm = std::sqrt(G[d][d]);
+        for (int a = 0; a < 3; ++a)
+          g.cn[d][a] = G[d][a] / nrm;
+        g.fw[d]    = ad * nrm;
+        g.sigma[d] = double(p + 1) * (p + 1) * std::abs(g.cn[d][d]); // penalty_factor = 1 (:47)
+      }
+    return MGX_OK;
+  }
+
+  // diagonal of T^T A_KK T for one combination of Dirichlet faces (bit f of cat): Kronecker
+  // products of 1D forms in the eigenvector basis, in which the mass matrix is the identity
+  void transformed_diagonal(const Host1D &h, const Geometry &g, unsigned cat, std::vector<double> &diag)
+  {
+    const int n = h.n;
+    diag.assign((size_t)n * n * n, 0.0);
+    for (int k = 0; k < n; ++k)
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i)
+          {
+            const int e[3] = {i, j, k};
+            double    v    = g.K[0] * h.lt[i] + g.K[1] * h.lt[j] + g.K[2] * h.lt[k] +
+                       2 * (g.K[3] * h.ct[i] * h.ct[j] + g.K[4] * h.ct[i] * h.ct[k] + g.K[5] * h.ct[j] * h.ct[k]);
+            for (int f = 0; f < 6; ++f)
+              {
+                const int    d = f / 2, s = f % 2;
+                const double fbnd = (cat >> f) & 1u ? 1.0 : 0.5;
+                const double sgn  = s ? 1.0 : -1.0;
+                const double be = h.beta[s][e[d]], ga = h.gamma[s][e[d]];
+                double       vn = g.cn[d][d] * be * ga;
+                for (int a = 0; a < 3; ++a)
+                  if (a != d)
+                    vn += g.cn[d][a] * be * be * h.ct[e[a]];
+                v += g.fw[d] * (2 * fbnd * g.sigma[d] * be * be - 2 * fbnd * sgn * vn);
+              }
+            diag[(k * n + j) * n + i] = v;
+          }
+  }
+
+  template <typename T>
+  void fill_const(const Host1D &h, const Geometry &g, DGConst<T> &c)
+  {
+    std::memset(&c, 0, sizeof(c));
+    const int n = h.n;
+    for (int i = 0; i < n * n; ++i)
+      {
+        c.S[i] = (T)h.S[i];
+        c.D[i] = (T)h.D[i];
+        c.E[i] = (T)h.E[i];
+      }
+    for (int i = 0; i < n; ++i)
+      {
+        c.w[i] = (T)h.wq[i];
+        for (int s = 0; s < 2; ++s)
+          {
+            c.b[s][i]  = (T)h.b[s][i];
+            c.g[s][i]  = (T)h.g[s][i];
+            c.fb[s][i] = (T)h.fb[s][i];
+            c.fg[s][i] = (T)h.fg[s][i];
+          }
+      }
+    for (int i = 0; i < 6; ++i)
+      c.K[i] = (T)g.K[i];
+    for (int d = 0; d < 3; ++d)
+      {
+        for (int a = 0; a < 3; ++a)
+          c.cn[d][a] = (T)g.cn[d][a];
+        c.fw[d]    = (T)g.fw[d];
+        c.sigma[d] = (T)g.sigma[d];
+      }
+    c.hderiv = (T)h.hderiv;
+  }
+
+  template <int P, typename T, int TYPE, int ACTION>
+  void launch_one(hipStream_t s, const DGArgs<T> &a)
+  {
+    using C             = DGCfg<P, T>;
+    const uint32_t grid = (a.n_cells + C::CPW - 1) / C::CPW;
+    hipLaunchKernelGGL((dg_cell_kernel<P, T, TYPE, ACTION>), dim3(grid), dim3(C::THREADS), 0, s, a);
+  }
+
+  template <int P, typename T, int TYPE>
+  void launch_action(hipStream_t s, int action, const DGArgs<T> &a)
+  {
+    switch (action)
+      {
+        case kVmult:
+          return launch_one<P, T, TYPE, kVmult>(s, a);
+        case kChebyshev:
+          return launch_one<P, T, TYPE, kChebyshev>(s, a);
+        case kResidual:
+          return launch_one<P, T, TYPE, kResidual>(s, a);
+        default:
+          return launch_one<P, T, TYPE, kJacobi>(s, a);
+      }
+  }
+
+  template <int P, typename T>
+  void launch_type(hipStream_t s, int basis, int action, const DGArgs<T> &a)
+  {
+    if (basis == MGX_DG_HERMITE)
+      launch_action<P, T, MGX_DG_HERMITE>(s, action, a);
+    else if (basis == MGX_DG_GAUSS_LOBATTO)
+      launch_action<P, T, MGX_DG_GAUSS_LOBATTO>(s, action, a);
+    else
+      launch_action<P, T, MGX_DG_GAUSS>(s, action, a);
+  }
+
+  template <typename T>
+  void launch_degree(hipStream_t s, int p, int basis, int action, const DGArgs<T> &a)
+  {
+    switch (p)
+      {
+        case 1:
+          return launch_type<1, T>(s, basis, action, a);
+        case 2:
+          return launch_type<2, T>(s, basis, action, a);
+        case 3:
+          return launch_type<3, T>(s, basis, action, a);
+        case 4:
+          return launch_type<4, T>(s, basis, action, a);
+        case 5:
+          return launch_type<5, T>(s, basis, action, a);
+        case 6:
+          return launch_type<6, T>(s, basis, action, a);
+        case 7:
+          return launch_type<7, T>(s, basis, action, a);
+        case 8:
+          return launch_type<8, T>(s, basis, action, a);
+        default:
+          return launch_type<9, T>(s, basis, action, a);
+      }
+  }
+} // namespace
+
+struct mgx_dg_operator_s
+{
+  mgx_context_t ctx    = nullptr;
+  int           degree = 0, basis = 0, number = MGX_F32;
+  uint32_t      n_cells = 0;
+  int32_t      *neigh   = nullptr; // device
+  void         *consts  = nullptr; // device DGConst<T>
+  void         *inv_diag = nullptr; // device [64][(p+1)^3]
+  Host1D        h;
+  Geometry      g;
+};
+
+namespace
+{
+  int dg_fail(int code, const std::string &msg) { return mgx::report_error(code, msg.c_str()); }
+
+#define DG_HIP(call)                                                                       \
+  do                                                                                       \
+    {                                                                                      \
+      hipError_t e_ = (call);                                                              \
+      if (e_ != hipSuccess)                                                                \
+        return dg_fail(MGX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+    }                                                                                      \
+  while (0)
+
+  int run(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
+          int iteration_index)
+  {
+    hipStream_t s = (hipStream_t)mgx_context_stream(op->ctx);
+    if (op->number == MGX_F64)
+      {
+        DGArgs<double> a{(const double *)src, (const double *)rhs, (double *)dst, op->neigh,
+                         (const DGConst<double> *)op->consts, (const double *)op->inv_diag, op->n_cells, f1, f2,
+                         iteration_index};
+        launch_degree<double>(s, op->degree, op->basis, action, a);
+      }
+    else
+      {
+        DGArgs<float> a{(const float *)src, (const float *)rhs, (float *)dst, op->neigh,
+                        (const DGConst<float> *)op->consts, (const float *)op->inv_diag, op->n_cells, (float)f1,
+                        (float)f2, iteration_index};
+        launch_degree<float>(s, op->degree, op->basis, action, a);
+      }
+    DG_HIP(hipGetLastError());
+    return MGX_OK;
+  }
+} // namespace
+
+extern "C" {
+
+int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, mgx_dg_operator_t *out)
+{
+  if (!ctx || !desc || !out)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: null argument");
+  if (desc->degree < 1 || desc->degree > MGX_MAX_DEGREE)
+    return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: degree must be in 1.." + std::to_string(MGX_MAX_DEGREE));
+  if (desc->basis < MGX_DG_HERMITE || desc->basis > MGX_DG_GAUSS)
+    return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: basis must be MGX_DG_HERMITE, _GAUSS_LOBATTO or _GAUSS");
+  if (desc->number != MGX_F32 && desc->number != MGX_F64)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: number must be MGX_F32 or MGX_F64");
+  if (desc->n_cells == 0 || !desc->neighbours)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: empty mesh");
+  const uint64_t n3 = (uint64_t)(desc->degree + 1) * (desc->degree + 1) * (desc->degree + 1);
+  if ((uint64_t)desc->n_cells * n3 * (desc->number == MGX_F64 ? 8 : 4) >= (1ull << 40))
+    return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: vector larger than 1 TiB");
+  for (uint64_t i = 0; i < (uint64_t)desc->n_cells * 6; ++i)
+    if (desc->neighbours[i] != MGX_DG_BOUNDARY &&
+        (desc->neighbours[i] < 0 || (uint32_t)desc->neighbours[i] >= desc->n_cells))
+      return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: neighbour entry " + std::to_string(i) +
+                                                 " is neither a cell of the mesh nor MGX_DG_BOUNDARY");
+  std::unique_ptr<mgx_dg_operator_s> op(new mgx_dg_operator_s);
+  op->ctx     = ctx;
+  op->degree  = desc->degree;
+  op->basis   = desc->basis;
+  op->number  = desc->number;
+  op->n_cells = desc->n_cells;
+  std::string why;
+  int         status = build_1d(desc->degree, desc->basis, op->h, why);
+  if (status == MGX_OK)
+    status = build_geometry(desc->jacobian, desc->degree, op->g, why);
+  if (status != MGX_OK)
+    return dg_fail(status, "mgx_dg_operator_create: " + why);
+
+  const size_t        nsz = desc->number == MGX_F64 ? 8 : 4;
+  std::vector<double> table(64 * n3), diag;
+  for (unsigned cat = 0; cat < 64; ++cat)
+    {
+      transformed_diagonal(op->h, op->g, cat, diag);
+      for (uint64_t i = 0; i < n3; ++i)
+        {
+          if (!(diag[i] > 0))
+            return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: transformed cell block is not positive");
+          table[cat * n3 + i] = 1.0 / diag[i];
+        }
+    }
+  hipStream_t s = (hipStream_t)mgx_context_stream(ctx);
+  auto        cleanup = [&]() {
+    (void)hipFree(op->neigh);
+    (void)hipFree(op->consts);
+    (void)hipFree(op->inv_diag);
+  };
+#define DG_HIP_C(call)                                                                      \
+  do                                                                                        \
+    {                                                                                       \
+      hipError_t e_ = (call);                                                               \
+      if (e_ != hipSuccess)                                                                 \
+        {                                                                                   \
+          cleanup();                                                                        \
+          return dg_fail(MGX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+        }                                                                                   \
+    }                                                                                       \
+  while (0)
+  DG_HIP_C(hipMalloc((void **)&op->neigh, sizeof(int32_t) * 6 * (size_t)desc->n_cells));
+  DG_HIP_C(hipMemcpyAsync(op->neigh, desc->neighbours, sizeof(int32_t) * 6 * (size_t)desc->n_cells,
+                          hipMemcpyHostToDevice, s));
+  DG_HIP_C(hipMalloc(&op->inv_diag, nsz * table.size()));
+  if (desc->number == MGX_F64)
+    {
+      DGConst<double> c;
+      fill_const(op->h, op->g, c);
+      DG_HIP_C(hipMalloc(&op->consts, sizeof(c)));
+      DG_HIP_C(hipMemcpyAsync(op->consts, &c, sizeof(c), hipMemcpyHostToDevice, s));
+      DG_HIP_C(hipMemcpyAsync(op->inv_diag, table.data(), nsz * table.size(), hipMemcpyHostToDevice, s));
+      DG_HIP_C(hipStreamSynchronize(s));
+    }
+  else
+    {
+      DGConst<float> c;
+      fill_const(op->h, op->g, c);
+      std::vector<float> tf(table.begin(), table.end());
+      DG_HIP_C(hipMalloc(&op->consts, sizeof(c)));
+      DG_HIP_C(hipMemcpyAsync(op->consts, &c, sizeof(c), hipMemcpyHostToDevice, s));
+      DG_HIP_C(hipMemcpyAsync(op->inv_diag, tf.data(), nsz * tf.size(), hipMemcpyHostToDevice, s));
+      DG_HIP_C(hipStreamSynchronize(s));
+    }
+#undef DG_HIP_C
+  *out = op.release();
+  return MGX_OK;
+}
+
+int mgx_dg_operator_destroy(mgx_dg_operator_t op)
+{
+  if (!op)
+    return MGX_OK;
+  (void)hipStreamSynchronize((hipStream_t)mgx_context_stream(op->ctx));
+  (void)hipFree(op->neigh);
+  (void)hipFree(op->consts);
+  (void)hipFree(op->inv_diag);
+  delete op;
+  return MGX_OK;
+}
+
+uint64_t mgx_dg_operator_n_dofs(mgx_dg_operator_t op)
+{
+  return op ? (uint64_t)op->n_cells * (op->degree + 1) * (op->degree + 1) * (op->degree + 1) : 0;
+}
+
+int mgx_dg_vmult(mgx_dg_operator_t op, void *dst, const void *src)
+{
+  if (!op || !dst || !src || dst == src)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult: null or aliased vectors");
+  return run(op, kVmult, dst, nullptr, src, 0, 0, 0);
+}
+
+int mgx_dg_vmult_residual(mgx_dg_operator_t op, void *dst, const void *rhs, const void *src)
+{
+  if (!op || !dst || !src || !rhs || dst == src)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_residual: null or aliased vectors");
+  return run(op, kResidual, dst, rhs, src, 0, 0, 0);
+}
+
+int mgx_dg_jacobi_vmult(mgx_dg_operator_t op, void *dst, const void *src)
+{
+  if (!op || !dst || !src)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_jacobi_vmult: null vector");
+  return run(op, kJacobi, dst, nullptr, src, 0, 1.0, 0);
+}
+
+int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, unsigned iteration_index, double factor1,
+                                       double factor2, void *solution, void *solution_old)
+{
+  if (!op || !rhs || !solution)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_with_chebyshev_update: null vector");
+  if (iteration_index == 0)
+    return run(op, kJacobi, solution, nullptr, rhs, 0, factor2, 0);
+  if (!solution_old || solution_old == solution)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_with_chebyshev_update: solution_old is null or aliases solution");
+  return run(op, kChebyshev, solution_old, rhs, solution, factor1, factor2, (int)iteration_index);
+}
+
+int mgx_dg_operator_info(mgx_dg_operator_t op, double *hderiv, double penalty[3], double eigenvalues_1d[MGX_MAX_DEGREE + 1])
+{
+  if (!op)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_info: null operator");
+  if (hderiv)
+    *hderiv = op->h.hderiv;
+  if (penalty)
+    for (int d = 0; d < 3; ++d)
+      penalty[d] = op->g.sigma[d];
+  if (eigenvalues_1d)
+    for (int i = 0; i <= MGX_MAX_DEGREE; ++i)
+      eigenvalues_1d[i] = i < op->h.n ? op->h.lambda[i] : 0.0;
+  return MGX_OK;
+}
+
+int mgx_dg_cheby_mesh(int n_cell_steps, int cells[3], double jacobian[9])
+{
+  if (n_cell_steps < 0 || n_cell_steps > 30 || !cells || !jacobian)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_cheby_mesh: invalid argument");
+  for (int d = 0; d < 3; ++d)
+    {
+      const double left = -1.0 + 0.05 * (d + 1), right = 0.95 - 0.06 * d;
+      cells[d]          = (d < n_cell_steps % 3 ? 2 : 1) << (n_cell_steps / 3);
+      const double h    = (right - left) / cells[d];
+      for (int r = 0; r < 3; ++r)
+        jacobian[r * 3 + d] = ((r == d ? 1.0 : 0.0) + 0.12 * (r + 1) * (d + 1)) * h;
+    }
+  return MGX_OK;
+}
+
+int mgx_dg_box_neighbours(const int cells[3], int ordering, int32_t *neighbours, int32_t *cell_ijk)
+{
+  if (!cells || !neighbours || cells[0] < 1 || cells[1] < 1 || cells[2] < 1)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_box_neighbours: invalid argument");
+  const uint64_t n = (uint64_t)cells[0] * cells[1] * cells[2];
+  if (n >= (1ull << 31))
+    return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_box_neighbours: more than 2^31 cells");
+  std::vector<uint32_t> order(n), position(n);
+  std::iota(order.begin(), order.end(), 0u);
+  auto ijk = [&](uint32_t lex, int out[3]) {
+    out[0] = lex % cells[0];
+    out[1] = (lex / cells[0]) % cells[1];
+    out[2] = lex / ((uint64_t)cells[0] * cells[1]);
+  };
+  if (ordering == 1)
+    {
+      auto spread = [](uint64_t v) { // bits of v to every third position
+        uint64_t r = 0;
+        for (int bit = 0; bit < 21; ++bit)
+          r |= ((v >> bit) & 1ull) << (3 * bit);
+        return r;
+      };
+      std::vector<uint64_t> key(n);
+      for (uint32_t c = 0; c < n; ++c)
+        {
+          int p[3];
+          ijk(c, p);
+          key[c] = spread(p[0]) | (spread(p[1]) << 1) | (spread(p[2]) << 2);
+        }
+      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+    }
+  for (uint32_t c = 0; c < n; ++c)
+    position[order[c]] = c;
+  for (uint32_t c = 0; c < n; ++c)
+    {
+      int p[3];
+      ijk(order[c], p);
+      if (cell_ijk)
+        for (int d = 0; d < 3; ++d)
+          cell_ijk[(size_t)c * 3 + d] = p[d];
+      const uint64_t stride[3] = {1, (uint64_t)cells[0], (uint64_t)cells[0] * cells[1]};
+      for (int d = 0; d < 3; ++d)
+        {
+          neighbours[(size_t)c * 6 + 2 * d] = p[d] > 0 ? (int32_t)position[order[c] - stride[d]] : MGX_DG_BOUNDARY;
+          neighbours[(size_t)c * 6 + 2 * d + 1] =
+            p[d] + 1 < cells[d] ? (int32_t)position[order[c] + stride[d]] : MGX_DG_BOUNDARY;
+        }
+    }
+  return MGX_OK;
+}
+
+} // extern "C"

@@ -135,6 +135,10 @@ namespace mgx
     uint32_t            colour_min = 16384; // Tunables::restrict_colour_min
   };
 
+  // records the message mgx_last_error() returns on the calling thread; returns `code` (used by the
+  // translation units that implement parts of the C ABI outside mgx_api.cpp)
+  int report_error(int code, const char *message);
+
   void launch_prolongate_pipe(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
                               bool with_constraints);
   void launch_restrict_add_pipe(hipStream_t s, const TransferData &t, void *coarse, const void *fine,
