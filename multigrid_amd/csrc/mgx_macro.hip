@@ -19,20 +19,22 @@
 // never written, as in read_dof_values_compressed / distribute_local_to_global_compressed
 // (vector_access_reduced.h:174-179, 431-433).
 //
-// Schedule of one 320-thread workgroup (p = 4 and p = 8: G = 17, 289 lines):
+// Schedule of one 256-thread workgroup (p = 4 and p = 8: G = 17, 289 lines):
 //   1. gather: the G^3 source values are loaded entity by entity (consecutive work items are
 //      consecutive DoFs of one mesh entity = consecutive addresses) through a per-degree item table
 //      (item -> entity slot, offset inside the entity, brick point) and written to the LDS array U;
 //      every thread keeps the values it loaded in registers: the write-out below uses the same
 //      item -> thread mapping, so the fused Chebyshev update has its x_i without a second read.
 //   2. x sweep, thread = line (y,z): reads its line of U, writes Mb u to W and Kb u back to its own
-//      line of U (in place: no other thread touches that line in this phase).
+//      line of U (in place: no other thread touches that line in this phase).  The 33 lines beyond
+//      the 256 threads are swept in a second pass, one cell block of a line per thread.
 //   3. y sweep, thread = line (x,z): reads its lines of W and U, writes t2 / s2 back in place.
 //   4. z sweep, thread = line (x,y): reads its lines of W and U, writes the result to W.
-//   5. write-out entity by entity with the fused post-operation (BrickMode), as store_brick does:
-//      pass 1 loads everything that has to be read, pass 2 only stores.
-// One workgroup barrier between the phases (5 per brick, against 8 + 1 per cell round before).
-// LDS: two fp64 arrays of 17^3 + the 729-word entity table = 81.5 kB: two workgroups per CU.
+//   5. write-out entity by entity with the fused post-operation (BrickMode), in chunks whose loads
+//      are issued one chunk ahead of the stores.
+// One workgroup barrier between the phases.  LDS: two fp64 arrays of 17^3 and nothing else
+// (78.6 kB): two workgroups per CU.  The workgroups are persistent and software-pipelined over
+// the bricks of a colour launch -- see brick_macro_kernel below.
 #include "mgx_brick_device.hpp"
 #include "mgx_bricks.hpp" // MGX_MACRO_PAIRS
 

@@ -24,7 +24,7 @@ def lib():
 def test_exports_every_declared_symbol(lib):
     from multigrid_amd import _lib
     declared = set()
-    for hdr in ("mgx.h", "mgx_cube.h"):
+    for hdr in ("mgx.h", "mgx_cube.h", "mgx_dg.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         declared |= set(re.findall(r"\b(mgx_[a-z0-9_]+)\s*\(", text))
