@@ -328,6 +328,15 @@ int mgx_solver_solve_hooked(mgx_solver_t solver, int do_analyze, double *reducti
 int mgx_solver_solve_cg(mgx_solver_t solver, unsigned int *iterations, double *reduction_rate);
 /* MultigridSolver::vmult(dst, src) :498-510: one V-cycle; dst/src fp64 device vectors */
 int mgx_solver_vmult(mgx_solver_t solver, double *dst, const double *src);
+/* Decomposed hierarchies only (no counterpart in the reference, whose MPI ranks keep exchanging on
+ * every level): the V-cycle on levels <= `level` runs on `coarse`, an UNDECOMPOSED solver for the
+ * same mesh up to that level which every rank creates on a second context of its own (without a
+ * communicator).  Per V-cycle the defect of `level` is summed over the ranks into coarse's defect
+ * (each DoF by its owner: owned[i] != 0), coarse runs its V-cycle, and every rank reads back the
+ * correction of its DoFs through local_to_global[i] (the DoF of coarse's level `level` that local
+ * DoF i is).  The finest level always stays decomposed.  The arrays are host memory, copied. */
+int mgx_solver_set_agglomeration(mgx_solver_t solver, int level, mgx_solver_t coarse, const uint32_t *local_to_global,
+                                 const uint8_t *owned, uint32_t n_local);
 /* MultigridSolver::vmult_with_residual_update(residual, update, factor) :516-619: the V-cycle
  * as preconditioner with the residual update of the PCG step merged into the two precision casts:
  *   defect = residual + factor update ; V-cycle ; residual += factor update ; update = z

@@ -216,6 +216,7 @@ class Context:
         h = C.c_void_p()
         check(self.lib.mgx_context_create(C.byref(h), device))
         self.h = h
+        self.device = device
 
     def sync(self):
         check(self.lib.mgx_sync(self.h))
@@ -322,6 +323,8 @@ class Cube:
         self.lib = _lib.load()
         h = C.c_void_p()
         num = self.NUMBERING[numbering]
+        self.box_desc = None if box is None else dict(box=tuple(box), origin=origin, h0=h0, geometry=geometry,
+                                                        problem=problem, numbering=numbering)
         if box is None:
             check(self.lib.mgx_cube_create_numbered(degree, n_subdiv, n_refine, num, C.byref(h)))
         else:
@@ -588,6 +591,38 @@ class MultigridSolver:
         self.n_levels = self.s.n_levels
         self.max_level = self.n_levels - 1
         self.h = C.c_void_p(self.s.solver)
+        self.coarse = None
+        if cube.size > 1 and cube.box_desc is not None and os.environ.get("MGX_AGGLOMERATE", "1") != "0":
+            self._agglomerate(degree_pre, n_cycles, vcycle_number)
+
+    def _agglomerate(self, degree, n_cycles, vnumber):
+        """Coarse levels of a decomposed hierarchy on every rank as a whole (mgx_solver_set_agglomeration):
+        the levels whose global size is at most MGX_AGGLOMERATE_MAX_DOFS (default 600000: the ones a
+        single GPU replays as one HIP graph) -- there a level's work is a few microseconds and
+        every exchange a latency."""
+        cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "600000"))
+        level = -1
+        for l in range(self.max_level):
+            g = np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * cube.degree + 1
+            if int(g.prod()) <= limit:
+                level = l
+        if level < 0:
+            return
+        d = cube.box_desc
+        whole = Cube(cube.degree, n_refine=level, box=d["box"], procs=(1, 1, 1), rank=0, numbering=d["numbering"],
+                     origin=d["origin"], h0=d["h0"], geometry=d["geometry"], problem=d["problem"])
+        ctx2 = Context(self.ctx.device)
+        coarse = MultigridSolver(ctx2, whole, degree, degree, n_cycles, vnumber)
+        gg = whole.dof_grid(level)
+        pos = np.full(int(gg.max()) + 1, INVALID_INDEX, dtype=np.uint32)
+        pos[gg] = np.arange(gg.size, dtype=np.uint32)
+        mine = np.ascontiguousarray(pos[cube.dof_grid(level)])
+        assert (mine != INVALID_INDEX).all()
+        owned = np.ones(mine.size, dtype=np.uint8)
+        owned[cube.not_owned(level)] = 0
+        check(self.lib.mgx_solver_set_agglomeration(self.h, level, coarse.h, mine.ctypes.data_as(_lib.u32p),
+                                                    owned.ctypes.data_as(C.POINTER(C.c_uint8)), mine.size))
+        self.coarse, self.coarse_level = coarse, level
 
     def matrix_dp(self, level):
         return LaplaceOperator(self.ctx, handle=self.s.matrix_dp[level])
@@ -680,6 +715,12 @@ class MultigridSolver:
         if getattr(self, "h", None):
             self.lib.mgx_cube_solver_destroy(C.byref(self.s))
             self.h = None
+        if getattr(self, "coarse", None) is not None:
+            c = self.coarse
+            self.coarse = None
+            c.close()
+            c.cube.close()
+            c.ctx.close()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -269,6 +269,15 @@ struct mgx_solver_s
   bool            graph_failed = false;
   hipGraph_t      graph = nullptr;
   hipGraphExec_t  graph_exec = nullptr;
+  // Agglomeration of the coarse levels of a decomposed hierarchy (mgx_solver_set_agglomeration):
+  // the V-cycle below agg_level runs on agg_solver, an undecomposed copy of those levels that
+  // every rank holds on a context of its own (no exchange, graph replay)
+  mgx_solver_t    agg_solver = nullptr;
+  int             agg_level  = -1;
+  uint32_t       *agg_map    = nullptr; // device [n_dofs(agg_level)]: local DoF -> DoF of agg_solver's level
+  uint8_t        *agg_owned  = nullptr; // device: 1 where this rank owns the DoF
+  hipEvent_t      agg_in = nullptr, agg_out = nullptr;
+  std::vector<double> agg_host;         // callback transport: staging of the allreduce
 };
 
 namespace
@@ -368,10 +377,14 @@ namespace
         RcclApi             &R  = rccl_api();
         const ncclDataType_t dt = num == MGX_F64 ? ncclDouble : ncclFloat;
         bool                 ok = R.GroupStart() == ncclSuccess;
+        // MGX_RCCL_SELFTEST on a one-rank communicator: every neighbour is the rank itself, so one
+        // GPU runs the launch sequence of a rank of a decomposed mesh (tools/rank_emulation.py)
+        const bool to_self = ctx->tun.rccl_selftest && ctx->rccl_size == 1;
         for (size_t k = 0; ok && k < P->rank.size(); ++k)
           {
-            ok = ok && R.Send(P->send[k], P->count[k], dt, P->rank[k], ctx->nccl, s) == ncclSuccess;
-            ok = ok && R.Recv(P->recv[k], P->count[k], dt, P->rank[k], ctx->nccl, s) == ncclSuccess;
+            const int peer = to_self ? 0 : P->rank[k];
+            ok = ok && R.Send(P->send[k], P->count[k], dt, peer, ctx->nccl, s) == ncclSuccess;
+            ok = ok && R.Recv(P->recv[k], P->count[k], dt, peer, ctx->nccl, s) == ncclSuccess;
           }
         ok = (R.GroupEnd() == ncclSuccess) && ok;
         if (!ok)
@@ -2155,6 +2168,12 @@ int mgx_solver_destroy(mgx_solver_t S)
     (void)hipGraphExecDestroy(S->graph_exec);
   if (S->graph)
     (void)hipGraphDestroy(S->graph);
+  (void)hipFree(S->agg_map);
+  (void)hipFree(S->agg_owned);
+  if (S->agg_in)
+    (void)hipEventDestroy(S->agg_in);
+  if (S->agg_out)
+    (void)hipEventDestroy(S->agg_out);
   (void)hipFree(S->cg_r);
   (void)hipFree(S->cg_z);
   (void)hipFree(S->cg_d);
@@ -2290,9 +2309,98 @@ static bool graph_usable(mgx_solver_t S, int level)
   return true;
 }
 
+// The V-cycle on levels <= agg_level of a decomposed hierarchy, run on the undecomposed copy of
+// those levels every rank holds: the defect is summed over the ranks into the copy's defect vector
+// (every DoF contributed by its owner, all others add zero: exact, identical on all ranks), the
+// copy's V-cycle runs on its own context (graph replay, no exchanges), and every rank reads the
+// correction of its DoFs back.  Replaces one latency-bound exchange per operator application and
+// level by one allreduce per V-cycle.
+static int v_cycle(mgx_solver_t S, int level, int my_n_cycles);
+
+static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
+{
+  mgx_solver_t  G   = S->agg_solver;
+  mgx_context_t ctx = S->ctx;
+  const int     L   = S->agg_level;
+  hipStream_t   s = ctx->stream, sg = G->ctx->stream;
+  const int     num = S->vnumber;
+  const size_t  ng = G->matrix[L]->d.n_dofs, nl = S->matrix[L]->d.n_dofs;
+  Stopwatch     sw(S, L, 5);
+  MGX_HIP(hipMemsetAsync(G->defect[L], 0, number_size(num) * ng, s));
+  launch_scatter_map(s, num, G->defect[L], S->defect[L], S->agg_map, S->agg_owned, (uint32_t)nl);
+  if (ctx->use_rccl)
+    {
+      RcclApi &R = rccl_api();
+      if (R.AllReduce(G->defect[L], G->defect[L], ng, num == MGX_F64 ? ncclDouble : ncclFloat, ncclSum, ctx->nccl, s) !=
+          ncclSuccess)
+        return fail(MGX_ERR_HIP, "ncclAllReduce of the agglomerated defect failed");
+    }
+  else
+    {
+      S->agg_host.resize(ng);
+      if (num == MGX_F64)
+        MGX_HIP(hipMemcpyAsync(S->agg_host.data(), G->defect[L], 8 * ng, hipMemcpyDeviceToHost, s));
+      else
+        {
+          std::vector<float> tmp(ng);
+          MGX_HIP(hipMemcpyAsync(tmp.data(), G->defect[L], 4 * ng, hipMemcpyDeviceToHost, s));
+          MGX_HIP(hipStreamSynchronize(s));
+          std::copy(tmp.begin(), tmp.end(), S->agg_host.begin());
+        }
+      MGX_HIP(hipStreamSynchronize(s));
+      if (!ctx->comm.allreduce_sum || ctx->comm.allreduce_sum(ctx->comm.user, S->agg_host.data(), (int)ng) != 0)
+        return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+      if (num == MGX_F64)
+        MGX_HIP(hipMemcpyAsync(G->defect[L], S->agg_host.data(), 8 * ng, hipMemcpyHostToDevice, s));
+      else
+        {
+          std::vector<float> tmp(S->agg_host.begin(), S->agg_host.end());
+          MGX_HIP(hipMemcpyAsync(G->defect[L], tmp.data(), 4 * ng, hipMemcpyHostToDevice, s));
+          MGX_HIP(hipStreamSynchronize(s));
+        }
+    }
+  MGX_HIP(hipEventRecord(S->agg_in, s));
+  MGX_HIP(hipStreamWaitEvent(sg, S->agg_in, 0));
+  MGX_TRY(v_cycle(G, L, my_n_cycles));
+  MGX_HIP(hipEventRecord(S->agg_out, sg));
+  MGX_HIP(hipStreamWaitEvent(s, S->agg_out, 0));
+  launch_pack(s, num, S->solution_update[L], G->solution_update[L], S->agg_map, (uint32_t)nl);
+  MGX_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_solver_set_agglomeration(mgx_solver_t S, int level, mgx_solver_t coarse, const uint32_t *local_to_global,
+                                 const uint8_t *owned, uint32_t n_local)
+{
+  MGX_REQUIRE(S && coarse && local_to_global && owned, "mgx_solver_set_agglomeration: null argument");
+  MGX_REQUIRE(S->agg_solver == nullptr, "mgx_solver_set_agglomeration: already set");
+  MGX_REQUIRE(level >= 0 && level < S->n_levels - 1, "mgx_solver_set_agglomeration: the finest level stays decomposed");
+  MGX_REQUIRE(coarse->n_levels == level + 1, "mgx_solver_set_agglomeration: the coarse solver must end at `level`");
+  MGX_REQUIRE(coarse->vnumber == S->vnumber && coarse->degree == S->degree,
+              "mgx_solver_set_agglomeration: number type or smoother degree differ");
+  MGX_REQUIRE(coarse->ctx != S->ctx && !coarse->ctx->has_comm,
+              "mgx_solver_set_agglomeration: the coarse solver lives on a context of its own without a communicator");
+  MGX_REQUIRE(n_local == S->matrix[level]->d.n_dofs, "mgx_solver_set_agglomeration: map length is not the level size");
+  const uint32_t ng = coarse->matrix[level]->d.n_dofs;
+  for (uint32_t i = 0; i < n_local; ++i)
+    if (local_to_global[i] >= ng)
+      return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_solver_set_agglomeration: map entry out of range");
+  MGX_HIP(hipMalloc((void **)&S->agg_map, sizeof(uint32_t) * ((size_t)n_local + 1)));
+  MGX_HIP(hipMalloc((void **)&S->agg_owned, (size_t)n_local + 1));
+  MGX_HIP(hipMemcpy(S->agg_map, local_to_global, sizeof(uint32_t) * n_local, hipMemcpyHostToDevice));
+  MGX_HIP(hipMemcpy(S->agg_owned, owned, n_local, hipMemcpyHostToDevice));
+  MGX_HIP(hipEventCreateWithFlags(&S->agg_in, hipEventDisableTiming));
+  MGX_HIP(hipEventCreateWithFlags(&S->agg_out, hipEventDisableTiming));
+  S->agg_solver = coarse;
+  S->agg_level  = level;
+  return MGX_OK;
+}
+
 // MultigridSolver::v_cycle (multigrid_solver.h:641-681), with graph replay of the coarse part
 static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
 {
+  if (S->agg_solver && level == S->agg_level)
+    return agglomerated_cycle(S, my_n_cycles);
   if (my_n_cycles != 1 || !graph_usable(S, level))
     return v_cycle_eager(S, level, my_n_cycles);
   hipStream_t s = S->ctx->stream;

@@ -469,6 +469,25 @@ namespace mgx
                                          count, (const T *)ax, (const T *)old, (T)f0));
   }
 
+  // dst[map[i]] = src[i] where mask[i] (coarse-level agglomeration: every DoF is written by its owner)
+  template <typename T>
+  __global__ void k_scatter_map(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ map,
+                                const uint8_t *__restrict__ mask, uint32_t n)
+  {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+      if (mask[i])
+        dst[map[i]] = src[i];
+  }
+
+  void launch_scatter_map(hipStream_t s, int number, void *dst, const void *src, const uint32_t *map,
+                          const uint8_t *mask, uint32_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_scatter_map<T>), stream_grid(n), dim3(256), 0, s, (T *)dst, (const T *)src,
+                                         map, mask, n));
+  }
+
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count)
   {
     if (count == 0)

@@ -142,7 +142,8 @@ def main():
         assert its == oits, (its, oits)
         l2 = solver.compute_l2_error()
         assert abs(l2 - orc.l2_error()) < tol_l2 * l2
-        print("rank %d gpu ok: FMG L2 %.6e, cg its %d%s" % (rank, l2, its, ", native RCCL" if comm.native_enabled else ""),
+        agg = (", coarse levels <= %d agglomerated" % solver.coarse_level) if solver.coarse is not None else ""
+        print("rank %d gpu ok: FMG L2 %.6e, cg its %d%s%s" % (rank, l2, its, ", native RCCL" if comm.native_enabled else "", agg),
               flush=True)
         solver.close()
         ctx.close()

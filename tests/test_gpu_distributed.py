@@ -32,6 +32,21 @@ def test_interface_bricks_first_with_overlapped_exchange(monkeypatch, world, p, 
     assert all("gpu ok" in o for o in outs), outs
 
 
+@pytest.mark.parametrize("world,p,nr,extra,limit", [(2, 4, 3, (), "0"), (4, 4, 3, ("strong",), "3000"), (2, 4, 3, ("f32",), "40000"),
+                                                     (2, 2, 4, ("strong",), "600000")])
+def test_agglomerated_coarse_levels(monkeypatch, world, p, nr, extra, limit):
+    """the coarse levels on every rank as a whole (mgx_solver_set_agglomeration), default in the other
+    tests of this file with the threshold of 600 000 global DoFs: here switched off ("0") and with
+    thresholds that put the seam at other levels; same comparisons with the single-domain oracle"""
+    if limit == "0":
+        monkeypatch.setenv("MGX_AGGLOMERATE", "0")
+    else:
+        monkeypatch.setenv("MGX_AGGLOMERATE_MAX_DOFS", limit)
+    outs = launch("gpu", world, p, nr, extra=extra)
+    assert all("gpu ok" in o for o in outs), outs
+    assert all(("agglomerated" in o) == (limit != "0") for o in outs), outs
+
+
 def test_bench_launches_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts two ranks itself; here over gloo, both on the one GPU"""
     import json
