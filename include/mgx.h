@@ -19,7 +19,9 @@
  *     (norms, iteration counts) synchronise that stream, everything else is asynchronous
  *     until mgx_sync().
  *   - one host thread per context (the reference is single-threaded per MPI rank,
- *     multigrid_solver.h:153,176).
+ *     multigrid_solver.h:153,176).  Contexts do not order their streams against each other: a
+ *     vector that one context has allocated, zeroed or written may be handed to an object of
+ *     another context only after mgx_sync() on the first.
  *   - there is NO CPU fallback: without a HIP device mgx_context_create() fails.
  */
 #ifndef MGX_H

@@ -507,9 +507,14 @@ namespace
     return MGX_OK;
   }
 
-  // dst = A src on the unconstrained rows (constrained rows untouched)
-  int apply_plain(mgx_operator_t op, void *dst, const void *src)
+  // dst = A src on the unconstrained rows (constrained rows untouched).  identity_rows (per-cell
+  // kernel only): also dst = src on the constrained rows, set by the launch that zeroes dst when the
+  // constrained DoFs are the tail of the vector; *identity_done tells the caller whether it was
+  int apply_plain(mgx_operator_t op, void *dst, const void *src, bool identity_rows = false,
+                  bool *identity_done = nullptr)
   {
+    if (identity_done)
+      *identity_done = false;
     hipStream_t s = op->ctx->stream;
     if (op->d.bricks.available())
       return brick_loop_with_exchange(
@@ -520,7 +525,15 @@ namespace
         [](hipStream_t) {});
     ProfileBracket pb(op, 0);
     // "zero dst within the loop" (laplace_operator.h:590)
-    MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
+    if (identity_rows && identity_done && op->constrained_last && op->d.n_dofs < (1u << 22))
+      {
+        // small levels are launch-bound: one launch instead of the two fill kernels of a memset
+        // plus the copy of the constrained rows
+        launch_zero_head_copy_tail(s, op->d.number, dst, src, op->d.n_dofs - op->d.n_constrained, op->d.n_dofs);
+        *identity_done = true;
+      }
+    else
+      MGX_HIP(hipMemsetAsync(dst, 0, number_size(op->d.number) * op->d.n_dofs, s));
     launch_cell_loop(s, op->d, dst, src);
     return exchange_add(op, dst); // no-op on a single rank
   }
@@ -1011,6 +1024,15 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   // the separable fast path needs the symmetry A[a][b] = A[n-1-a][n-1-b] of M and K (true for
   // any symmetric node/quadrature set); MGX_GENERAL_KERNEL=1 forces the quadrature-point form
   const Tunables &tun = ctx->tun;
+  if (!desc->coef_q)
+    {
+      // the one coefficient tensor of an affine mesh (xx yy zz xy xz yz) must be positive definite
+      const double *c  = desc->coef;
+      const double  m2 = c[0] * c[1] - c[3] * c[3];
+      const double  m3 = c[0] * (c[1] * c[2] - c[5] * c[5]) - c[3] * (c[3] * c[2] - c[5] * c[4]) +
+                        c[4] * (c[3] * c[5] - c[1] * c[4]);
+      MGX_REQUIRE(c[0] > 0 && m2 > 0 && m3 > 0, "mgx_operator_create: the coefficient tensor is not positive definite");
+    }
   d.full_tensor      = !desc->coef_q && (desc->coef[3] != 0. || desc->coef[4] != 0. || desc->coef[5] != 0.);
   const bool general = d.full_tensor || desc->coef_q; // quadrature-point operation with the full tensor
   d.separable        = !tun.general_kernel && !general;
@@ -1378,9 +1400,11 @@ int mgx_vmult(mgx_operator_t op, void *dst, const void *src)
   MGX_REQUIRE(op && dst && src, "mgx_vmult: null argument");
   MGX_REQUIRE(dst != src, "mgx_vmult: dst and src must not alias (laplace_operator.h:573-601)");
   hipStream_t s = op->ctx->stream;
-  MGX_TRY(apply_plain(op, dst, src));
+  bool identity_done = false;
+  MGX_TRY(apply_plain(op, dst, src, true, &identity_done));
   // dst[c] = src[c] on constrained rows (:592-593)
-  launch_constrained_copy(s, op->d.number, dst, src, op->d.constrained, op->d.n_constrained);
+  if (!identity_done)
+    launch_constrained_copy(s, op->d.number, dst, src, op->d.constrained, op->d.n_constrained);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }

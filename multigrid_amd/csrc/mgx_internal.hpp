@@ -217,6 +217,7 @@ namespace mgx
                                const void *ax = nullptr, const void *old = nullptr, double f0 = 0.);
   // interface exchange helpers
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
+  void launch_zero_head_copy_tail(hipStream_t s, int number, void *dst, const void *src, uint32_t n_head, uint32_t n);
   void launch_scatter_map(hipStream_t s, int number, void *dst, const void *src, const uint32_t *map,
                           const uint8_t *mask, uint32_t n);
   void launch_pack_all(hipStream_t s, int number, void *const *send, const uint32_t *start, int n_neighbors,

@@ -469,6 +469,23 @@ namespace mgx
                                          count, (const T *)ax, (const T *)old, (T)f0));
   }
 
+  // dst[i] = 0 for i < n_head, dst[i] = src[i] behind: the zeroing before a cell loop that scatters
+  // with atomics and the identity on the (trailing) constrained rows in one launch
+  template <typename T>
+  __global__ void k_zero_head_copy_tail(T *__restrict__ dst, const T *__restrict__ src, uint32_t n_head, uint32_t n)
+  {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+      dst[i] = i < n_head ? T(0) : src[i];
+  }
+
+  void launch_zero_head_copy_tail(hipStream_t s, int number, void *dst, const void *src, uint32_t n_head, uint32_t n)
+  {
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_zero_head_copy_tail<T>), stream_grid(n), dim3(256), 0, s, (T *)dst,
+                                         (const T *)src, n_head, n));
+  }
+
   // dst[map[i]] = src[i] where mask[i] (coarse-level agglomeration: every DoF is written by its owner)
   template <typename T>
   __global__ void k_scatter_map(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ map,

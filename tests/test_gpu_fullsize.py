@@ -135,7 +135,11 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
         monkeypatch.setenv(k, v)
     ctx2 = mg.Context(0)  # the switches are read when a context is created
     plain = mg.MultigridSolver(ctx2, cube, 3, 3, 1, mg.F64)
-    b = ctx.vector(n)
+    # a vector belongs to the stream of the context that made it (its zeroing is enqueued there):
+    # the second solver works on vectors of its own context, and both streams are drained before
+    # one context reads what the other wrote
+    ctx.sync()
+    b = ctx2.vector(n)
     plain.vmult(b, x)
     ctx2.sync()
     nb = ctx.l2_norm(b)

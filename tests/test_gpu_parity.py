@@ -138,8 +138,8 @@ def test_error_paths(ctx):
     with pytest.raises(mg.MgxError):
         op.vmult(v, v)  # aliasing refused (laplace_operator.h:573-601 needs distinct vectors)
     d2 = cube.operator_desc(1)
-    d2.coef[3] = 0.1
-    with pytest.raises(mg.MgxError):
+    d2.coef[3] = 10.0 * d2.coef[0]  # an indefinite coefficient tensor is refused (a definite full one is
+    with pytest.raises(mg.MgxError):  # the sheared-mesh case of tests/test_gpu_shell.py)
         mg.LaplaceOperator(ctx, d2)
     op.clear()
     cube.close()
