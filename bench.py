@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--smoother-degree", type=int, default=3)
     ap.add_argument("--vcycle-number", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--smoother-polynomial", choices=["reference", "first_kind", "fourth_kind"], default="reference",
+                    help="reference: what the reference instantiates for the V-cycle number type -- fourth_kind for an "
+                         "fp64 V-cycle (MultigridSolver<dim,p,double,double>, multigrid_solver.h:951-952), first_kind "
+                         "for fp32 (:277-278); the work per V-cycle is the same")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -218,6 +222,9 @@ def main():
     vnum = mg.F64 if args.vcycle_number == "f64" else mg.F32
     decomposed = world > 1 and not args.replicas
     native = False
+    polynomial = args.smoother_polynomial
+    if polynomial == "reference":
+        polynomial = "fourth_kind" if vnum == mg.F64 else "first_kind"
     if decomposed:
         if ns != 1 or nr < 1:
             raise SystemExit("--cells must be a power of two (>= 2) for N > 1")
@@ -229,7 +236,8 @@ def main():
             cube = mg.Cube(args.degree, n_refine=nr - 1, box=(2, 2, 2), procs=procs, rank=rank, origin=-0.9, h0=0.95)
         else:
             cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
-        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, comm=comm)
+        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, comm=comm,
+                                    polynomial=polynomial)
         # RCCL send/recv issued by the library on its own stream (no host round trip per exchange),
         # switched on only after one exchange + one reduction agree bitwise with the torch transport
         native = comm.verify_and_enable_native(solver.matrix_dp(cube.max_level), cube.n_dofs(cube.max_level))
@@ -239,7 +247,7 @@ def main():
     else:
         procs = (1, 1, 1)
         cube = mg.Cube(args.degree, ns, nr)
-        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum)
+        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, polynomial=polynomial)
     lmax = cube.max_level
     n_dofs = cube.n_dofs(lmax)
     if not decomposed:
@@ -361,9 +369,9 @@ def main():
         "higher_is_better": True, "scaling": args.scaling if decomposed else "weak", "vs_baseline": None,
         "dtype": "f64" if vnum == mg.F64 else "f64 outer / f32 V-cycle", "data": "synthetic",
         "config": {"workload": "poisson_cube FE_Q(%d) %d^3 cells%s, %d DoFs per GPU, %d levels, "
-                               "step = 1 fp64 vmult + 1 V-cycle (Chebyshev degree %d)" %
+                               "step = 1 fp64 vmult + 1 V-cycle (Chebyshev degree %d, %s)" %
                                (args.degree, args.cells, " in total" if decomposed and args.scaling == "strong" else "", n_dofs,
-                                cube.n_levels, args.smoother_degree),
+                                cube.n_levels, args.smoother_degree, polynomial.replace("_", " ")),
                    "cells_per_dim": args.cells, "degree": args.degree, "n_dofs_per_gpu": n_dofs,
                    "global_dofs": total_dofs,
                    "parallelism": "1 GPU" if world == 1 else

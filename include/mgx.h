@@ -258,6 +258,14 @@ typedef struct
   int    degree, cg_iterations;
 } mgx_smoother_info;
 int mgx_smoother_get_info(mgx_smoother_t smoother, mgx_smoother_info *info);
+/* AdditionalData::polynomial_type: first_kind (MultigridSolver<dim,p,Number,Number2>,
+ * multigrid_solver.h:277-278; the default here) or fourth_kind (the Number == Number2 specialisation,
+ * multigrid_solver.h:951-952: delta = lambda_max, first step 4/(3 lambda_max), then
+ * factor1 = (2k+1)/(2k+5), factor2 = (8k+12)/(lambda_max (2k+5))).  mgx_smoother_get_info then
+ * reports delta = lambda_max.  May be switched at any time between applications. */
+#define MGX_CHEBYSHEV_FIRST_KIND 0
+#define MGX_CHEBYSHEV_FOURTH_KIND 1
+int mgx_smoother_set_polynomial_type(mgx_smoother_t smoother, int polynomial_type);
 /* PreconditionChebyshev::vmult (zero start) / ::step (multigrid_solver.h:399,657-659,678) */
 int mgx_smoother_vmult(mgx_smoother_t smoother, void *x, const void *b);
 int mgx_smoother_step(mgx_smoother_t smoother, void *x, const void *b);
@@ -312,6 +320,9 @@ typedef struct
  * eigenvalues, allocates the level vectors (:709-735) */
 int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver_t *solver);
 int mgx_solver_destroy(mgx_solver_t solver);
+/* polynomial type of the smoothers above the coarsest level (which keeps the first kind with the
+ * degree from its tolerance, multigrid_solver.h:955-959) */
+int mgx_solver_set_polynomial_type(mgx_solver_t solver, int polynomial_type);
 /* MultigridSolver::solve(do_analyze) :387-476.  trace (may be NULL) receives for every level
  * l >= 1 the residual norms {start, end} at trace[2*l], trace[2*l+1] when do_analyze != 0
  * (the L2 errors printed next to them need the analytic solution and are computed by the

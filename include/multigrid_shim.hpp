@@ -284,6 +284,11 @@ namespace multigrid
       check(mgx_cube_solver_create(ctx.handle(), disc.handle(), number_id<Number>::value, (int)degree_pre,
                                    (int)n_cycles, &s_));
       maxlevel_ = s_.n_levels - 1;
+      // the reference's specialisation MultigridSolver<dim,fe_degree,Number,Number> smooths with
+      // Chebyshev polynomials of the fourth kind (multigrid_solver.h:951-952), the general
+      // template with the first kind (:277-278)
+      if (std::is_same<Number, Number2>::value)
+        check(mgx_solver_set_polynomial_type(s_.solver, MGX_CHEBYSHEV_FOURTH_KIND));
     }
     ~MultigridSolver() { mgx_cube_solver_destroy(&s_); }
     MultigridSolver(const MultigridSolver &) = delete;

@@ -517,7 +517,9 @@ class LaplaceOperator:
 class Chebyshev:
     """dealii::PreconditionChebyshev<LaplaceOperator, Vector> (multigrid_solver.h:269-289)."""
 
-    def __init__(self, op, smoothing_range=20., degree=3, eig_cg_n_iterations=15, handle=None):
+    POLYNOMIAL = {"first_kind": 0, "fourth_kind": 1}
+
+    def __init__(self, op, smoothing_range=20., degree=3, eig_cg_n_iterations=15, handle=None, polynomial=None):
         self.op, self.lib = op, op.lib
         self.owned = handle is None
         if handle is None:
@@ -526,6 +528,12 @@ class Chebyshev:
             self.h = h
         else:
             self.h = C.c_void_p(handle)
+        if polynomial is not None:
+            self.set_polynomial_type(polynomial)
+
+    def set_polynomial_type(self, polynomial):
+        """AdditionalData::polynomial_type: "first_kind" or "fourth_kind" (multigrid_solver.h:277, 951)"""
+        check(self.lib.mgx_smoother_set_polynomial_type(self.h, self.POLYNOMIAL[polynomial]))
 
     def info(self):
         i = _lib.SmootherInfo()
@@ -578,7 +586,11 @@ class MultigridSolver:
     ctor arguments follow the reference: (dof_handler -> cube, degree_pre, degree_post, n_cycles);
     `vcycle_number` is the template parameter Number (program.cc:76: float; BASELINE: double)."""
 
-    def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64, comm=None):
+    def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64, comm=None,
+                 polynomial="first_kind"):
+        """polynomial: Chebyshev polynomial type of the level smoothers: "first_kind" is what
+        MultigridSolver<dim,p,Number,Number2> sets (multigrid_solver.h:277-278), "fourth_kind" what
+        the Number == Number2 specialisation sets (:951-952)"""
         assert degree_pre == degree_post  # multigrid_solver.h:126
         self.ctx, self.cube, self.lib = ctx, cube, ctx.lib
         self.vnumber = vcycle_number
@@ -594,6 +606,8 @@ class MultigridSolver:
         self.coarse = None
         if cube.size > 1 and cube.box_desc is not None and os.environ.get("MGX_AGGLOMERATE", "1") != "0":
             self._agglomerate(degree_pre, n_cycles, vcycle_number)
+        if polynomial != "first_kind":
+            check(self.lib.mgx_solver_set_polynomial_type(self.h, Chebyshev.POLYNOMIAL[polynomial]))
 
     def _agglomerate(self, degree, n_cycles, vnumber):
         """Coarse levels of a decomposed hierarchy on every rank as a whole (mgx_solver_set_agglomeration):

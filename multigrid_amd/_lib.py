@@ -190,6 +190,8 @@ SIGNATURES = {
     "mgx_cube_seeded_vector": (C.c_int, [vp, C.c_int, C.c_uint64, f64p]),
     "mgx_cube_solver_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(CubeSolver)]),
     "mgx_cube_solver_destroy": (C.c_int, [C.POINTER(CubeSolver)]),
+    "mgx_smoother_set_polynomial_type": (C.c_int, [vp, C.c_int]),
+    "mgx_solver_set_polynomial_type": (C.c_int, [vp, C.c_int]),
     "mgx_solver_set_agglomeration": (C.c_int, [vp, C.c_int, vp, u32p, C.POINTER(C.c_uint8), C.c_uint32]),
     # include/mgx_dg.h
     "mgx_dg_operator_create": (C.c_int, [vp, C.POINTER(DGOperatorDesc), C.POINTER(vp)]),

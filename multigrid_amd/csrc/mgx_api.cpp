@@ -239,6 +239,24 @@ struct mgx_smoother_s
   mgx_smoother_info info{};
   void             *x_old = nullptr, *tmp = nullptr;
   void             *x_old2 = nullptr; // third iterate buffer (odd number of fused iterations in step())
+  // AdditionalData::PolynomialType::fourth_kind (multigrid_solver.h:951-952): info.delta = lambda_max
+  bool              fourth_kind = false;
+  double            range_a     = 0; // lower end of the smoothing range (first-kind delta / theta)
+  // factor of the first step, and factor1 / factor2 of iteration k = 0, 1, ... of the recurrence
+  double first_factor() const { return fourth_kind ? 4. / (3. * info.delta) : 1. / info.theta; }
+  void   next_factors(int k, double &rhok, double &f1, double &f2) const
+  {
+    if (fourth_kind)
+      {
+        f1 = (2. * k + 1.) / (2. * k + 5.);
+        f2 = (8. * k + 12.) / (info.delta * (2. * k + 5.));
+        return;
+      }
+    const double sigma = info.theta / info.delta, rhokp = 1. / (2. * sigma - rhok);
+    f1   = rhokp * rhok;
+    f2   = 2. * rhokp / info.delta;
+    rhok = rhokp;
+  }
 };
 
 struct mgx_transfer_s
@@ -1676,6 +1694,7 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
   info.degree = degree;
   info.delta  = (info.lambda_max - a) * 0.5;
   info.theta  = (info.lambda_max + a) * 0.5;
+  sm->range_a = a;
   *out        = sm.release();
   return MGX_OK;
 }
@@ -1699,6 +1718,16 @@ int mgx_smoother_get_info(mgx_smoother_t sm, mgx_smoother_info *info)
   return MGX_OK;
 }
 
+int mgx_smoother_set_polynomial_type(mgx_smoother_t sm, int polynomial_type)
+{
+  MGX_REQUIRE(sm, "mgx_smoother_set_polynomial_type: null smoother");
+  MGX_REQUIRE(polynomial_type == MGX_CHEBYSHEV_FIRST_KIND || polynomial_type == MGX_CHEBYSHEV_FOURTH_KIND,
+              "mgx_smoother_set_polynomial_type: unknown polynomial type");
+  sm->fourth_kind = polynomial_type == MGX_CHEBYSHEV_FOURTH_KIND;
+  sm->info.delta  = sm->fourth_kind ? sm->info.lambda_max : (sm->info.lambda_max - sm->range_a) * 0.5;
+  return MGX_OK;
+}
+
 // legacy path (levels without a brick schedule): matvec into tmp, then an elementwise update
 static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 {
@@ -1707,13 +1736,12 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
   hipStream_t              s  = op->ctx->stream;
   if (I.degree < 2 || std::fabs(I.delta) < 1e-40)
     return MGX_OK;
-  double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+  double rhok = I.delta / I.theta;
   for (int k = 0; k < I.degree - 1; ++k)
     {
       MGX_TRY(mgx_vmult(op, sm->tmp, x));
-      const double rhokp = 1. / (2. * sigma - rhok);
-      const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
-      rhok = rhokp;
+      double f1, f2;
+      sm->next_factors(k, rhok, f1, f2);
       launch_cheb_update(s, op->d.number, 2, x, sm->x_old, b, sm->tmp, op->d.inv_diag, f1, f2, op->d.n_dofs);
     }
   return MGX_OK;
@@ -1769,10 +1797,10 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
       if (is_step)
         {
           MGX_TRY(mgx_vmult(op, sm->tmp, x));
-          launch_cheb_update(s, num, 1, x, sm->x_old, b, sm->tmp, op->d.inv_diag, 0., 1. / I.theta, n);
+          launch_cheb_update(s, num, 1, x, sm->x_old, b, sm->tmp, op->d.inv_diag, 0., sm->first_factor(), n);
         }
       else
-        launch_cheb_update(s, num, 0, x, sm->x_old, b, nullptr, op->d.inv_diag, 0., 1. / I.theta, n);
+        launch_cheb_update(s, num, 0, x, sm->x_old, b, nullptr, op->d.inv_diag, 0., sm->first_factor(), n);
       return cheb_loop(sm, x, b);
     }
   const bool three_term = I.degree >= 2 && std::fabs(I.delta) >= 1e-40;
@@ -1783,14 +1811,13 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
       // Zero initial guess: x_1 = (1/theta) D^-1 b is not stored.  The first loop iteration
       // evaluates it while gathering (mode 5), the second one again as its x_old (mode 6); from the
       // third on both operands are stored iterates.  Targets alternate so that the last is X.
-      const double f0   = 1. / I.theta;
-      double       rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+      const double f0   = sm->first_factor();
+      double       rhok = I.delta / I.theta;
       void        *cur = nullptr, *old = nullptr;
       for (int k = 0; k < n_loop; ++k)
         {
-          const double rhokp = 1. / (2. * sigma - rhok);
-          const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
-          rhok      = rhokp;
+          double f1, f2;
+          sm->next_factors(k, rhok, f1, f2);
           void *out = ((n_loop - 1 - k) % 2 == 0) ? X : Y;
           MGX_TRY(cheb_fused_iteration(sm, k == 0 ? 5 : (k == 1 ? 6 : 2), cur, old, out, b, f1, f2, f0));
           old = cur;
@@ -1802,13 +1829,12 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
     {
       // x_1 = (1/theta) D^-1 b goes where an alternation over {X,Y} ends in X
       void *cur = (n_loop % 2 == 0) ? X : Y, *old = nullptr;
-      launch_cheb_init(s, num, cur, b, op->d.inv_diag, 1. / I.theta, n);
-      double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+      launch_cheb_init(s, num, cur, b, op->d.inv_diag, sm->first_factor(), n);
+      double rhok = I.delta / I.theta;
       for (int k = 0; k < n_loop; ++k)
         {
-          const double rhokp = 1. / (2. * sigma - rhok);
-          const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
-          rhok      = rhokp;
+          double f1, f2;
+          sm->next_factors(k, rhok, f1, f2);
           void *out = (cur == X) ? Y : X;
           MGX_TRY(cheb_fused_iteration(sm, k == 0 ? 4 : 2, cur, old, out, b, f1, f2)); // k = 0: x_0 = 0
           old = cur;
@@ -1821,7 +1847,7 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
   if (T % 2 == 1 && T >= 3 && !sm->x_old2)
     MGX_HIP(hipMalloc(&sm->x_old2, number_size(num) * n));
   void  *Z = sm->x_old2, *cur = X, *old = nullptr;
-  double rhok = I.delta / I.theta, sigma = I.theta / I.delta;
+  double rhok = I.delta / I.theta;
   for (int k = 1; k <= T; ++k)
     {
       void *out;
@@ -1832,13 +1858,12 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
       else
         out = k == 1 ? Y : (k == 2 ? Z : (k == 3 ? X : ((cur == X) ? Y : X)));
       if (k == 1)
-        MGX_TRY(cheb_fused_iteration(sm, prolong_blocks ? 9 : 3, cur, nullptr, out, b, 0., 1. / I.theta, 0., prolong_coarse,
-                                     prolong_blocks));
+        MGX_TRY(cheb_fused_iteration(sm, prolong_blocks ? 9 : 3, cur, nullptr, out, b, 0., sm->first_factor(), 0.,
+                                     prolong_coarse, prolong_blocks));
       else
         {
-          const double rhokp = 1. / (2. * sigma - rhok);
-          const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
-          rhok = rhokp;
+          double f1, f2;
+          sm->next_factors(k - 2, rhok, f1, f2);
           MGX_TRY(cheb_fused_iteration(sm, 2, cur, old, out, b, f1, f2));
         }
       old = cur;
@@ -2163,6 +2188,26 @@ int mgx_restrict_and_add(mgx_transfer_t tr, void *coarse, const void *fine, int 
 /* ------------------------------------------------------------------------------------------
  * MultigridSolver
  * ------------------------------------------------------------------------------------------ */
+int mgx_solver_set_polynomial_type(mgx_solver_t S, int polynomial_type)
+{
+  MGX_REQUIRE(S, "mgx_solver_set_polynomial_type: null solver");
+  // the coarsest level keeps the first kind with the degree from the tolerance (multigrid_solver.h:955-959)
+  for (int l = 1; l < S->n_levels; ++l)
+    MGX_TRY(mgx_smoother_set_polynomial_type(S->smooth[l], polynomial_type));
+  if (S->graph_exec) // the factors are baked into the captured launches
+    {
+      MGX_HIP(hipStreamSynchronize(S->ctx->stream));
+      (void)hipGraphExecDestroy(S->graph_exec);
+      (void)hipGraphDestroy(S->graph);
+      S->graph_exec  = nullptr;
+      S->graph       = nullptr;
+      S->graph_calls = 0;
+    }
+  if (S->agg_solver)
+    MGX_TRY(mgx_solver_set_polynomial_type(S->agg_solver, polynomial_type));
+  return MGX_OK;
+}
+
 int mgx_solver_destroy(mgx_solver_t S)
 {
   if (!S)

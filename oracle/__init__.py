@@ -72,6 +72,7 @@ def lib():
         getattr(L, name).argtypes = [vp, C.c_int]
     L.orc_h.restype = C.c_double
     L.orc_h.argtypes = [vp, C.c_int]
+    L.orc_set_polynomial_type.argtypes = [vp, C.c_int]
     L.orc_cheb_info.argtypes = [vp, C.c_int] + [_f64p] * 4 + [C.POINTER(C.c_int)] * 2
     L.orc_bc.restype = C.c_uint32
     L.orc_bc.argtypes = [vp, C.c_int, _u32p, _f64p]
@@ -112,7 +113,7 @@ class Oracle:
     PROBLEM = {"cube": 0, "shell": 1}
 
     def __init__(self, p, n_subdiv=1, n_refine=3, degree=3, n_cycles=1, vfloat=False, box=None, geometry=None,
-                 problem="cube", origin=-0.9, h0=None):
+                 problem="cube", origin=-0.9, h0=None, polynomial="first_kind"):
         """box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1));
         otherwise the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction"""
         self.L = lib()
@@ -130,6 +131,9 @@ class Oracle:
         self.p = p
         self.n_levels = self.L.orc_n_levels(self.h)
         self.max_level = self.n_levels - 1
+        if polynomial != "first_kind":  # multigrid_solver.h:951-952 (Number == Number2 specialisation)
+            assert polynomial == "fourth_kind"
+            self.L.orc_set_polynomial_type(self.h, 1)
 
     def close(self):
         if self.h:

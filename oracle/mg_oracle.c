@@ -927,6 +927,28 @@ const double *orc_inv_diag(const orc_problem *P, int l) { return VL(P)[l].cheb.i
 double orc_h(const orc_problem *P, int l) { return P->levels[l].h; }
 const double *orc_solution(orc_problem *P, int l) { return P->solution[l]; }
 
+/* smoothers of the levels above the coarsest: 0 first_kind (multigrid_solver.h:277-278), 1 fourth_kind
+ * (the Number == Number2 specialisation, multigrid_solver.h:951-952) */
+void orc_set_polynomial_type(orc_problem *P, int fourth_kind)
+{
+  for (int l = 1; l < P->n_levels; ++l)
+    {
+      cheb_d *C = &VL(P)[l].cheb;
+      if (P->vfloat)
+        {
+          cheb_f *F      = &VL(P)[l].cheb_f_;
+          F->fourth_kind = fourth_kind;
+          F->delta       = fourth_kind ? F->lambda_max : F->lambda_max - F->theta;
+          C->delta       = F->delta;
+        }
+      else
+        {
+          C->fourth_kind = fourth_kind;
+          C->delta       = fourth_kind ? C->lambda_max : C->lambda_max - C->theta;
+        }
+    }
+}
+
 void orc_cheb_info(const orc_problem *P, int l, double *lambda_min, double *lambda_max, double *theta,
                    double *delta, int *degree, int *cg_its)
 {

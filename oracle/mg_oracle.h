@@ -82,6 +82,7 @@ const double *orc_inv_diag(const orc_problem *P, int level);
 double orc_h(const orc_problem *P, int level);
 
 /* Chebyshev parameters per level (PreconditionChebyshev) */
+void orc_set_polynomial_type(orc_problem *P, int fourth_kind);
 void orc_cheb_info(const orc_problem *P, int level, double *lambda_min, double *lambda_max,
                    double *theta, double *delta, int *degree, int *cg_its);
 

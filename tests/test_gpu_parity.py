@@ -440,3 +440,49 @@ def test_vector_kernels(ctx):
     np.testing.assert_array_equal(db.download(), b + b.astype(np.float32).astype(np.float64))
     z = ctx.vector(0)
     assert ctx.dot(z, z) == 0.0  # empty input
+
+
+@pytest.mark.parametrize("p,ns,nr,degree", [(4, 1, 3, 3), (2, 1, 3, 2), (4, 3, 1, 4), (8, 1, 2, 3), (3, 1, 3, 1)])
+def test_fourth_kind_chebyshev_smoother(ctx, p, ns, nr, degree):
+    """PolynomialType::fourth_kind, the choice of the reference's MultigridSolver<dim,p,Number,Number>
+    specialisation (multigrid_solver.h:951-952): smoother, V-cycle, FMG and PCG against the oracle
+    (whose recurrence tests/test_oracle_properties.py pins to the closed form), then back to the first kind
+    on the same solver (the replayed graph of the coarse levels has to be dropped)"""
+    cube = mg.Cube(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr, degree=degree, polynomial="fourth_kind")
+    first = oracle_for(cube, p, ns, nr, degree=degree)
+    solver = mg.MultigridSolver(ctx, cube, degree, degree, 1, mg.F64, polynomial="fourth_kind")
+    for l in range(cube.n_levels):
+        sm = solver.smoother(l)
+        gi, oi = sm.info(), orc.cheb_info(l)
+        assert gi["degree"] == oi["degree"]
+        assert gi["delta"] == pytest.approx(oi["delta"], rel=1e-8)
+        if l > 0:
+            assert gi["delta"] == gi["lambda_max"]
+        b = cube.seeded_vector(l, 7)
+        bd, xd = ctx.vector(b.size, data=b), ctx.vector(b.size)
+        sm.vmult(xd, bd)
+        x_ref = orc.cheb_vmult(l, b)
+        assert rel(xd.download(), x_ref) < 1e-10
+        sm.step(xd, bd)
+        assert rel(xd.download(), orc.cheb_step(l, x_ref, b)) < 1e-10
+    lmax = cube.max_level
+    x = cube.seeded_vector(lmax, 5)
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    for _ in range(3):  # eager, captured, replayed
+        solver.vmult(dst, src)
+        assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    rate, trace = solver.solve(True)
+    orate, otrace = orc.solve(True)
+    assert rate == pytest.approx(orate, rel=1e-6)
+    np.testing.assert_allclose(trace[1:, 0], otrace[1:, 1], rtol=1e-9)
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-8)
+    its, _ = solver.solve_cg()
+    assert its == orc.solve_cg()[0]
+    mg.check(ctx.lib.mgx_solver_set_polynomial_type(solver.h, 0))
+    solver.vmult(dst, src)
+    assert rel(dst.download(), first.vcycle(x)) < 1e-9
+    solver.close()
+    cube.close()
+    orc.close()
+    first.close()

@@ -166,3 +166,40 @@ def test_inverse_diagonal():
     d = np.array([o.vmult(l, np.eye(1, n, i).ravel())[i] for i in range(n)])
     np.testing.assert_allclose(o.inv_diag(l), 1.0 / d, rtol=1e-12)
     o.close()
+
+
+@pytest.mark.parametrize("degree", [2, 3, 5])
+def test_fourth_kind_chebyshev_matches_the_closed_form(degree):
+    """PolynomialType::fourth_kind (multigrid_solver.h:951-952; deal.II's recurrence, recalled) pinned
+    against the closed form: after n steps from a zero guess the error is
+    W_n(1 - 2 t / lambda_max) / (2n + 1) times the initial one on every eigenvector of D^-1 A with
+    eigenvalue t, W_n the Chebyshev polynomial of the fourth kind, W_n(cos th) = sin((n+1/2) th) / sin(th/2)
+    (Lottes, Optimal polynomial smoothers for multigrid V-cycles, 2023)."""
+    import scipy.linalg
+    o = Oracle(2, 1, 1, degree=degree, polynomial="fourth_kind")
+    l, n = 1, o.n_dofs(1)
+    A = np.empty((n, n))
+    e = np.zeros(n)
+    for i in range(n):
+        e[i] = 1.0
+        A[:, i] = o.vmult(l, e)
+        e[i] = 0.0
+    D = 1.0 / o.inv_diag(l)
+    lam, V = scipy.linalg.eigh(A, np.diag(D))
+    info = o.cheb_info(l)
+    assert info["delta"] == info["lambda_max"] and info["degree"] == degree
+    for k in (0, n // 3, n - 1):
+        v = V[:, k]
+        x = o.cheb_vmult(l, A @ v)
+        th = np.arccos(1.0 - 2.0 * lam[k] / info["lambda_max"])
+        expected = np.sin((degree + 0.5) * th) / np.sin(0.5 * th) / (2 * degree + 1)
+        assert np.allclose(v - x, expected * v, atol=1e-11 * np.abs(v).max()), (k, lam[k])
+    # step() from a non-zero guess reduces the error by the same polynomial
+    v = V[:, n // 2]
+    x0 = 0.3 * V[:, 1]
+    x = o.cheb_step(l, x0, A @ v)
+    c = np.linalg.solve(V, v - x)
+    c0 = np.linalg.solve(V, v - x0)
+    th = np.arccos(1.0 - 2.0 * lam / info["lambda_max"])
+    assert np.allclose(c, np.sin((degree + 0.5) * th) / np.sin(0.5 * th) / (2 * degree + 1) * c0, atol=1e-10)
+    o.close()
