@@ -320,6 +320,19 @@ typedef struct
  * eigenvalues, allocates the level vectors (:709-735) */
 int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver_t *solver);
 int mgx_solver_destroy(mgx_solver_t solver);
+/* v_cycle(maxlevel, 1) (multigrid_solver.h:641-681) on the solver's own vectors: defect[maxlevel]
+ * in, solution_update[maxlevel] out (mgx_solver_get_vector ids 2, 4) -- for a level put on top of
+ * the hierarchy, as MultigridSolverDG does (multigrid_solver_dg.h:605-633) */
+int mgx_solver_v_cycle(mgx_solver_t solver);
+/* re-creates one level's smoother with other parameters (multigrid_solver_dg.h:271-291 configures
+ * its FE_Q hierarchy differently from multigrid_solver.h:269-289); degree < 0: from the tolerance */
+int mgx_solver_reset_smoother(mgx_solver_t solver, int level, double smoothing_range, int degree,
+                              int eig_cg_n_iterations);
+int mgx_solver_n_levels(mgx_solver_t solver);
+int mgx_solver_get_operator(mgx_solver_t solver, int level, int fp64, mgx_operator_t *op);
+/* device pointer to an operator's compressed index table [n_cells][27] and its sizes */
+int mgx_operator_device_indices(mgx_operator_t op, const uint32_t **idx27, uint32_t *n_cells, uint32_t *n_dofs,
+                                int *degree);
 /* polynomial type of the smoothers above the coarsest level (which keeps the first kind with the
  * degree from its tolerance, multigrid_solver.h:955-959) */
 int mgx_solver_set_polynomial_type(mgx_solver_t solver, int polynomial_type);

@@ -80,6 +80,37 @@ int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, un
 int mgx_dg_operator_info(mgx_dg_operator_t op, double *hermite_derivative_on_face, double penalty[3],
                          double eigenvalues_1d[MGX_MAX_DEGREE + 1]);
 
+/* ---- MultigridSolverDG<3,p,Number,double> (common/multigrid_solver_dg.h:55-747): the DG level on top
+ * of the FE_Q(p) multigrid hierarchy of the same mesh ---- */
+typedef struct mgx_dg_solver_s *mgx_dg_solver_t;
+typedef struct
+{
+  mgx_dg_operator_t matrix_dg;    /* V-cycle number type (multigrid_solver_dg.h:700) */
+  mgx_dg_operator_t matrix_dg_dp; /* its fp64 twin for the outer iteration (:703) */
+  /* MultigridSolver of the FE_Q(p) hierarchy (include/mgx.h) in the V-cycle number type, built on
+   * the same context; the cells of its finest level in the order of the DG operators' cells.  The
+   * DG solver re-configures its smoothers as the reference does (:271-291: degree_pre - 1 on the
+   * finest FE_Q level, coarse tolerance 2e-3) and runs its V-cycle in place. */
+  mgx_solver_t      cfe;
+  int               degree_pre;   /* Chebyshev degree of the DG smoother (:300) */
+} mgx_dg_solver_desc;
+/* ctor (:58-323), incl. smooth_dg.initialize: eigenvalue estimate with JacobiTransformed */
+int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_dg_solver_t *solver);
+int mgx_dg_solver_destroy(mgx_dg_solver_t solver);
+int mgx_dg_solver_smoother_info(mgx_dg_solver_t solver, mgx_smoother_info *info);
+/* MultigridSolverDG::vmult (:429-440): one DG V-cycle = smoother, residual restricted to FE_Q
+ * (laplace_operator_dg.h:1798-1819), FE_Q V-cycle, correction embedded back (:1863-1894), smoother;
+ * fp64 device vectors in the DG layout */
+int mgx_dg_solver_vmult(mgx_dg_solver_t solver, double *dst, const double *src);
+/* MultigridSolverDG::solve_cg(tolerance) (:410-424) on a given right-hand side: zero start, at
+ * most 100 iterations; iterations = last_step, reduction_rate = (res/res0)^(1/its) */
+int mgx_dg_solver_solve_cg(mgx_dg_solver_t solver, double tolerance, const double *rhs, double *solution,
+                           unsigned *iterations, double *reduction_rate);
+/* the two transfers of the DG level on their own (V-cycle number type): cg = P^T dg (cg is
+ * zeroed first; constrained rows stay zero) and dg += P cg */
+int mgx_dg_restrict_to_cg(mgx_dg_solver_t solver, void *cg_dst, const void *dg_src);
+int mgx_dg_prolongate_add_cg_to_dg(mgx_dg_solver_t solver, void *dg_dst, const void *cg_src);
+
 /* ---- mesh helpers (stand in for GridGenerator + DoFHandler of the harness) ---- */
 
 /* matvec_dg_cheby/program.cc:55-77: cells per direction and the cell Jacobian of the sheared box

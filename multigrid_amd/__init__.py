@@ -21,7 +21,7 @@ from ._lib import F32, F64, INVALID_INDEX, MgxError, check
 
 __all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
            "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError", "DGLaplaceOperator", "dg_cheby_mesh",
-           "dg_box_neighbours", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS"]
+           "dg_box_neighbours", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver"]
 
 
 def process_grid(size):
@@ -813,3 +813,68 @@ class DGLaplaceOperator:
         if getattr(self, "h", None):
             self.lib.mgx_dg_operator_destroy(self.h)
             self.h = None
+
+
+class DGMultigridSolver:
+    """multigrid::MultigridSolverDG<3,p,Number,double> (common/multigrid_solver_dg.h:55-747) on the
+    Cartesian meshes of the Cube provider: a DG level (operator, block-Jacobi Chebyshev smoother) on
+    top of the FE_Q(p) hierarchy of the same mesh, V-cycle in `vcycle_number`, outer CG in fp64.
+    The DG cells are the cells of the cube's finest level in the provider's order."""
+
+    def __init__(self, ctx, cube, basis=DG_HERMITE, degree_pre=3, vcycle_number=F32):
+        self.ctx, self.cube, self.lib = ctx, cube, ctx.lib
+        assert cube.size == 1, "the DG level is single-rank in this slice"
+        l = cube.max_level
+        coords = cube.cell_coords(l).astype(np.int64)
+        n1 = int(coords.max()) + 1
+        key = coords[:, 0] + n1 * (coords[:, 1] + n1 * coords[:, 2])
+        inv = np.full(n1 ** 3, -1, dtype=np.int64)
+        inv[key] = np.arange(key.size)
+        nb = np.full((key.size, 6), -1, dtype=np.int32)
+        for d, stride in enumerate((1, n1, n1 * n1)):
+            lo, hi = coords[:, d] > 0, coords[:, d] < n1 - 1
+            nb[lo, 2 * d] = inv[key[lo] - stride]
+            nb[hi, 2 * d + 1] = inv[key[hi] + stride]
+        self.neighbours, self.cell_ijk = nb, coords
+        jac = np.eye(3) * cube.cell_size(l)
+        self.cfe = MultigridSolver(ctx, cube, degree_pre, degree_pre, 1, vcycle_number)
+        self.matrix_dg = DGLaplaceOperator(ctx, cube.degree, basis, nb, jac, vcycle_number)
+        self.matrix_dg_dp = DGLaplaceOperator(ctx, cube.degree, basis, nb, jac, F64)
+        d = _lib.DGSolverDesc(self.matrix_dg.h, self.matrix_dg_dp.h, self.cfe.h, degree_pre)
+        h = C.c_void_p()
+        check(self.lib.mgx_dg_solver_create(ctx.h, C.byref(d), C.byref(h)))
+        self.h = h
+        self.vnumber = vcycle_number
+
+    def m(self):
+        return self.matrix_dg.m()
+
+    def smoother_info(self):
+        i = _lib.SmootherInfo()
+        check(self.lib.mgx_dg_solver_smoother_info(self.h, C.byref(i)))
+        return dict(lambda_min=i.lambda_min, lambda_max=i.lambda_max, theta=i.theta, delta=i.delta,
+                    degree=i.degree, cg_its=i.cg_iterations)
+
+    def vmult(self, dst, src):
+        """one DG V-cycle (multigrid_solver_dg.h:429-440); fp64 vectors"""
+        check(self.lib.mgx_dg_solver_vmult(self.h, dst.ptr, src.ptr))
+
+    def solve_cg(self, rhs, solution, tolerance=1e-9):
+        """(iterations, reduction rate per iteration) of the V-cycle-preconditioned CG (:410-424)"""
+        its, red = C.c_uint(), C.c_double()
+        check(self.lib.mgx_dg_solver_solve_cg(self.h, tolerance, rhs.ptr, solution.ptr, C.byref(its), C.byref(red)))
+        return its.value, red.value
+
+    def restrict_to_cg(self, cg_dst, dg_src):
+        check(self.lib.mgx_dg_restrict_to_cg(self.h, cg_dst.ptr, dg_src.ptr))
+
+    def prolongate_add_cg_to_dg(self, dg_dst, cg_src):
+        check(self.lib.mgx_dg_prolongate_add_cg_to_dg(self.h, dg_dst.ptr, cg_src.ptr))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mgx_dg_solver_destroy(self.h)
+            self.h = None
+            self.matrix_dg.clear()
+            self.matrix_dg_dp.clear()
+            self.cfe.close()

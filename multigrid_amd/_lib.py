@@ -56,6 +56,10 @@ class DGOperatorDesc(C.Structure):
                 ("neighbours", C.POINTER(C.c_int32)), ("jacobian", C.c_double * 9)]
 
 
+class DGSolverDesc(C.Structure):
+    _fields_ = [("matrix_dg", vp), ("matrix_dg_dp", vp), ("cfe", vp), ("degree_pre", C.c_int)]
+
+
 class SmootherInfo(C.Structure):
     _fields_ = [("lambda_min", C.c_double), ("lambda_max", C.c_double), ("theta", C.c_double),
                 ("delta", C.c_double), ("degree", C.c_int), ("cg_iterations", C.c_int)]
@@ -192,6 +196,11 @@ SIGNATURES = {
     "mgx_cube_solver_destroy": (C.c_int, [C.POINTER(CubeSolver)]),
     "mgx_smoother_set_polynomial_type": (C.c_int, [vp, C.c_int]),
     "mgx_solver_set_polynomial_type": (C.c_int, [vp, C.c_int]),
+    "mgx_solver_v_cycle": (C.c_int, [vp]),
+    "mgx_solver_reset_smoother": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "mgx_solver_n_levels": (C.c_int, [vp]),
+    "mgx_solver_get_operator": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "mgx_operator_device_indices": (C.c_int, [vp, C.POINTER(u32p), u32p, u32p, C.POINTER(C.c_int)]),
     "mgx_solver_set_agglomeration": (C.c_int, [vp, C.c_int, vp, u32p, C.POINTER(C.c_uint8), C.c_uint32]),
     # include/mgx_dg.h
     "mgx_dg_operator_create": (C.c_int, [vp, C.POINTER(DGOperatorDesc), C.POINTER(vp)]),
@@ -202,6 +211,13 @@ SIGNATURES = {
     "mgx_dg_jacobi_vmult": (C.c_int, [vp, vp, vp]),
     "mgx_dg_vmult_with_chebyshev_update": (C.c_int, [vp, vp, C.c_uint, C.c_double, C.c_double, vp, vp]),
     "mgx_dg_operator_info": (C.c_int, [vp, f64p, f64p, f64p]),
+    "mgx_dg_solver_create": (C.c_int, [vp, C.POINTER(DGSolverDesc), C.POINTER(vp)]),
+    "mgx_dg_solver_destroy": (C.c_int, [vp]),
+    "mgx_dg_solver_smoother_info": (C.c_int, [vp, C.POINTER(SmootherInfo)]),
+    "mgx_dg_solver_vmult": (C.c_int, [vp, vp, vp]),
+    "mgx_dg_solver_solve_cg": (C.c_int, [vp, C.c_double, vp, vp, C.POINTER(C.c_uint), f64p]),
+    "mgx_dg_restrict_to_cg": (C.c_int, [vp, vp, vp]),
+    "mgx_dg_prolongate_add_cg_to_dg": (C.c_int, [vp, vp, vp]),
     "mgx_dg_cheby_mesh": (C.c_int, [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_double * 9)]),
     "mgx_dg_box_neighbours": (C.c_int, [C.POINTER(C.c_int * 3), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

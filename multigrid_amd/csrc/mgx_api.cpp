@@ -2855,6 +2855,63 @@ int mgx_solver_get_vector(mgx_solver_t S, int level, int which, void **dptr)
   return MGX_OK;
 }
 
+// One V-cycle on the solver's own level vectors: defect[maxlevel] in, solution_update[maxlevel]
+// out (mgx_solver_get_vector ids 2 and 4), for a caller that puts another level on top of the
+// hierarchy (MultigridSolverDG::dg_v_cycle calls v_cycle(maxlevel, 1), multigrid_solver_dg.h:622)
+int mgx_solver_v_cycle(mgx_solver_t S)
+{
+  MGX_REQUIRE(S, "mgx_solver_v_cycle: null solver");
+  return v_cycle(S, S->n_levels - 1, 1);
+}
+
+// Re-creates the smoother of one level with other parameters (MultigridSolverDG sets up its FE_Q
+// hierarchy with degree_pre - 1 on the finest level and a coarse tolerance of 2e-3,
+// multigrid_solver_dg.h:271-291); degree < 0: from the tolerance, as on the coarsest level
+int mgx_solver_reset_smoother(mgx_solver_t S, int level, double smoothing_range, int degree, int eig_cg_n_iterations)
+{
+  MGX_REQUIRE(S && level >= 0 && level < S->n_levels, "mgx_solver_reset_smoother: bad argument");
+  MGX_REQUIRE(S->agg_solver == nullptr, "mgx_solver_reset_smoother: not on an agglomerated hierarchy");
+  mgx_smoother_t sm = nullptr;
+  MGX_TRY(mgx_smoother_create(S->matrix[level], smoothing_range, degree, eig_cg_n_iterations, &sm));
+  MGX_TRY(mgx_smoother_destroy(S->smooth[level]));
+  S->smooth[level] = sm;
+  if (S->graph_exec) // the captured launches belong to the old smoother
+    {
+      MGX_HIP(hipStreamSynchronize(S->ctx->stream));
+      (void)hipGraphExecDestroy(S->graph_exec);
+      (void)hipGraphDestroy(S->graph);
+      S->graph_exec  = nullptr;
+      S->graph       = nullptr;
+      S->graph_calls = 0;
+    }
+  return MGX_OK;
+}
+
+// level operators of a solver (V-cycle number type / fp64)
+int mgx_solver_get_operator(mgx_solver_t S, int level, int fp64, mgx_operator_t *op)
+{
+  MGX_REQUIRE(S && op && level >= 0 && level < S->n_levels, "mgx_solver_get_operator: bad argument");
+  *op = fp64 ? S->matrix_dp[level] : S->matrix[level];
+  return MGX_OK;
+}
+
+int mgx_solver_n_levels(mgx_solver_t S) { return S ? S->n_levels : 0; }
+
+// device view of an operator's compressed index table (the DG <-> FE_Q transfer of the DG level reads it)
+int mgx_operator_device_indices(mgx_operator_t op, const uint32_t **idx27, uint32_t *n_cells, uint32_t *n_dofs, int *degree)
+{
+  MGX_REQUIRE(op, "mgx_operator_device_indices: null operator");
+  if (idx27)
+    *idx27 = op->d.idx27;
+  if (n_cells)
+    *n_cells = op->d.n_cells;
+  if (n_dofs)
+    *n_dofs = op->d.n_dofs;
+  if (degree)
+    *degree = op->d.p;
+  return MGX_OK;
+}
+
 int mgx_solver_get_smoother(mgx_solver_t S, int level, mgx_smoother_t *sm)
 {
   MGX_REQUIRE(S && sm && level >= 0 && level < S->n_levels, "mgx_solver_get_smoother: bad argument");

@@ -812,6 +812,7 @@ namespace
     std::vector<double> xq, wq, S, SD, D, E, lambda;
     double              b[2][kMaxN], g[2][kMaxN], fb[2][kMaxN], fg[2][kMaxN];
     double              hderiv = 0;
+    std::vector<double> P1; // [i*n+q]: values in the Gauss-Lobatto nodes -> coefficients of the element basis
     // eigenfunctions: Laplace form, first-derivative form, values and derivatives at the two ends
     std::vector<double> lt, ct, beta[2], gamma[2];
   };
@@ -854,6 +855,57 @@ namespace
           h.fg[s][i] = fe[i].der(s);
         }
     h.hderiv = fe[0].der(0.0);
+    {
+      // embedding of FE_Q(p) (nodal in the Gauss-Lobatto points g_q) into this basis on one cell:
+      // sum_i d_i phi_i(g_q) = c_q, i.e. d = B^-1 c with B[q][i] = phi_i(g_q)
+      // (LocalBasisTransformer type 1, laplace_operator_dg.h:103-135, applied at :1802, :1881)
+      std::vector<double> nodes{0.0};
+      for (double x : jacobi_roots01(n - 2, 1.0))
+        nodes.push_back(x);
+      nodes.push_back(1.0);
+      if (n == 1)
+        nodes = {0.5};
+      std::vector<double> Bm(n * n), inv(n * n, 0.0);
+      for (int q = 0; q < n; ++q)
+        for (int i = 0; i < n; ++i)
+          Bm[q * n + i] = fe[i].val(nodes[q]);
+      for (int i = 0; i < n; ++i)
+        inv[i * n + i] = 1;
+      for (int col = 0; col < n; ++col) // Gauss-Jordan with partial pivoting
+        {
+          int piv = col;
+          for (int r = col + 1; r < n; ++r)
+            if (std::abs(Bm[r * n + col]) > std::abs(Bm[piv * n + col]))
+              piv = r;
+          if (std::abs(Bm[piv * n + col]) < 1e-14)
+            {
+              why = "element basis is not unisolvent in the Gauss-Lobatto nodes";
+              return MGX_ERR_UNSUPPORTED;
+            }
+          for (int k = 0; k < n; ++k)
+            {
+              std::swap(Bm[piv * n + k], Bm[col * n + k]);
+              std::swap(inv[piv * n + k], inv[col * n + k]);
+            }
+          const double dinv = 1.0 / Bm[col * n + col];
+          for (int k = 0; k < n; ++k)
+            {
+              Bm[col * n + k] *= dinv;
+              inv[col * n + k] *= dinv;
+            }
+          for (int r = 0; r < n; ++r)
+            if (r != col)
+              {
+                const double f = Bm[r * n + col];
+                for (int k = 0; k < n; ++k)
+                  {
+                    Bm[r * n + k] -= f * Bm[col * n + k];
+                    inv[r * n + k] -= f * inv[col * n + k];
+                  }
+              }
+        }
+      h.P1 = inv;
+    }
 
     // generalised eigenproblem lapl v = lambda mass v (laplace_operator_dg.h:179-215)
     std::vector<double> mass(n * n, 0), lapl(n * n, 0), cfirst(n * n, 0);
@@ -1139,6 +1191,23 @@ struct mgx_dg_operator_s
   Geometry      g;
 };
 
+// MultigridSolverDG (common/multigrid_solver_dg.h:55-747): the DG level on top of an FE_Q hierarchy
+struct mgx_dg_solver_s
+{
+  mgx_context_t     ctx = nullptr;
+  mgx_dg_operator_t A = nullptr, A_dp = nullptr;
+  mgx_solver_t      cfe = nullptr;
+  int               degree = 0, number = MGX_F32;
+  size_t            n = 0;
+  mgx_smoother_info info{};
+  void             *defect = nullptr, *t = nullptr, *update = nullptr, *old = nullptr; // V-cycle number type
+  void             *P1 = nullptr;                                                      // device, V-cycle number type
+  const uint32_t   *idx27 = nullptr;
+  uint32_t          n_cells = 0, n_cg = 0;
+  void             *cg_defect = nullptr, *cg_update = nullptr; // the FE_Q solver's finest-level vectors
+  double           *r = nullptr, *z = nullptr, *d = nullptr, *h = nullptr; // PCG, fp64
+};
+
 namespace
 {
   int dg_fail(int code, const std::string &msg) { return mgx::report_error(code, msg.c_str()); }
@@ -1150,6 +1219,15 @@ namespace
       if (e_ != hipSuccess)                                                                \
         return dg_fail(MGX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
     }                                                                                      \
+  while (0)
+
+#define MGX_DG_TRY(call) \
+  do                     \
+    {                    \
+      int s_ = (call);   \
+      if (s_ != MGX_OK)  \
+        return s_;       \
+    }                    \
   while (0)
 
   int run(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
@@ -1396,6 +1474,294 @@ int mgx_dg_box_neighbours(const int cells[3], int ordering, int32_t *neighbours,
         }
     }
   return MGX_OK;
+}
+
+} // extern "C"
+
+/* ---------------------------------------------------------------------------------------------
+ * MultigridSolverDG
+ * --------------------------------------------------------------------------------------------- */
+namespace
+{
+  size_t dg_nsz(int number) { return number == MGX_F64 ? 8 : 4; }
+
+  // PreconditionChebyshev<LaplaceOperatorCompactCombine, Vector, JacobiTransformed>: vmult (zero start) and
+  // step, through the merged operation (deal.II hands iteration index 0 / 1, then k + 1 / k + 2)
+  int dg_smoother_apply(mgx_dg_solver_t S, bool is_step)
+  {
+    const mgx_smoother_info &I = S->info;
+    int                      index;
+    if (!is_step)
+      {
+        MGX_DG_TRY(mgx_dg_vmult_with_chebyshev_update(S->A, S->defect, 0, 0., 1. / I.theta, S->update, S->old));
+        index = 1;
+      }
+    else
+      {
+        MGX_DG_TRY(mgx_dg_vmult_with_chebyshev_update(S->A, S->defect, 1, 0., 1. / I.theta, S->update, S->old));
+        std::swap(S->update, S->old);
+        index = 2;
+      }
+    if (I.degree < 2 || std::fabs(I.delta) < 1e-40)
+      return MGX_OK;
+    double rhok = I.delta / I.theta;
+    const double sigma = I.theta / I.delta;
+    for (int k = 0; k < I.degree - 1; ++k, ++index)
+      {
+        const double rhokp = 1. / (2. * sigma - rhok);
+        const double f1 = rhokp * rhok, f2 = 2. * rhokp / I.delta;
+        rhok = rhokp;
+        MGX_DG_TRY(mgx_dg_vmult_with_chebyshev_update(S->A, S->defect, (unsigned)index, f1, f2, S->update, S->old));
+        std::swap(S->update, S->old);
+      }
+    return MGX_OK;
+  }
+
+  // dg_v_cycle(1) (multigrid_solver_dg.h:605-633): defect in, update out
+  int dg_v_cycle(mgx_dg_solver_t S)
+  {
+    hipStream_t s = (hipStream_t)mgx_context_stream(S->ctx);
+    MGX_DG_TRY(dg_smoother_apply(S, false));
+    // vmult_residual_and_restrict_to_cg (:616-618; laplace_operator_dg.h:1798-1819)
+    MGX_DG_TRY(mgx_dg_vmult_residual(S->A, S->t, S->defect, S->update));
+    DG_HIP(hipMemsetAsync(S->cg_defect, 0, dg_nsz(S->number) * S->n_cg, s));
+    mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, S->cg_defect, S->t, S->idx27, S->n_cells, S->P1);
+    MGX_DG_TRY(mgx_solver_v_cycle(S->cfe)); // :622
+    // prolongate_add_cg_to_dg (:625; laplace_operator_dg.h:1863-1894)
+    mgx::launch_dg_cg_transfer(s, S->number, S->degree, true, S->update, S->cg_update, S->idx27, S->n_cells, S->P1);
+    DG_HIP(hipGetLastError());
+    return dg_smoother_apply(S, true); // :629
+  }
+} // namespace
+
+extern "C" {
+
+int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_dg_solver_t *out)
+{
+  if (!ctx || !desc || !out || !desc->matrix_dg || !desc->matrix_dg_dp || !desc->cfe)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_create: null argument");
+  mgx_dg_operator_t A = desc->matrix_dg, Ad = desc->matrix_dg_dp;
+  if (Ad->number != MGX_F64 || A->n_cells != Ad->n_cells || A->degree != Ad->degree || A->basis != Ad->basis)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_create: matrix_dg_dp must be the fp64 twin of matrix_dg");
+  if (desc->degree_pre < 1)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_create: degree_pre must be at least 1");
+  const int      lmax = mgx_solver_n_levels(desc->cfe) - 1;
+  mgx_operator_t fe   = nullptr;
+  MGX_DG_TRY(mgx_solver_get_operator(desc->cfe, lmax, 0, &fe));
+  const uint32_t *idx27 = nullptr;
+  uint32_t        nc = 0, ncg = 0;
+  int             p = 0;
+  MGX_DG_TRY(mgx_operator_device_indices(fe, &idx27, &nc, &ncg, &p));
+  if (nc != A->n_cells || p != A->degree || mgx_operator_number(fe) != A->number)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_create: the FE_Q hierarchy's finest level must have the DG "
+                                             "operator's cells, degree and number type");
+  std::unique_ptr<mgx_dg_solver_s, int (*)(mgx_dg_solver_t)> S(new mgx_dg_solver_s, mgx_dg_solver_destroy);
+  S->ctx = ctx;
+  S->A = A;
+  S->A_dp = Ad;
+  S->cfe = desc->cfe;
+  S->degree = A->degree;
+  S->number = A->number;
+  S->n = (size_t)mgx_dg_operator_n_dofs(A);
+  S->idx27 = idx27;
+  S->n_cells = nc;
+  S->n_cg = ncg;
+  hipStream_t  s  = (hipStream_t)mgx_context_stream(ctx);
+  const size_t vb = dg_nsz(S->number) * S->n;
+  for (void **v : {&S->defect, &S->t, &S->update, &S->old})
+    {
+      DG_HIP(hipMalloc(v, vb));
+      DG_HIP(hipMemsetAsync(*v, 0, vb, s));
+    }
+  for (double **v : {&S->r, &S->z, &S->d, &S->h})
+    DG_HIP(hipMalloc((void **)v, 8 * S->n));
+  {
+    const int n1 = S->degree + 1;
+    DG_HIP(hipMalloc(&S->P1, dg_nsz(S->number) * n1 * n1));
+    if (S->number == MGX_F64)
+      DG_HIP(hipMemcpy(S->P1, A->h.P1.data(), 8 * n1 * n1, hipMemcpyHostToDevice));
+    else
+      {
+        std::vector<float> pf(A->h.P1.begin(), A->h.P1.end());
+        DG_HIP(hipMemcpy(S->P1, pf.data(), 4 * n1 * n1, hipMemcpyHostToDevice));
+      }
+  }
+  // the FE_Q hierarchy under a DG level smooths with degree_pre - 1 on its finest level and solves
+  // the coarsest one to 2e-3 (multigrid_solver_dg.h:271-291)
+  if (lmax > 0)
+    MGX_DG_TRY(mgx_solver_reset_smoother(desc->cfe, lmax, 20., std::max(1, desc->degree_pre - 1), 15));
+  {
+    uint32_t n0 = 0;
+    mgx_operator_t f0 = nullptr;
+    MGX_DG_TRY(mgx_solver_get_operator(desc->cfe, 0, 0, &f0));
+    MGX_DG_TRY(mgx_operator_device_indices(f0, nullptr, nullptr, &n0, nullptr));
+    MGX_DG_TRY(mgx_solver_reset_smoother(desc->cfe, 0, 2e-3, -1, (int)std::max<uint32_t>(3u, n0)));
+  }
+  MGX_DG_TRY(mgx_solver_get_vector(desc->cfe, lmax, 2, &S->cg_defect));
+  MGX_DG_TRY(mgx_solver_get_vector(desc->cfe, lmax, 4, &S->cg_update));
+
+  // smooth_dg.initialize (multigrid_solver_dg.h:293-303): eigenvalue estimate by 15 iterations of
+  // CG preconditioned with JacobiTransformed on v_i = (i mod 11) - mean, lambda_max = 1.2 x the
+  // largest Ritz value, range 20
+  {
+    const size_t n  = S->n;
+    void        *r = S->t, *z = S->update, *d = S->old, *h = S->defect; // free until the first cycle
+    const size_t full = n / 11, rem = n % 11;
+    const double mean = (full * 55.0 + rem * (rem - 1) / 2.0) / (double)n;
+    mgx::launch_index_mod11(s, S->number, r, nullptr, mean, n);
+    std::vector<double> diag, off;
+    double              res = 0, rz = 0, rz_old = 0, alpha = 0, alpha_old = 0, beta = 0;
+    MGX_DG_TRY(mgx_l2_norm(ctx, S->number, r, n, &res));
+    int it = 0;
+    while (it < 15 && res > 1e-10)
+      {
+        ++it;
+        rz_old = rz;
+        MGX_DG_TRY(mgx_dg_jacobi_vmult(A, z, r));
+        MGX_DG_TRY(mgx_dot(ctx, S->number, r, z, n, &rz));
+        if (it > 1)
+          {
+            beta = rz / rz_old;
+            MGX_DG_TRY(mgx_sadd(ctx, S->number, d, beta, 1.0, z, n));
+          }
+        else
+          MGX_DG_TRY(mgx_copy_cast(ctx, d, S->number, z, S->number, n));
+        alpha_old = alpha;
+        MGX_DG_TRY(mgx_dg_vmult(A, h, d));
+        double dh = 0;
+        MGX_DG_TRY(mgx_dot(ctx, S->number, d, h, n, &dh));
+        alpha = rz / dh;
+        MGX_DG_TRY(mgx_sadd(ctx, S->number, r, 1.0, -alpha, h, n));
+        MGX_DG_TRY(mgx_l2_norm(ctx, S->number, r, n, &res));
+        if (it == 1)
+          diag.push_back(1. / alpha);
+        else
+          {
+            off.push_back(std::sqrt(beta) / alpha_old);
+            diag.push_back(1. / alpha + beta / alpha_old);
+          }
+      }
+    mgx_smoother_info &I = S->info;
+    I.cg_iterations      = it;
+    if (diag.empty())
+      I.lambda_min = I.lambda_max = 1.;
+    else
+      {
+        const int           m = (int)diag.size();
+        std::vector<double> Tm((size_t)m * m, 0.0), lam, V;
+        for (int i = 0; i < m; ++i)
+          {
+            Tm[i * m + i] = diag[i];
+            if (i + 1 < m)
+              Tm[i * m + i + 1] = Tm[(i + 1) * m + i] = off[i];
+          }
+        sym_eig(m, Tm, lam, V);
+        I.lambda_min = lam.front();
+        I.lambda_max = 1.2 * lam.back();
+      }
+    const double a = I.lambda_max / 20.;
+    I.degree       = desc->degree_pre;
+    I.delta        = (I.lambda_max - a) * 0.5;
+    I.theta        = (I.lambda_max + a) * 0.5;
+    for (void *v : {S->defect, S->t, S->update, S->old})
+      DG_HIP(hipMemsetAsync(v, 0, vb, s));
+    DG_HIP(hipStreamSynchronize(s));
+  }
+  *out = S.release();
+  return MGX_OK;
+}
+
+int mgx_dg_solver_destroy(mgx_dg_solver_t S)
+{
+  if (!S)
+    return MGX_OK;
+  if (S->ctx)
+    (void)hipStreamSynchronize((hipStream_t)mgx_context_stream(S->ctx));
+  for (void *v : {S->defect, S->t, S->update, S->old, S->P1, (void *)S->r, (void *)S->z, (void *)S->d, (void *)S->h})
+    (void)hipFree(v);
+  delete S;
+  return MGX_OK;
+}
+
+int mgx_dg_solver_smoother_info(mgx_dg_solver_t S, mgx_smoother_info *info)
+{
+  if (!S || !info)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_smoother_info: null argument");
+  *info = S->info;
+  return MGX_OK;
+}
+
+int mgx_dg_restrict_to_cg(mgx_dg_solver_t S, void *cg_dst, const void *dg_src)
+{
+  if (!S || !cg_dst || !dg_src)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_restrict_to_cg: null argument");
+  hipStream_t s = (hipStream_t)mgx_context_stream(S->ctx);
+  DG_HIP(hipMemsetAsync(cg_dst, 0, dg_nsz(S->number) * S->n_cg, s));
+  mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, cg_dst, dg_src, S->idx27, S->n_cells, S->P1);
+  DG_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_dg_prolongate_add_cg_to_dg(mgx_dg_solver_t S, void *dg_dst, const void *cg_src)
+{
+  if (!S || !dg_dst || !cg_src)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_prolongate_add_cg_to_dg: null argument");
+  hipStream_t s = (hipStream_t)mgx_context_stream(S->ctx);
+  mgx::launch_dg_cg_transfer(s, S->number, S->degree, true, dg_dst, cg_src, S->idx27, S->n_cells, S->P1);
+  DG_HIP(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_dg_solver_vmult(mgx_dg_solver_t S, double *dst, const double *src)
+{
+  if (!S || !dst || !src)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_vmult: null argument");
+  MGX_DG_TRY(mgx_copy_cast(S->ctx, S->defect, S->number, src, MGX_F64, S->n)); // multigrid_solver_dg.h:433
+  MGX_DG_TRY(dg_v_cycle(S));
+  return mgx_copy_cast(S->ctx, dst, MGX_F64, S->update, S->number, S->n);       // :436
+}
+
+int mgx_dg_solver_solve_cg(mgx_dg_solver_t S, double tolerance, const double *rhs, double *solution,
+                           unsigned *iterations, double *reduction_rate)
+{
+  if (!S || !rhs || !solution)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_solve_cg: null argument");
+  // SolverCG with ReductionControl(100, 1e-16, tolerance), zero start, preconditioner = one DG V-cycle
+  // (multigrid_solver_dg.h:410-424)
+  mgx_context_t ctx = S->ctx;
+  const size_t  n   = S->n;
+  hipStream_t   s   = (hipStream_t)mgx_context_stream(ctx);
+  double       *r = S->r, *z = S->z, *d = S->d, *h = S->h;
+  DG_HIP(hipMemsetAsync(solution, 0, 8 * n, s));
+  MGX_DG_TRY(mgx_copy_cast(ctx, r, MGX_F64, rhs, MGX_F64, n));
+  double res0 = 0, res = 0, rz = 0, rz_old = 0;
+  MGX_DG_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
+  res         = res0;
+  unsigned it = 0;
+  while (res > std::max(1e-16, tolerance * res0) && it < 100)
+    {
+      ++it;
+      MGX_DG_TRY(mgx_dg_solver_vmult(S, z, r));
+      rz_old = rz;
+      MGX_DG_TRY(mgx_dot(ctx, MGX_F64, r, z, n, &rz));
+      if (it > 1)
+        MGX_DG_TRY(mgx_sadd(ctx, MGX_F64, d, rz / rz_old, 1.0, z, n));
+      else
+        MGX_DG_TRY(mgx_copy_cast(ctx, d, MGX_F64, z, MGX_F64, n));
+      MGX_DG_TRY(mgx_dg_vmult(S->A_dp, h, d));
+      double dh = 0;
+      MGX_DG_TRY(mgx_dot(ctx, MGX_F64, d, h, n, &dh));
+      const double alpha = rz / dh;
+      MGX_DG_TRY(mgx_sadd(ctx, MGX_F64, solution, 1.0, alpha, d, n));
+      MGX_DG_TRY(mgx_sadd(ctx, MGX_F64, r, 1.0, -alpha, h, n));
+      MGX_DG_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res));
+    }
+  if (iterations)
+    *iterations = it;
+  if (reduction_rate)
+    *reduction_rate = it ? std::pow(res / res0, 1.0 / it) : 1.0;
+  return res > std::max(1e-16, tolerance * res0) ? dg_fail(MGX_ERR_NOT_CONVERGED, "mgx_dg_solver_solve_cg: 100 iterations")
+                                                 : MGX_OK;
 }
 
 } // extern "C"

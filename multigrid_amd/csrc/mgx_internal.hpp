@@ -217,6 +217,9 @@ namespace mgx
                                const void *ax = nullptr, const void *old = nullptr, double f0 = 0.);
   // interface exchange helpers
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
+  // DG <-> FE_Q transfer on one mesh (mgx_kernels.hip): to_dg: dg += P cg, else cg += P^T dg
+  void launch_dg_cg_transfer(hipStream_t s, int number, int p, bool to_dg, void *dst, const void *src,
+                             const uint32_t *idx27, uint32_t n_cells, const void *P1);
   void launch_zero_head_copy_tail(hipStream_t s, int number, void *dst, const void *src, uint32_t n_head, uint32_t n);
   void launch_scatter_map(hipStream_t s, int number, void *dst, const void *src, const uint32_t *map,
                           const uint8_t *mask, uint32_t n);

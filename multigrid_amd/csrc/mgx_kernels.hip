@@ -756,6 +756,126 @@ namespace mgx
                          (T)op.coef[2]);
   }
 
+  // ------------------------------------------------------------------------------------------
+  // Transfer between the DG space and the FE_Q space of the same mesh and degree, cell by cell
+  // (laplace_operator_dg.h:1798-1819 residual -> FE_Q, :1863-1894 FE_Q -> DG).  Both spaces contain
+  // Q_p on every cell: the embedding of an FE_Q function is exact, d = (P1 x P1 x P1) c with the 1D
+  // matrix P1 = (phi_i(g_q))^-1 from the values in the Gauss-Lobatto nodes g_q to the coefficients of
+  // the DG basis phi_i; the restriction is its transpose.  The DG vector holds (p+1)^3 contiguous
+  // values per cell, cells in the order of the compressed index table.
+  // TO_DG: dg[cell] += P c[cell]   else: cg += P^T dg[cell] (atomics; constrained rows skipped)
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T, bool TO_DG>
+  __global__ void __launch_bounds__(Cfg<P>::THREADS)
+    dg_cg_transfer_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
+                          uint32_t n_cells, const T *__restrict__ P1)
+  {
+    using C         = Cfg<P>;
+    constexpr int N = C::N, LN = C::LN, N3 = N * N * N;
+    __shared__ T  tile[C::CPB * C::CELL_LDS];
+    const int     tid = threadIdx.x, cw = tid / C::TPC, t = tid - cw * C::TPC;
+    const int     a = t % N, b = t / N;
+    const bool    lane_ok = cw < C::CPB;
+    uint32_t      cell    = blockIdx.x * C::CPB + (lane_ok ? cw : 0);
+    const bool    active  = lane_ok && cell < n_cells;
+    if (cell >= n_cells)
+      cell = n_cells - 1;
+    T *U = tile + (lane_ok ? cw : 0) * C::CELL_LDS;
+    T  r[N], o[N];
+    // x-lines (j = a, k = b)
+    if (lane_ok)
+      {
+        if (TO_DG)
+          {
+            const LineIndex<P> L = line_index<P>(idx27, cell, a, b);
+            gather_line<P, T>(src, L, r);
+            mv<N>(P1, r, o);
+          }
+        else
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r[i] = src[(size_t)cell * N3 + (b * N + a) * N + i];
+            mvT<N>(P1, r, o);
+          }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          U[(b * N + a) * LN + i] = o[i];
+      }
+    __syncthreads();
+    if (lane_ok) // y-lines (i = a, k = b)
+      {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          r[j] = U[(b * N + j) * LN + a];
+        if (TO_DG)
+          mv<N>(P1, r, o);
+        else
+          mvT<N>(P1, r, o);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          U[(b * N + j) * LN + a] = o[j];
+      }
+    __syncthreads();
+    if (lane_ok) // z-lines (i = a, j = b)
+      {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          r[k] = U[(k * N + b) * LN + a];
+        if (TO_DG)
+          mv<N>(P1, r, o);
+        else
+          mvT<N>(P1, r, o);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          U[(k * N + b) * LN + a] = o[k];
+      }
+    __syncthreads();
+    if (active)
+      {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          r[i] = U[(b * N + a) * LN + i];
+        if (TO_DG)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              dst[(size_t)cell * N3 + (b * N + a) * N + i] += r[i];
+          }
+        else
+          scatter_add_line<P, T>(dst, line_index<P>(idx27, cell, a, b), r);
+      }
+  }
+
+  template <int P, typename T>
+  static void dg_cg_transfer_t(hipStream_t s, bool to_dg, void *dst, const void *src, const uint32_t *idx27,
+                               uint32_t n_cells, const void *P1)
+  {
+    using C           = Cfg<P>;
+    const uint32_t nb = (n_cells + C::CPB - 1) / C::CPB;
+    if (to_dg)
+      hipLaunchKernelGGL((dg_cg_transfer_kernel<P, T, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                         idx27, n_cells, (const T *)P1);
+    else
+      hipLaunchKernelGGL((dg_cg_transfer_kernel<P, T, false>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                         idx27, n_cells, (const T *)P1);
+  }
+
+  void launch_dg_cg_transfer(hipStream_t s, int number, int p, bool to_dg, void *dst, const void *src,
+                             const uint32_t *idx27, uint32_t n_cells, const void *P1)
+  {
+    if (n_cells == 0)
+      return;
+    if (number == 1)
+      {
+        MGX_DISPATCH_P(p, dg_cg_transfer_t<P, double>(s, to_dg, dst, src, idx27, n_cells, P1));
+      }
+    else
+      {
+        MGX_DISPATCH_P(p, dg_cg_transfer_t<P, float>(s, to_dg, dst, src, idx27, n_cells, P1));
+      }
+  }
+
   void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src)
   {
     if (op.number == 1)

@@ -73,6 +73,7 @@ def lib():
     L.orc_h.restype = C.c_double
     L.orc_h.argtypes = [vp, C.c_int]
     L.orc_set_polynomial_type.argtypes = [vp, C.c_int]
+    L.orc_reset_smoother.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_int]
     L.orc_cheb_info.argtypes = [vp, C.c_int] + [_f64p] * 4 + [C.POINTER(C.c_int)] * 2
     L.orc_bc.restype = C.c_uint32
     L.orc_bc.argtypes = [vp, C.c_int, _u32p, _f64p]
@@ -217,6 +218,10 @@ class Oracle:
 
     def cell_size(self, l):
         return self.L.orc_h(self.h, l)
+
+    def reset_smoother(self, l, smoothing_range, degree, eig_cg_n_iterations):
+        """multigrid_solver_dg.h:271-291 configures the FE_Q hierarchy under a DG level differently"""
+        self.L.orc_reset_smoother(self.h, l, smoothing_range, degree, eig_cg_n_iterations)
 
     def cheb_info(self, l):
         v = [C.c_double() for _ in range(4)]

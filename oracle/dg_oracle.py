@@ -322,3 +322,138 @@ class DGOracle:
                     ref = q + np.array([i, j, k])
                     out[k, j, i] = S3.T @ (W3 * fn(ref @ self.J.T))
         return out
+
+
+class DGMultigridOracle:
+    """multigrid::MultigridSolverDG (common/multigrid_solver_dg.h:55-747) restated: the DG level --
+    Chebyshev smoother with the JacobiTransformed preconditioner, residual restricted to FE_Q(p)
+    (laplace_operator_dg.h:1798-1819), V-cycle of the FE_Q hierarchy, correction embedded back
+    (:1863-1894) -- on top of the C oracle's FE_Q multigrid (oracle/mg_oracle.c) on the same Cartesian
+    mesh.  `dg`: DGOracle, `fe`: oracle.Oracle of the same mesh and degree (its smoothers are
+    re-configured as multigrid_solver_dg.h:271-291 does), `start`: the start vector of the
+    eigenvalue estimate in the DG oracle's layout (deal.II: (global DoF index mod 11) - mean)."""
+
+    def __init__(self, dg, fe, degree_pre, start):
+        self.dg, self.fe, self.degree = dg, fe, degree_pre
+        p, n = dg.p, dg.n
+        lmax = fe.max_level
+        self.lmax = lmax
+        if lmax > 0:
+            fe.reset_smoother(lmax, 20.0, max(1, degree_pre - 1), 15)
+        fe.reset_smoother(0, 2e-3, -1, max(3, fe.n_dofs(0)))
+        polys = basis_1d(p, dg.kind)
+        g = gauss_lobatto01(n)
+        B = np.array([f(g) for f in polys]).T            # B[q, i] = phi_i(g_q)
+        self.P1 = np.linalg.inv(B)                        # GLL values -> DG coefficients
+        self.P3 = kron3(self.P1, self.P1, self.P1)
+        nx, ny, nz = dg.cells
+        self.G = (nx * p + 1, ny * p + 1, nz * p + 1)
+        self.fe_grid = fe.dof_grid(lmax).astype(np.int64)
+        # eigenvalue estimate: CG preconditioned with JacobiTransformed (multigrid_solver_dg.h:293-303)
+        r = np.array(start, dtype=float).reshape(dg.shape)
+        d = None
+        diag, off = [], []
+        res, rz, alpha, it = np.linalg.norm(r), 0.0, 0.0, 0
+        while it < 15 and res > 1e-10:
+            it += 1
+            rz_old = rz
+            z = dg.jacobi_vmult(r)
+            rz = float(np.vdot(r, z))
+            if it > 1:
+                beta = rz / rz_old
+                d = z + beta * d
+            else:
+                beta = 0.0
+                d = z
+            alpha_old = alpha
+            h = dg.vmult(d)
+            alpha = rz / float(np.vdot(d, h))
+            r = r - alpha * h
+            res = np.linalg.norm(r)
+            if it == 1:
+                diag.append(1.0 / alpha)
+            else:
+                off.append(np.sqrt(beta) / alpha_old)
+                diag.append(1.0 / alpha + beta / alpha_old)
+        T = np.diag(diag) + np.diag(off, 1) + np.diag(off, -1)
+        ev = np.linalg.eigvalsh(T)
+        self.lambda_max = 1.2 * ev[-1]
+        a = self.lambda_max / 20.0
+        self.delta, self.theta = 0.5 * (self.lambda_max - a), 0.5 * (self.lambda_max + a)
+        self.cg_its = it
+
+    # ---- transfers ----
+    def restrict_to_cg(self, r_dg):
+        """P^T r, as a vector of the FE_Q oracle's finest level (constrained rows zero)"""
+        p, n = self.dg.p, self.dg.n
+        nx, ny, nz = self.dg.cells
+        Gx, Gy, Gz = self.G
+        grid = np.zeros((Gz, Gy, Gx))
+        loc = np.asarray(r_dg).reshape(self.dg.shape) @ self.P3      # (P3^T r)_q = sum_i P3[i, q] r_i
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    grid[k * p:k * p + n, j * p:j * p + n, i * p:i * p + n] += loc[k, j, i].reshape(n, n, n)
+        grid[0], grid[-1], grid[:, 0], grid[:, -1], grid[:, :, 0], grid[:, :, -1] = 0, 0, 0, 0, 0, 0
+        return grid.ravel()[self.fe_grid]
+
+    def prolongate_cg_to_dg(self, u_cg):
+        p, n = self.dg.p, self.dg.n
+        nx, ny, nz = self.dg.cells
+        Gx, Gy, Gz = self.G
+        grid = np.zeros(Gx * Gy * Gz)
+        grid[self.fe_grid] = u_cg
+        grid = grid.reshape(Gz, Gy, Gx)
+        grid[0], grid[-1], grid[:, 0], grid[:, -1], grid[:, :, 0], grid[:, :, -1] = 0, 0, 0, 0, 0, 0
+        out = np.empty(self.dg.shape)
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    c = grid[k * p:k * p + n, j * p:j * p + n, i * p:i * p + n].ravel()
+                    out[k, j, i] = self.P3 @ c
+        return out
+
+    # ---- smoother: PreconditionChebyshev with the merged operation (laplace_operator_dg.h:910-955) ----
+    def smooth(self, x, b, is_step):
+        dg = self.dg
+        if not is_step:
+            x, old = dg.vmult_with_chebyshev_update(b, 0, 0.0, 1.0 / self.theta, None if x is None else x, np.zeros(dg.shape))
+            index = 1
+        else:
+            x, old = dg.vmult_with_chebyshev_update(b, 1, 0.0, 1.0 / self.theta, x, np.zeros(dg.shape))
+            index = 2
+        rhok, sigma = self.delta / self.theta, self.theta / self.delta
+        for _ in range(self.degree - 1):
+            rhokp = 1.0 / (2.0 * sigma - rhok)
+            f1, f2 = rhokp * rhok, 2.0 * rhokp / self.delta
+            rhok = rhokp
+            x, old = dg.vmult_with_chebyshev_update(b, index, f1, f2, x, old)
+            index += 1
+        return x
+
+    def v_cycle(self, defect):
+        """dg_v_cycle(1), multigrid_solver_dg.h:605-633"""
+        defect = np.asarray(defect, dtype=float).reshape(self.dg.shape)
+        x = self.smooth(np.zeros(self.dg.shape), defect, False)
+        t = defect - self.dg.vmult(x)
+        x = x + self.prolongate_cg_to_dg(self.fe.vcycle(self.restrict_to_cg(t)))
+        return self.smooth(x, defect, True)
+
+    def solve_cg(self, rhs, tolerance=1e-9):
+        """(solution, iterations, reduction rate), multigrid_solver_dg.h:410-424"""
+        rhs = np.asarray(rhs, dtype=float).reshape(self.dg.shape)
+        x = np.zeros(self.dg.shape)
+        r = rhs.copy()
+        res0 = res = np.linalg.norm(r)
+        it, rz, d = 0, 0.0, None
+        while res > max(1e-16, tolerance * res0) and it < 100:
+            it += 1
+            z = self.v_cycle(r)
+            rz_old, rz = rz, float(np.vdot(r, z))
+            d = z if it == 1 else z + (rz / rz_old) * d
+            h = self.dg.vmult(d)
+            alpha = rz / float(np.vdot(d, h))
+            x = x + alpha * d
+            r = r - alpha * h
+            res = np.linalg.norm(r)
+        return x, it, (res / res0) ** (1.0 / max(it, 1))

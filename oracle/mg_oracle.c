@@ -927,6 +927,28 @@ const double *orc_inv_diag(const orc_problem *P, int l) { return VL(P)[l].cheb.i
 double orc_h(const orc_problem *P, int l) { return P->levels[l].h; }
 const double *orc_solution(orc_problem *P, int l) { return P->solution[l]; }
 
+/* re-creates the smoother of one level with other parameters: MultigridSolverDG configures its FE_Q
+ * hierarchy with degree_pre - 1 on the finest level and a coarse tolerance of 2e-3
+ * (multigrid_solver_dg.h:271-291); degree < 0: numbers::invalid_unsigned_int */
+void orc_reset_smoother(orc_problem *P, int l, double smoothing_range, int degree, int eig_cg_n_iterations)
+{
+  const orc_level *L = &P->levels[l];
+  if (!P->vfloat)
+    cheb_setup_d(P, L, BD(P), &VL(P)[l].cheb, smoothing_range, degree, eig_cg_n_iterations);
+  else
+    {
+      cheb_f *F = &VL(P)[l].cheb_f_;
+      cheb_d *C = &VL(P)[l].cheb;
+      cheb_setup_f(P, L, BF(P), F, smoothing_range, degree, eig_cg_n_iterations);
+      C->lambda_min = F->lambda_min;
+      C->lambda_max = F->lambda_max;
+      C->theta      = F->theta;
+      C->delta      = F->delta;
+      C->degree     = F->degree;
+      C->cg_its     = F->cg_its;
+    }
+}
+
 /* smoothers of the levels above the coarsest: 0 first_kind (multigrid_solver.h:277-278), 1 fourth_kind
  * (the Number == Number2 specialisation, multigrid_solver.h:951-952) */
 void orc_set_polynomial_type(orc_problem *P, int fourth_kind)

@@ -83,6 +83,7 @@ double orc_h(const orc_problem *P, int level);
 
 /* Chebyshev parameters per level (PreconditionChebyshev) */
 void orc_set_polynomial_type(orc_problem *P, int fourth_kind);
+void orc_reset_smoother(orc_problem *P, int l, double smoothing_range, int degree, int eig_cg_n_iterations);
 void orc_cheb_info(const orc_problem *P, int level, double *lambda_min, double *lambda_max,
                    double *theta, double *delta, int *degree, int *cg_its);
 

@@ -1,0 +1,127 @@
+"""MultigridSolverDG on the GPU (include/mgx_dg.h: the DG level on top of the FE_Q hierarchy,
+common/multigrid_solver_dg.h:55-747) against its restatement (oracle/dg_oracle.py DGMultigridOracle on
+top of the C oracle's FE_Q multigrid): transfers DG <-> FE_Q, eigenvalue estimate of the block-Jacobi
+Chebyshev smoother, one DG V-cycle, and the V-cycle-preconditioned CG of poisson_dg/program.cc."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+mg = pytest.importorskip("multigrid_amd")
+from oracle import Oracle, dg_oracle as dg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mg.Context(0)
+    yield c
+    c.close()
+
+
+class Pair:
+    def __init__(self, ctx, p, nr, basis, number, degree_pre=3):
+        self.ctx = ctx
+        self.cube = mg.Cube(p, 1, nr)
+        self.solver = mg.DGMultigridSolver(ctx, self.cube, basis, degree_pre, number)
+        n1 = 2 ** nr
+        self.dgo = dg.DGOracle(p, basis, (n1, n1, n1), np.eye(3) * self.cube.cell_size(nr))
+        self.fe = Oracle(p, 1, nr, degree=degree_pre, vfloat=(number == mg.F32))
+        self.ijk = self.solver.cell_ijk
+        n = self.solver.m()
+        start = (np.arange(n) % 11).astype(float)
+        start -= start.mean()
+        self.orc = dg.DGMultigridOracle(self.dgo, self.fe, degree_pre, self.to_oracle(start))
+        # FE_Q vectors: provider numbering <-> oracle numbering through the lexicographic grid
+        l = self.cube.max_level
+        gc, go = self.cube.dof_grid(l), self.fe.dof_grid(l)
+        pos = np.empty(go.size, np.int64)
+        pos[go] = np.arange(go.size)
+        self.cg_to_oracle = pos[gc]   # oracle index of provider DoF i
+
+    def to_oracle(self, v):
+        out = np.empty(self.dgo.shape)
+        i = self.ijk
+        out[i[:, 2], i[:, 1], i[:, 0]] = np.asarray(v, dtype=float).reshape(len(i), -1)
+        return out
+
+    def to_product(self, a):
+        i = self.ijk
+        return a[i[:, 2], i[:, 1], i[:, 0]].ravel()
+
+    def close(self):
+        self.solver.close()
+        self.cube.close()
+        self.fe.close()
+
+
+def rel(a, b):
+    return abs(a - b).max() / abs(b).max()
+
+
+@pytest.mark.parametrize("number,tol", [(mg.F64, 1e-11), (mg.F32, 2e-5)], ids=["f64", "f32"])
+@pytest.mark.parametrize("p,nr,basis", [(2, 2, 0), (3, 2, 0), (4, 2, 0), (3, 2, 1), (3, 2, 2), (1, 3, 0), (5, 1, 0)])
+def test_transfers_between_dg_and_fe_q(ctx, p, nr, basis, number, tol):
+    P = Pair(ctx, p, nr, basis, number)
+    rng = np.random.default_rng(p + nr)
+    l = P.cube.max_level
+    r = rng.standard_normal(P.dgo.shape)
+    src = ctx.vector(P.solver.m(), number, P.to_product(r))
+    cg = ctx.vector(P.cube.n_dofs(l), number, np.full(P.cube.n_dofs(l), 7.0))
+    P.solver.restrict_to_cg(cg, src)
+    ref = P.orc.restrict_to_cg(r)[P.cg_to_oracle]
+    assert rel(cg.download().astype(float), ref) < tol
+    c = rng.standard_normal(P.cube.n_dofs(l))
+    c_or = np.empty_like(c)
+    c_or[P.cg_to_oracle] = c
+    d0 = rng.standard_normal(P.dgo.shape)
+    dst = ctx.vector(P.solver.m(), number, P.to_product(d0))
+    P.solver.prolongate_add_cg_to_dg(dst, ctx.vector(c.size, number, c))
+    ref = d0 + P.orc.prolongate_cg_to_dg(c_or)
+    assert rel(P.to_oracle(dst.download()), ref) < tol
+    P.close()
+
+
+@pytest.mark.parametrize("p,nr,basis", [(2, 2, 0), (3, 2, 0), (4, 2, 0), (3, 3, 0), (3, 2, 2), (2, 2, 1)])
+def test_dg_v_cycle_and_pcg_fp64(ctx, p, nr, basis):
+    P = Pair(ctx, p, nr, basis, mg.F64)
+    info = P.solver.smoother_info()
+    assert info["cg_its"] == P.orc.cg_its and info["degree"] == 3
+    assert info["lambda_max"] == pytest.approx(P.orc.lambda_max, rel=1e-8)
+    assert info["theta"] == pytest.approx(P.orc.theta, rel=1e-8)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(P.dgo.shape)
+    src, dst = ctx.vector(P.solver.m(), data=P.to_product(x)), ctx.vector(P.solver.m())
+    for _ in range(3):  # eager, coarse levels captured, replayed
+        P.solver.vmult(dst, src)
+        assert rel(P.to_oracle(dst.download()), P.orc.v_cycle(x)) < 1e-8
+    rhs = rng.standard_normal(P.dgo.shape)
+    b, sol = ctx.vector(P.solver.m(), data=P.to_product(rhs)), ctx.vector(P.solver.m())
+    its, red = P.solver.solve_cg(b, sol, 1e-9)
+    xo, oits, ored = P.orc.solve_cg(rhs, 1e-9)
+    assert its == oits and red == pytest.approx(ored, rel=1e-5)
+    assert rel(P.to_oracle(sol.download()), xo) < 1e-7
+    # the solution solves the DG system
+    res = ctx.vector(P.solver.m())
+    P.solver.matrix_dg_dp.vmult_residual(res, b, sol)
+    assert ctx.l2_norm(res) < 2e-9 * ctx.l2_norm(b)
+    P.close()
+
+
+@pytest.mark.parametrize("p,nr,basis", [(3, 2, 0), (4, 2, 0), (2, 3, 0), (3, 2, 2)])
+def test_dg_v_cycle_and_pcg_mixed_precision(ctx, p, nr, basis):
+    """the reference's default: fp32 V-cycle inside the fp64 CG (poisson_dg/program.cc:72-73)"""
+    P = Pair(ctx, p, nr, basis, mg.F32)
+    info = P.solver.smoother_info()
+    assert info["lambda_max"] == pytest.approx(P.orc.lambda_max, rel=1e-4)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(P.dgo.shape)
+    src, dst = ctx.vector(P.solver.m(), data=P.to_product(x)), ctx.vector(P.solver.m())
+    P.solver.vmult(dst, src)
+    assert rel(P.to_oracle(dst.download()), P.orc.v_cycle(x)) < 5e-4
+    rhs = rng.standard_normal(P.dgo.shape)
+    b, sol = ctx.vector(P.solver.m(), data=P.to_product(rhs)), ctx.vector(P.solver.m())
+    its, red = P.solver.solve_cg(b, sol, 1e-9)
+    xo, oits, ored = P.orc.solve_cg(rhs, 1e-9)
+    assert abs(its - oits) <= 1 and red == pytest.approx(ored, rel=0.05)
+    assert rel(P.to_oracle(sol.download()), xo) < 1e-6
+    P.close()
