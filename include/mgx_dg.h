@@ -80,6 +80,12 @@ int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, un
 int mgx_dg_operator_info(mgx_dg_operator_t op, double *hermite_derivative_on_face, double penalty[3],
                          double eigenvalues_1d[MGX_MAX_DEGREE + 1]);
 
+/* 1D element data a harness needs for right-hand sides and error norms (what FEEvaluation hands the
+ * reference's drivers): shape_values[q*(p+1)+i] = phi_i at Gauss point q of [0,1], the points and
+ * weights of the (p+1)-point Gauss rule.  Any pointer may be NULL. */
+int mgx_dg_operator_basis(mgx_dg_operator_t op, double *shape_values, double *quadrature_points,
+                          double *quadrature_weights);
+
 /* ---- MultigridSolverDG<3,p,Number,double> (common/multigrid_solver_dg.h:55-747): the DG level on top
  * of the FE_Q(p) multigrid hierarchy of the same mesh ---- */
 typedef struct mgx_dg_solver_s *mgx_dg_solver_t;

@@ -801,6 +801,14 @@ class DGLaplaceOperator:
             solution.ptr, solution_old.ptr = solution_old.ptr, solution.ptr
             solution.owned, solution_old.owned = solution_old.owned, solution.owned
 
+    def basis_1d(self):
+        """(shape values [q, i] in the Gauss points, Gauss points, Gauss weights) on [0, 1]"""
+        n = self.degree + 1
+        S, x, w = np.empty((n, n)), np.empty(n), np.empty(n)
+        check(self.lib.mgx_dg_operator_basis(self.h, S.ctypes.data_as(_lib.f64p), x.ctypes.data_as(_lib.f64p),
+                                             w.ctypes.data_as(_lib.f64p)))
+        return S, x, w
+
     def info(self):
         hd = C.c_double()
         pen = (C.c_double * 3)()

@@ -211,6 +211,7 @@ SIGNATURES = {
     "mgx_dg_jacobi_vmult": (C.c_int, [vp, vp, vp]),
     "mgx_dg_vmult_with_chebyshev_update": (C.c_int, [vp, vp, C.c_uint, C.c_double, C.c_double, vp, vp]),
     "mgx_dg_operator_info": (C.c_int, [vp, f64p, f64p, f64p]),
+    "mgx_dg_operator_basis": (C.c_int, [vp, f64p, f64p, f64p]),
     "mgx_dg_solver_create": (C.c_int, [vp, C.POINTER(DGSolverDesc), C.POINTER(vp)]),
     "mgx_dg_solver_destroy": (C.c_int, [vp]),
     "mgx_dg_solver_smoother_info": (C.c_int, [vp, C.POINTER(SmootherInfo)]),

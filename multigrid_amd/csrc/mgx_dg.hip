@@ -1410,6 +1410,21 @@ int mgx_dg_operator_info(mgx_dg_operator_t op, double *hderiv, double penalty[3]
   return MGX_OK;
 }
 
+int mgx_dg_operator_basis(mgx_dg_operator_t op, double *shape_values, double *quadrature_points,
+                          double *quadrature_weights)
+{
+  if (!op)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_basis: null operator");
+  const int n = op->h.n;
+  if (shape_values)
+    std::copy(op->h.S.begin(), op->h.S.begin() + n * n, shape_values);
+  if (quadrature_points)
+    std::copy(op->h.xq.begin(), op->h.xq.begin() + n, quadrature_points);
+  if (quadrature_weights)
+    std::copy(op->h.wq.begin(), op->h.wq.begin() + n, quadrature_weights);
+  return MGX_OK;
+}
+
 int mgx_dg_cheby_mesh(int n_cell_steps, int cells[3], double jacobian[9])
 {
   if (n_cell_steps < 0 || n_cell_steps > 30 || !cells || !jacobian)

@@ -125,3 +125,22 @@ def test_dg_v_cycle_and_pcg_mixed_precision(ctx, p, nr, basis):
     assert abs(its - oits) <= 1 and red == pytest.approx(ored, rel=0.05)
     assert rel(P.to_oracle(sol.download()), xo) < 1e-6
     P.close()
+
+
+def test_poisson_dg_harness_runs():
+    """tools/poisson_dg.py (poisson_dg/program.cc): converges in a mesh-independent number of iterations
+    and prints the reference's table row"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = []
+    for nr in (2, 3):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "poisson_dg.py"), "3", str(nr)], cwd=root,
+                             capture_output=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = out.stdout.decode().strip().splitlines()
+        assert lines[-2].split() == "cells dofs mv_outer mv_inner cg_L2error cg_time cg_its cg_reduction".split()
+        rows.append(lines[-1].split())
+    assert int(rows[0][0]) == 64 and int(rows[1][0]) == 512 and int(rows[1][1]) == 512 * 64
+    assert 5 <= int(rows[0][6]) <= 10 and 5 <= int(rows[1][6]) <= 10
