@@ -84,7 +84,11 @@ namespace
     static constexpr int PX   = (N % 2 == 0) ? N + 1 : N; // odd row pitch: conflict-free x-lines
     static constexpr int VOL  = N * N * PX;
     static constexpr int FS   = N * PX;
-    static constexpr int CELL = 3 * VOL + 24 * FS;
+    // per-cell LDS stride: congruent to the threads per cell modulo the 32 banks (of 4 B for fp32,
+    // of 8 B for fp64 accesses), so that accesses of the form "thread index + constant" (z-lines,
+    // face points) of neighbouring cells in one half-wave fall on consecutive banks
+    static constexpr int CELL0 = 3 * VOL + 24 * FS;
+    static constexpr int CELL  = CELL0 + (((NN2 - CELL0) % 32) + 32) % 32;
     static constexpr int CPW_T = 256 / NN2;
     static constexpr int CPW_L = 65536 / (CELL * (int)sizeof(T));
     static constexpr int CPW   = CPW_T < CPW_L ? CPW_T : CPW_L;

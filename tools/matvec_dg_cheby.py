@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--bases", default="0,1,2")
     ap.add_argument("--outer", type=int, default=5)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="also time the numpy restatement (oracle/dg_oracle.py, the checker of tests/) on a bounded sample "
+                         "on the host: a reported baseline, not the target")
     a = ap.parse_args()
     number = mg.F32 if a.number == "f32" else mg.F64
     nbytes = 4 if number == mg.F32 else 8
@@ -109,8 +112,32 @@ def main():
         for v in (rhs, inp, out):
             v.free()
         op.clear()
+    cpu = None
+    if a.cpu_baseline:
+        from oracle import dg_oracle as dgo
+        ccells = (16, 16, 8)
+        orc = dgo.DGOracle(a.degree, 0, ccells, dgo.cheby_mesh(11)[1])
+        shape = orc.shape
+        r, x, xo = (rng.random(shape) for _ in range(3))
+        orc.vmult_with_chebyshev_update(r, 2, 0.6, 0.2, x, xo)  # builds the cached inverse diagonals
+        t, reps = time.perf_counter(), 0
+        while time.perf_counter() - t < 10.0:
+            x, xo = orc.vmult_with_chebyshev_update(r, 2, 0.6, 0.2, x, xo)
+            reps += 1
+        dt = (time.perf_counter() - t) / reps
+        nd = int(np.prod(shape))
+        try:
+            from threadpoolctl import threadpool_info
+            cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        except Exception:  # noqa: BLE001
+            cores = os.cpu_count() or 1
+        cpu = dict(value=nd / dt, unit="DoFs/s", cores=cores, kind="port",
+                   sample="FE_DGQHermite(%d) on %dx%dx%d cells (%d DoFs), %d merged Chebyshev steps of the dense numpy "
+                          "restatement (fp64), %.1f s" % (a.degree, *ccells, nd, reps, dt * reps))
+        print("CPU baseline (numpy restatement, %d BLAS threads): %.3e DoFs/s  [%s]" % (cores, cpu["value"], cpu["sample"]))
     if a.json:
-        print(json.dumps(dict(metric="DoFs/s, DG-SIP matvec merged with a Chebyshev update", results=results)))
+        print(json.dumps(dict(metric="DoFs/s, DG-SIP matvec merged with a Chebyshev update", results=results,
+                              cpu_baseline=cpu)))
     ctx.close()
 
 
