@@ -30,6 +30,23 @@ extern "C" {
 
 typedef struct mgx_dg_operator_s *mgx_dg_operator_t;
 
+/* Ghost-cell exchange of a decomposed DG mesh (replaces the MPI_Isend / MPI_Irecv of face data,
+ * laplace_operator_dg.h:986-1057, and the send lists built at :607-723).  A rank stores its owned
+ * cells first and, behind them, one copy of every cell of another rank that shares a face with an
+ * owned cell ("ghost cells", whole cells in this slice -- the reference sends two node layers for
+ * the Hermite-like basis); neighbour-table entries >= n_cells address them.  Ghosts of one rank
+ * are contiguous.  Both sides of a pair exchange the same number of cells (true for block
+ * decompositions; checked). */
+typedef struct
+{
+  int                    plan_id;
+  int                    n_neighbors;
+  const int             *neighbor_rank; /* ascending */
+  const uint32_t        *count;         /* cells sent to = received from neighbour k */
+  const uint32_t *const *send_cells;    /* owned cells to send, in the order the neighbour stores them */
+  const uint32_t        *recv_first;    /* first ghost cell (>= n_cells) filled by neighbour k */
+} mgx_dg_exchange_desc;
+
 typedef struct
 {
   int      degree;             /* 1 .. MGX_MAX_DEGREE */
@@ -43,6 +60,11 @@ typedef struct
   /* the one cell Jacobian dx/dxi, row-major [real][reference]; the reference asserts a single
    * Jacobian for the whole mesh as well (laplace_operator_dg.h:749-750) */
   double jacobian[9];
+  /* decomposed mesh (one rank per GPU; the context carries the communicator, mgx.h): number of
+   * ghost cells and their exchange; 0 / NULL on a single rank.  Vectors then hold
+   * (n_cells + n_ghost_cells) (p+1)^3 entries, owned cells first, like deal.II's owned | ghost layout */
+  uint32_t                    n_ghost_cells;
+  const mgx_dg_exchange_desc *exchange;
 } mgx_dg_operator_desc;
 
 /* LaplaceOperatorCompactCombine::reinit (:361-771) + JacobiTransformed::JacobiTransformed
@@ -54,6 +76,13 @@ int mgx_dg_operator_destroy(mgx_dg_operator_t op);
 
 /* LaplaceOperatorCompactCombine::m (:796-800) */
 uint64_t mgx_dg_operator_n_dofs(mgx_dg_operator_t op);
+
+/* entries of a vector including the ghost cells (== mgx_dg_operator_n_dofs on a single rank) */
+uint64_t mgx_dg_operator_vector_size(mgx_dg_operator_t op);
+/* Vector::update_ghost_values (the import of laplace_operator_dg.h:986-1057): fills the ghost cells
+ * of vec from their owners.  Every operator application below does this for its source vector
+ * (whose ghost part is therefore written although the argument is const). */
+int mgx_dg_update_ghost_values(mgx_dg_operator_t op, void *vec);
 
 /* LaplaceOperatorCompactCombine::vmult (:802-806, action 0).  dst must not alias src. */
 int mgx_dg_vmult(mgx_dg_operator_t op, void *dst, const void *src);

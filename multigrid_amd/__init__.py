@@ -21,7 +21,7 @@ from ._lib import F32, F64, INVALID_INDEX, MgxError, check
 
 __all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
            "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError", "DGLaplaceOperator", "dg_cheby_mesh",
-           "dg_box_neighbours", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver"]
+           "dg_box_neighbours", "dg_box_partition", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver"]
 
 
 def process_grid(size):
@@ -761,11 +761,71 @@ def dg_box_neighbours(cells, ordering="z"):
     return nb, ijk
 
 
+def dg_box_partition(cells, procs, rank, ordering="z"):
+    """Block decomposition of a box of cells over a process grid (the DG counterpart of the Cube
+    provider's decomposition; stands in for the p4est partition of the reference).  Returns a dict:
+    neighbours [n_owned, 6] (entries >= n_owned: ghost cells, -1: boundary), ijk [n_owned, 3] global
+    positions of the owned cells in local order, n_ghost, and exchange = [(rank, send_cells,
+    recv_first, count)] in ascending rank order; ghosts of one rank and the cells sent to it are in
+    ascending global lexicographic order on both sides."""
+    cells, procs = np.asarray(cells), np.asarray(procs)
+    assert (cells % procs == 0).all(), "the process grid must divide the cells"
+    blk = cells // procs
+    r3 = np.array([rank % procs[0], (rank // procs[0]) % procs[1], rank // (procs[0] * procs[1])])
+    lo = r3 * blk
+    loc = np.stack(np.meshgrid(np.arange(blk[0]), np.arange(blk[1]), np.arange(blk[2]), indexing="ij"), -1).reshape(-1, 3)
+    if ordering == "z":
+        def spread(v):
+            out = np.zeros_like(v, dtype=np.int64)
+            for bit in range(21):
+                out |= ((v >> bit) & 1) << (3 * bit)
+            return out
+        key = spread(loc[:, 0]) | (spread(loc[:, 1]) << 1) | (spread(loc[:, 2]) << 2)
+    else:
+        key = loc[:, 0] + blk[0] * (loc[:, 1] + blk[1] * loc[:, 2])
+    loc = loc[np.argsort(key, kind="stable")]
+    ijk = loc + lo
+    n_owned = len(ijk)
+    gid = lambda p: p[..., 0] + cells[0] * (p[..., 1] + cells[1] * p[..., 2])   # noqa: E731
+    owner = lambda p: (p[..., 0] // blk[0]) + procs[0] * ((p[..., 1] // blk[1]) + procs[1] * (p[..., 2] // blk[2]))  # noqa: E731
+    index_of = {int(g): i for i, g in enumerate(gid(ijk))}
+    ghosts, sends = {}, {}
+    for d in range(3):
+        for s in (-1, 1):
+            q = ijk.copy()
+            q[:, d] += s
+            ok = (q[:, d] >= 0) & (q[:, d] < cells[d])
+            own = owner(np.where(ok[:, None], q, ijk))
+            for i in np.nonzero(ok & (own != rank))[0]:
+                ghosts.setdefault(int(own[i]), set()).add(int(gid(q[i])))
+                sends.setdefault(int(own[i]), set()).add(int(gid(ijk[i])))
+    exchange, ghost_index, first = [], {}, n_owned
+    for rk in sorted(ghosts):
+        gl, sl = sorted(ghosts[rk]), sorted(sends[rk])
+        assert len(gl) == len(sl)
+        for g in gl:
+            ghost_index[g] = first + len(ghost_index)
+        exchange.append((rk, np.array([index_of[g] for g in sl], dtype=np.uint32), first + len(ghost_index) - len(gl), len(gl)))
+    nb = np.full((n_owned, 6), -1, dtype=np.int32)
+    for d in range(3):
+        for side, s in enumerate((-1, 1)):
+            q = ijk.copy()
+            q[:, d] += s
+            ok = (q[:, d] >= 0) & (q[:, d] < cells[d])
+            g = gid(q)
+            for i in np.nonzero(ok)[0]:
+                gi = int(g[i])
+                nb[i, 2 * d + side] = index_of[gi] if gi in index_of else ghost_index[gi]
+    return dict(neighbours=nb, ijk=ijk.astype(np.int32), n_ghost=len(ghost_index), exchange=exchange)
+
+
 class DGLaplaceOperator:
     """multigrid::LaplaceOperatorCompactCombine<3,p,Number,type> with its JacobiTransformed
     preconditioner (common/laplace_operator_dg.h:350-2256) on an affine mesh."""
 
-    def __init__(self, ctx, degree, basis, neighbours, jacobian, number=F32):
+    def __init__(self, ctx, degree, basis, neighbours, jacobian, number=F32, n_ghost=0, exchange=None, plan_id=77):
+        """n_ghost / exchange: decomposed mesh as dg_box_partition() describes it (the context then
+        needs a Communicator)"""
         self.ctx, self.lib = ctx, ctx.lib
         self.degree, self.basis, self.number = degree, basis, number
         nb = np.ascontiguousarray(neighbours, dtype=np.int32).reshape(-1, 6)
@@ -773,15 +833,40 @@ class DGLaplaceOperator:
         d.degree, d.basis, d.number, d.n_cells = degree, basis, number, nb.shape[0]
         d.neighbours = nb.ctypes.data_as(C.POINTER(C.c_int32))
         d.jacobian = (C.c_double * 9)(*np.asarray(jacobian, dtype=float).ravel())
+        d.n_ghost_cells = n_ghost
+        if n_ghost:
+            k = len(exchange)
+            ranks = (C.c_int * k)(*[e[0] for e in exchange])
+            counts = (C.c_uint32 * k)(*[e[3] for e in exchange])
+            first = (C.c_uint32 * k)(*[e[2] for e in exchange])
+            lists = [np.ascontiguousarray(e[1], dtype=np.uint32) for e in exchange]
+            ptrs = (_lib.u32p * k)(*[a.ctypes.data_as(_lib.u32p) for a in lists])
+            ex = _lib.DGExchangeDesc(plan_id, k, C.cast(ranks, C.POINTER(C.c_int)), C.cast(counts, _lib.u32p),
+                                     C.cast(ptrs, C.POINTER(_lib.u32p)), C.cast(first, _lib.u32p))
+            d.exchange = C.pointer(ex)
         h = C.c_void_p()
         check(self.lib.mgx_dg_operator_create(ctx.h, C.byref(d), C.byref(h)))
         self.h = h
 
     def m(self):
+        """owned DoFs of this rank"""
         return int(self.lib.mgx_dg_operator_n_dofs(self.h))
 
+    def vector_size(self):
+        """entries of a vector: owned cells, then ghost cells"""
+        return int(self.lib.mgx_dg_operator_vector_size(self.h))
+
     def initialize_dof_vector(self, data=None):
-        return self.ctx.vector(self.m(), self.number, data)
+        """data: values of the owned DoFs"""
+        v = self.ctx.vector(self.vector_size(), self.number)
+        if data is not None:
+            a = np.zeros(self.vector_size(), dtype=_DT[self.number])
+            a[:self.m()] = np.asarray(data).ravel()
+            v.upload(a)
+        return v
+
+    def update_ghost_values(self, v):
+        check(self.lib.mgx_dg_update_ghost_values(self.h, v.ptr))
 
     def vmult(self, dst, src):
         check(self.lib.mgx_dg_vmult(self.h, dst.ptr, src.ptr))

@@ -51,9 +51,15 @@ class OperatorDesc(C.Structure):
                 ("exchange", C.POINTER(ExchangeDesc)), ("coef_q", f64p)]
 
 
+class DGExchangeDesc(C.Structure):
+    _fields_ = [("plan_id", C.c_int), ("n_neighbors", C.c_int), ("neighbor_rank", C.POINTER(C.c_int)),
+                ("count", u32p), ("send_cells", C.POINTER(u32p)), ("recv_first", u32p)]
+
+
 class DGOperatorDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("basis", C.c_int), ("number", C.c_int), ("n_cells", C.c_uint32),
-                ("neighbours", C.POINTER(C.c_int32)), ("jacobian", C.c_double * 9)]
+                ("neighbours", C.POINTER(C.c_int32)), ("jacobian", C.c_double * 9),
+                ("n_ghost_cells", C.c_uint32), ("exchange", C.POINTER(DGExchangeDesc))]
 
 
 class DGSolverDesc(C.Structure):
@@ -206,6 +212,8 @@ SIGNATURES = {
     "mgx_dg_operator_create": (C.c_int, [vp, C.POINTER(DGOperatorDesc), C.POINTER(vp)]),
     "mgx_dg_operator_destroy": (C.c_int, [vp]),
     "mgx_dg_operator_n_dofs": (C.c_uint64, [vp]),
+    "mgx_dg_operator_vector_size": (C.c_uint64, [vp]),
+    "mgx_dg_update_ghost_values": (C.c_int, [vp, vp]),
     "mgx_dg_vmult": (C.c_int, [vp, vp, vp]),
     "mgx_dg_vmult_residual": (C.c_int, [vp, vp, vp, vp]),
     "mgx_dg_jacobi_vmult": (C.c_int, [vp, vp, vp]),

@@ -629,6 +629,39 @@ namespace
   }
 } // namespace
 
+// Point-to-point exchange of packed device buffers with the context's transport (native RCCL group
+// on the stream, or the blocking callback), for the parts of the ABI implemented in other
+// translation units (the DG ghost-cell update); allreduce of a few host doubles likewise
+int mgx::exchange_buffers(mgx_context_t ctx, int plan_id, int number, int n_neighbors, const int *ranks,
+                          const uint32_t *counts, void *const *send, void *const *recv)
+{
+  MGX_REQUIRE(ctx && ctx->has_comm, "exchange_buffers: no communicator on this context");
+  hipStream_t s = ctx->stream;
+  if (ctx->use_rccl)
+    {
+      RcclApi             &R  = rccl_api();
+      const ncclDataType_t dt = number == MGX_F64 ? ncclDouble : ncclFloat;
+      const bool           to_self = ctx->tun.rccl_selftest && ctx->rccl_size == 1;
+      bool                 ok = R.GroupStart() == ncclSuccess;
+      for (int k = 0; ok && k < n_neighbors; ++k)
+        {
+          const int peer = to_self ? 0 : ranks[k];
+          ok = ok && R.Send(send[k], counts[k], dt, peer, ctx->nccl, s) == ncclSuccess;
+          ok = ok && R.Recv(recv[k], counts[k], dt, peer, ctx->nccl, s) == ncclSuccess;
+        }
+      ok = (R.GroupEnd() == ncclSuccess) && ok;
+      return ok ? MGX_OK : fail(MGX_ERR_HIP, "RCCL exchange failed");
+    }
+  MGX_HIP(hipStreamSynchronize(s));
+  if (!ctx->comm.exchange || ctx->comm.exchange(ctx->comm.user, plan_id, number, n_neighbors, ranks, counts, send, recv) != 0)
+    return fail(MGX_ERR_HIP, "exchange callback failed");
+  return MGX_OK;
+}
+
+int mgx::allreduce_sum(mgx_context_t ctx, double *values, int count) { return comm_allreduce(ctx, values, count); }
+
+bool mgx::context_has_comm(mgx_context_t ctx) { return ctx && ctx->has_comm; }
+
 extern "C" {
 
 const char *mgx_last_error(void) { return g_last_error.c_str(); }

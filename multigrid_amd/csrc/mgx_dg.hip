@@ -1193,6 +1193,14 @@ struct mgx_dg_operator_s
   void         *inv_diag = nullptr; // device [64][(p+1)^3]
   Host1D        h;
   Geometry      g;
+  // decomposed mesh: ghost cells behind the owned ones, filled from their owners before every
+  // application (mgx_dg_update_ghost_values)
+  uint32_t                n_ghost = 0;
+  int                     plan_id = 0;
+  std::vector<int>        nb_rank;
+  std::vector<uint32_t>   nb_count, nb_recv_first, nb_entries;
+  std::vector<uint32_t *> nb_cells_dev;
+  std::vector<void *>     nb_send;
 };
 
 // MultigridSolverDG (common/multigrid_solver_dg.h:55-747): the DG level on top of an FE_Q hierarchy
@@ -1234,6 +1242,45 @@ namespace
     }                    \
   while (0)
 
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_pack_cells(T *__restrict__ buf, const T *__restrict__ vec, const uint32_t *__restrict__ cells, uint32_t count,
+                 uint32_t n3)
+  {
+    const uint64_t total = (uint64_t)count * n3;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+      {
+        const uint32_t c = (uint32_t)(i / n3), k = (uint32_t)(i - (uint64_t)c * n3);
+        buf[i] = vec[(uint64_t)cells[c] * n3 + k];
+      }
+  }
+
+  int update_ghosts(mgx_dg_operator_t op, void *vec)
+  {
+    if (op->n_ghost == 0)
+      return MGX_OK;
+    hipStream_t    s   = (hipStream_t)mgx_context_stream(op->ctx);
+    const uint32_t n3  = (uint32_t)(op->degree + 1) * (op->degree + 1) * (op->degree + 1);
+    const size_t   es  = op->number == MGX_F64 ? 8 : 4;
+    const int      nnb = (int)op->nb_rank.size();
+    std::vector<void *> recv(nnb);
+    for (int k = 0; k < nnb; ++k)
+      {
+        const uint64_t total = (uint64_t)op->nb_count[k] * n3;
+        const uint32_t grid  = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
+        if (op->number == MGX_F64)
+          hipLaunchKernelGGL(k_pack_cells<double>, dim3(grid), dim3(256), 0, s, (double *)op->nb_send[k], (const double *)vec,
+                             op->nb_cells_dev[k], op->nb_count[k], n3);
+        else
+          hipLaunchKernelGGL(k_pack_cells<float>, dim3(grid), dim3(256), 0, s, (float *)op->nb_send[k], (const float *)vec,
+                             op->nb_cells_dev[k], op->nb_count[k], n3);
+        recv[k] = (char *)vec + (size_t)op->nb_recv_first[k] * n3 * es; // straight into the ghost cells
+      }
+    DG_HIP(hipGetLastError());
+    return mgx::exchange_buffers(op->ctx, op->plan_id, op->number, nnb, op->nb_rank.data(), op->nb_entries.data(),
+                                 op->nb_send.data(), recv.data());
+  }
+
   int run(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
           int iteration_index)
   {
@@ -1274,17 +1321,42 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
   const uint64_t n3 = (uint64_t)(desc->degree + 1) * (desc->degree + 1) * (desc->degree + 1);
   if ((uint64_t)desc->n_cells * n3 * (desc->number == MGX_F64 ? 8 : 4) >= (1ull << 40))
     return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: vector larger than 1 TiB");
+  const uint64_t n_all = (uint64_t)desc->n_cells + desc->n_ghost_cells;
+  if (n_all * n3 >= (1ull << 32))
+    return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: more than 2^32 vector entries per rank");
   for (uint64_t i = 0; i < (uint64_t)desc->n_cells * 6; ++i)
-    if (desc->neighbours[i] != MGX_DG_BOUNDARY &&
-        (desc->neighbours[i] < 0 || (uint32_t)desc->neighbours[i] >= desc->n_cells))
+    if (desc->neighbours[i] != MGX_DG_BOUNDARY && (desc->neighbours[i] < 0 || (uint64_t)desc->neighbours[i] >= n_all))
       return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: neighbour entry " + std::to_string(i) +
-                                                 " is neither a cell of the mesh nor MGX_DG_BOUNDARY");
+                                                 " is neither a cell of the mesh, a ghost cell nor MGX_DG_BOUNDARY");
+  if (desc->n_ghost_cells > 0)
+    {
+      if (!desc->exchange || !mgx::context_has_comm(ctx))
+        return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: ghost cells need an exchange plan and a "
+                                                 "communicator on the context");
+      const mgx_dg_exchange_desc &e = *desc->exchange;
+      uint64_t                    covered = 0;
+      for (int k = 0; k < e.n_neighbors; ++k)
+        {
+          if (k > 0 && e.neighbor_rank[k] <= e.neighbor_rank[k - 1])
+            return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: neighbour ranks must be ascending");
+          if (e.recv_first[k] < desc->n_cells || (uint64_t)e.recv_first[k] + e.count[k] > n_all)
+            return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: ghost range outside the ghost cells");
+          for (uint32_t i = 0; i < e.count[k]; ++i)
+            if (e.send_cells[k][i] >= desc->n_cells)
+              return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: only owned cells can be sent");
+          covered += e.count[k];
+        }
+      if (covered != desc->n_ghost_cells)
+        return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: the exchange plan does not fill every ghost cell "
+                                                 "exactly once");
+    }
   std::unique_ptr<mgx_dg_operator_s> op(new mgx_dg_operator_s);
   op->ctx     = ctx;
   op->degree  = desc->degree;
   op->basis   = desc->basis;
   op->number  = desc->number;
   op->n_cells = desc->n_cells;
+  op->n_ghost = desc->n_ghost_cells;
   std::string why;
   int         status = build_1d(desc->degree, desc->basis, op->h, why);
   if (status == MGX_OK)
@@ -1309,6 +1381,10 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
     (void)hipFree(op->neigh);
     (void)hipFree(op->consts);
     (void)hipFree(op->inv_diag);
+    for (auto *p : op->nb_cells_dev)
+      (void)hipFree(p);
+    for (auto *p : op->nb_send)
+      (void)hipFree(p);
   };
 #define DG_HIP_C(call)                                                                      \
   do                                                                                        \
@@ -1324,6 +1400,25 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
   DG_HIP_C(hipMalloc((void **)&op->neigh, sizeof(int32_t) * 6 * (size_t)desc->n_cells));
   DG_HIP_C(hipMemcpyAsync(op->neigh, desc->neighbours, sizeof(int32_t) * 6 * (size_t)desc->n_cells,
                           hipMemcpyHostToDevice, s));
+  if (op->n_ghost > 0)
+    {
+      const mgx_dg_exchange_desc &e = *desc->exchange;
+      op->plan_id                   = e.plan_id;
+      for (int k = 0; k < e.n_neighbors; ++k)
+        {
+          op->nb_rank.push_back(e.neighbor_rank[k]);
+          op->nb_count.push_back(e.count[k]);
+          op->nb_entries.push_back((uint32_t)((uint64_t)e.count[k] * n3));
+          op->nb_recv_first.push_back(e.recv_first[k]);
+          uint32_t *cells = nullptr;
+          void     *buf   = nullptr;
+          DG_HIP_C(hipMalloc((void **)&cells, sizeof(uint32_t) * ((size_t)e.count[k] + 1)));
+          op->nb_cells_dev.push_back(cells);
+          DG_HIP_C(hipMemcpyAsync(cells, e.send_cells[k], sizeof(uint32_t) * e.count[k], hipMemcpyHostToDevice, s));
+          DG_HIP_C(hipMalloc(&buf, nsz * ((size_t)e.count[k] * n3 + 1)));
+          op->nb_send.push_back(buf);
+        }
+    }
   DG_HIP_C(hipMalloc(&op->inv_diag, nsz * table.size()));
   if (desc->number == MGX_F64)
     {
@@ -1357,8 +1452,24 @@ int mgx_dg_operator_destroy(mgx_dg_operator_t op)
   (void)hipFree(op->neigh);
   (void)hipFree(op->consts);
   (void)hipFree(op->inv_diag);
+  for (auto *p : op->nb_cells_dev)
+    (void)hipFree(p);
+  for (auto *p : op->nb_send)
+    (void)hipFree(p);
   delete op;
   return MGX_OK;
+}
+
+uint64_t mgx_dg_operator_vector_size(mgx_dg_operator_t op)
+{
+  return op ? ((uint64_t)op->n_cells + op->n_ghost) * (op->degree + 1) * (op->degree + 1) * (op->degree + 1) : 0;
+}
+
+int mgx_dg_update_ghost_values(mgx_dg_operator_t op, void *vec)
+{
+  if (!op || !vec)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_update_ghost_values: null argument");
+  return update_ghosts(op, vec);
 }
 
 uint64_t mgx_dg_operator_n_dofs(mgx_dg_operator_t op)
@@ -1370,6 +1481,7 @@ int mgx_dg_vmult(mgx_dg_operator_t op, void *dst, const void *src)
 {
   if (!op || !dst || !src || dst == src)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult: null or aliased vectors");
+  MGX_DG_TRY(update_ghosts(op, const_cast<void *>(src)));
   return run(op, kVmult, dst, nullptr, src, 0, 0, 0);
 }
 
@@ -1377,6 +1489,7 @@ int mgx_dg_vmult_residual(mgx_dg_operator_t op, void *dst, const void *rhs, cons
 {
   if (!op || !dst || !src || !rhs || dst == src)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_residual: null or aliased vectors");
+  MGX_DG_TRY(update_ghosts(op, const_cast<void *>(src)));
   return run(op, kResidual, dst, rhs, src, 0, 0, 0);
 }
 
@@ -1396,6 +1509,7 @@ int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, un
     return run(op, kJacobi, solution, nullptr, rhs, 0, factor2, 0);
   if (!solution_old || solution_old == solution)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_with_chebyshev_update: solution_old is null or aliases solution");
+  MGX_DG_TRY(update_ghosts(op, solution));
   return run(op, kChebyshev, solution_old, rhs, solution, factor1, factor2, (int)iteration_index);
 }
 

@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <vector>
 
+struct mgx_context_s;
+
 namespace mgx
 {
   constexpr int      kMaxN    = 10; // p <= 9
@@ -134,6 +136,14 @@ namespace mgx
     uint32_t            n_cus = 256;
     uint32_t            colour_min = 16384; // Tunables::restrict_colour_min
   };
+
+  // transport of the context (mgx_api.cpp) for other translation units: exchange of packed device
+  // buffers (counts[k] entries of `number` type with rank ranks[k], both directions), sum of a few
+  // host doubles over the ranks (no-op on a single rank)
+  int  exchange_buffers(struct ::mgx_context_s *ctx, int plan_id, int number, int n_neighbors, const int *ranks,
+                        const uint32_t *counts, void *const *send, void *const *recv);
+  int  allreduce_sum(struct ::mgx_context_s *ctx, double *values, int count);
+  bool context_has_comm(struct ::mgx_context_s *ctx);
 
   // records the message mgx_last_error() returns on the calling thread; returns `code` (used by the
   // translation units that implement parts of the C ABI outside mgx_api.cpp)

@@ -15,7 +15,7 @@ from oracle import Oracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(mode, world, p, nr, timeout=600, extra=()):
+def launch(mode, world, p, nr, timeout=600, extra=(), worker="dist_worker.py"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -24,9 +24,9 @@ def launch(mode, world, p, nr, timeout=600, extra=()):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(p),
-                                       str(nr)] + list(extra), env=env, cwd=ROOT, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT))
+        argv = [mode, str(p), str(nr)] if worker == "dist_worker.py" else []
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker)] + argv + list(extra), env=env,
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for pr in procs:
         try:

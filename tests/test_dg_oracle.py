@@ -110,3 +110,15 @@ def test_block_jacobi_is_the_inverse_of_the_transformed_diagonal():
     assert np.allclose(new1, 0.2 * o.jacobi_vmult(rhs - o.vmult(x)) + 1.6 * x)
     new0, _ = o.vmult_with_chebyshev_update(rhs, 0, 0.6, 0.2, x, xo)
     assert np.allclose(new0, 0.2 * o.jacobi_vmult(rhs))
+
+
+def test_partition_of_a_box_is_consistent():
+    multigrid_amd = pytest.importorskip("multigrid_amd")
+    cells, procs = (8, 4, 4), (2, 2, 2)
+    parts = [multigrid_amd.dg_box_partition(cells, procs, r) for r in range(8)]
+    assert sum(len(q["ijk"]) for q in parts) == 128
+    for r, q in enumerate(parts):
+        assert q["neighbours"].max() < len(q["ijk"]) + q["n_ghost"]
+        for (rk, send, first, cnt) in q["exchange"]:
+            back = [e for e in parts[rk]["exchange"] if e[0] == r]
+            assert len(back) == 1 and back[0][3] == cnt and len(send) == cnt

@@ -173,3 +173,14 @@ def test_errors_are_reported():
         op.vmult(v, v)
     op.clear()
     c.close()
+
+
+@pytest.mark.parametrize("world,p,basis,steps,number", [(2, 4, 0, 7, "f64"), (4, 3, 0, 7, "f64"), (2, 2, 2, 6, "f64"),
+                                                        (4, 4, 1, 8, "f32"), (2, 3, 0, 5, "f32")])
+def test_decomposed_operator_matches_single_domain_oracle(world, p, basis, steps, number):
+    """block decomposition with ghost cells (mgx_dg_exchange_desc; the reference's MPI face exchange,
+    laplace_operator_dg.h:986-1057): 2 and 4 ranks over gloo sharing the GPU"""
+    from test_decomposition import launch
+    outs = launch(None, world, None, None, extra=(str(p), str(basis), str(steps), number), worker="dg_dist_worker.py")
+    assert all("dg ok" in o for o in outs), outs
+

@@ -2,6 +2,11 @@
 with one Chebyshev update (block Jacobi in the eigenvector basis), three local bases, fp32.
 
     python tools/matvec_dg_cheby.py [degree=3] [n_refinement_steps=15] [nsteps=100] [--number f32|f64] [--json]
+                                    [--gpus N]
+
+--gpus N: the mesh is block-decomposed over N ranks (one process per GPU, started by this script or by
+torch.distributed.run), ghost cells exchanged over RCCL (MGX_BENCH_BACKEND=gloo: ranks share one GPU,
+functional test); rates are those of the whole job (global DoFs over the slowest rank's time).
 
 Same positional arguments as the reference program (program.cc:289-296) and the same result lines
 ("Best MF Chebyshev update <basis> n_dof= ... DoFs/s ... GFlop/s ... GB/s ... ops/dof", :171-187, and
@@ -46,27 +51,65 @@ def main():
     ap.add_argument("--bases", default="0,1,2")
     ap.add_argument("--outer", type=int, default=5)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--cpu-baseline", action="store_true",
                     help="also time the numpy restatement (oracle/dg_oracle.py, the checker of tests/) on a bounded sample "
                          "on the host: a reported baseline, not the target")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn(a.gpus)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    dist = comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            dist.init_process_group(backend)
     number = mg.F32 if a.number == "f32" else mg.F64
     nbytes = 4 if number == mg.F32 else 8
-    ctx = mg.Context(0)
+    ctx = mg.Context(local_rank)
     cells, jac = mg.dg_cheby_mesh(a.n_refinement_steps)
-    nb, _ = mg.dg_box_neighbours(cells)
-    n_cells = nb.shape[0]
-    print("Number of GPUs:                 1")
-    print("Degree of element:              %d" % a.degree)
-    print("Cells:                          %d x %d x %d, number type %s\n" % (*cells, a.number))
+    if world > 1:
+        comm = mg.Communicator(ctx, dist)
+        if comm.native_ready:  # RCCL send/recv issued by the library on its own stream
+            mg.check(ctx.lib.mgx_context_use_rccl(ctx.h, 1))
+        part = mg.dg_box_partition(cells, mg.process_grid(world), rank)
+        nb, n_ghost, exchange = part["neighbours"], part["n_ghost"], part["exchange"]
+    else:
+        nb, _ = mg.dg_box_neighbours(cells)
+        n_ghost, exchange = 0, None
+    n_cells = int(np.prod(cells))
+    say = print if rank == 0 else (lambda *args, **kw: None)
+
+    def slowest(t):
+        if dist is None:
+            return t
+        import torch
+        v = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    say("Number of GPUs:                 %d%s" % (world, "" if world == 1 else " (%s)" % ("native RCCL" if comm.native_ready
+                                                                                      else dist.get_backend())))
+    say("Degree of element:              %d" % a.degree)
+    say("Cells:                          %d x %d x %d, number type %s\n" % (*cells, a.number))
     results = []
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(rank)
     for kind in [int(k) for k in a.bases.split(",")]:
-        op = mg.DGLaplaceOperator(ctx, a.degree, kind, nb, jac, number)
-        n = op.m()
+        op = mg.DGLaplaceOperator(ctx, a.degree, kind, nb, jac, number, n_ghost, exchange)
+        n_own = op.m()
+        n = n_cells * (a.degree + 1) ** 3
         if kind == 0:
-            print("Number of DoFs: %d" % n)
-        rhs = op.initialize_dof_vector(rng.random(n))  # program.cc:106-107
+            say("Number of DoFs: %d" % n)
+        rhs = op.initialize_dof_vector(rng.random(n_own))  # program.cc:106-107
         inp, out = op.initialize_dof_vector(), op.initialize_dof_vector()
         best = 1e10
         for o in range(a.outer):
@@ -77,12 +120,12 @@ def main():
                 op.vmult_with_chebyshev_update(rhs, 2, 0.6, 0.2, out, inp)
                 out, inp = inp, out
             ctx.sync()
-            avg = (time.perf_counter() - t) / a.nsteps
-            print("MF Chebyshev update %12.4e" % avg)
+            avg = slowest((time.perf_counter() - t) / a.nsteps)
+            say("MF Chebyshev update %12.4e" % avg)
             best = min(best, avg)
         ops = ops_approx(n_cells, a.degree, kind)
         frac = 4 * nbytes * n / best / 8e12
-        print("Best MF Chebyshev update %s n_dof= %-12d%-12.4e   DoFs/s %.5e    GFlop/s %.1f    GB/s %.1f    ops/dof %.1f"
+        say("Best MF Chebyshev update %s n_dof= %-12d%-12.4e   DoFs/s %.5e    GFlop/s %.1f    GB/s %.1f    ops/dof %.1f"
               "    [4 accesses: %.1f GB/s = %.3f of 8 TB/s]\n"
               % (NAMES[kind], n, best, n / best, 1e-9 * ops / best, 1e-9 * n * nbytes * 5 / best, ops / n,
                  1e-9 * 4 * nbytes * n / best, frac))
@@ -94,8 +137,8 @@ def main():
         for _ in range(a.nsteps):
             op.vmult(out, inp)
         ctx.sync()
-        tv = (time.perf_counter() - t) / a.nsteps
-        print("MF vmult             %s n_dof= %-12d%-12.4e   DoFs/s %.5e    [2 accesses: %.3f of 8 TB/s]"
+        tv = slowest((time.perf_counter() - t) / a.nsteps)
+        say("MF vmult             %s n_dof= %-12d%-12.4e   DoFs/s %.5e    [2 accesses: %.3f of 8 TB/s]"
               % (NAMES[kind], n, tv, n / tv, 2 * nbytes * n / tv / 8e12))
         res.update(vmult_seconds=tv, vmult_dofs_per_s=n / tv)
         if kind == 2:
@@ -104,8 +147,8 @@ def main():
             for _ in range(a.nsteps):
                 op.jacobi_vmult(out, inp)
             ctx.sync()
-            tj = (time.perf_counter() - t) / a.nsteps
-            print("Best preconditioner  n_dof= %-12d%-12.4e   DoFs/s %.5e   GB/s %.1f\n"
+            tj = slowest((time.perf_counter() - t) / a.nsteps)
+            say("Best preconditioner  n_dof= %-12d%-12.4e   DoFs/s %.5e   GB/s %.1f\n"
                   % (n, tj, n / tj, 1e-9 * 4 * n * nbytes / tj))
             res.update(jacobi_seconds=tj)
         results.append(res)
@@ -113,7 +156,7 @@ def main():
             v.free()
         op.clear()
     cpu = None
-    if a.cpu_baseline:
+    if a.cpu_baseline and rank == 0:
         from oracle import dg_oracle as dgo
         ccells = (16, 16, 8)
         orc = dgo.DGOracle(a.degree, 0, ccells, dgo.cheby_mesh(11)[1])
@@ -135,10 +178,32 @@ def main():
                    sample="FE_DGQHermite(%d) on %dx%dx%d cells (%d DoFs), %d merged Chebyshev steps of the dense numpy "
                           "restatement (fp64), %.1f s" % (a.degree, *ccells, nd, reps, dt * reps))
         print("CPU baseline (numpy restatement, %d BLAS threads): %.3e DoFs/s  [%s]" % (cores, cpu["value"], cpu["sample"]))
-    if a.json:
-        print(json.dumps(dict(metric="DoFs/s, DG-SIP matvec merged with a Chebyshev update", results=results,
+    if a.json and rank == 0:
+        print(json.dumps(dict(metric="DoFs/s, DG-SIP matvec merged with a Chebyshev update", n_gpus=world, results=results,
                               cpu_baseline=cpu)))
     ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def spawn(n):
+    """start n ranks of this script (the parent never touches the GPU), relay rank 0's output"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    one_gpu = os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise SystemExit("matvec_dg_cheby.py: rank exit codes %s" % codes)
 
 
 if __name__ == "__main__":
