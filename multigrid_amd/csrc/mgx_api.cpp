@@ -984,7 +984,8 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       if (desc->constrained[i] >= desc->n_dofs)
         return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_operator_create: constrained index out of range");
   }
-  auto op          = std::make_unique<mgx_operator_s>();
+  // failures below return through the destroy function: device buffers allocated so far are freed
+  std::unique_ptr<mgx_operator_s, int (*)(mgx_operator_t)> op(new mgx_operator_s, mgx_operator_destroy);
   op->ctx          = ctx;
   {
     // (any order inside the list)
@@ -1641,12 +1642,22 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
   hipStream_t   s   = ctx->stream;
   const int     num = op->d.number;
   const size_t  n   = op->d.n_dofs, bytes = number_size(num) * n;
-  auto          sm  = std::make_unique<mgx_smoother_s>();
+  std::unique_ptr<mgx_smoother_s, int (*)(mgx_smoother_t)> sm(new mgx_smoother_s, mgx_smoother_destroy);
   sm->op            = op;
   MGX_HIP(hipMalloc(&sm->x_old, bytes));
   MGX_HIP(hipMalloc(&sm->tmp, bytes));
   // estimate_eigenvalues: PCG(D^-1) on v_i = (i mod 11) - mean; Lanczos tridiagonal
   void *r = nullptr, *z = nullptr, *d = nullptr, *h = sm->tmp, *x = sm->x_old;
+  struct Scratch
+  {
+    void *&a, *&b, *&c;
+    ~Scratch()
+    {
+      (void)hipFree(a);
+      (void)hipFree(b);
+      (void)hipFree(c);
+    }
+  } scratch{r, z, d};
   MGX_HIP(hipMalloc(&r, bytes));
   MGX_HIP(hipMalloc(&z, bytes));
   MGX_HIP(hipMalloc(&d, bytes));
@@ -1699,9 +1710,6 @@ int mgx_smoother_create(mgx_operator_t op, double smoothing_range, int degree, i
         }
     }
   MGX_HIP(hipStreamSynchronize(s));
-  MGX_HIP(hipFree(r));
-  MGX_HIP(hipFree(z));
-  MGX_HIP(hipFree(d));
   mgx_smoother_info &info = sm->info;
   info.cg_iterations      = it;
   if (diag.empty())

@@ -821,33 +821,38 @@ namespace
   }
 } // namespace
 
+namespace mgx
+{
+  int report_error(int code, const char *message); // mgx_api.cpp: message for mgx_last_error()
+}
+
 extern "C" {
 
 static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
 {
   const int degree = bd.degree, n_refine = bd.n_refine;
   if (!out || degree < 1 || degree > MGX_MAX_DEGREE || n_refine < 0 || n_refine > 9)
-    return MGX_ERR_INVALID_ARGUMENT;
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create: degree must be in 1..9 and n_refine in 0..9");
   uint64_t total = 1;
   int      size  = 1;
   for (int d = 0; d < 3; ++d)
     {
       if (bd.roots[d] < 1 || bd.procs[d] < 1 || bd.roots[d] % bd.procs[d] != 0)
-        return MGX_ERR_INVALID_ARGUMENT;
+        return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create: the process grid must divide the coarse cells");
       const uint64_t N = (uint64_t)bd.roots[d] << n_refine;
       if (N > 2047)
-        return MGX_ERR_UNSUPPORTED;
+        return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_create: more than 2047 cells per direction");
       total *= N * degree + 1;
       size *= bd.procs[d];
     }
   if (total >= 0xFFFFFFFFull)
-    return MGX_ERR_UNSUPPORTED; // 32-bit (global) DoF indices as in the reference's compressed table
+    return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_create: more than 2^32 global DoFs"); // 32-bit (global) DoF indices as in the reference's compressed table
   if (bd.rank < 0 || bd.rank >= size || !(bd.h0 > 0))
-    return MGX_ERR_INVALID_ARGUMENT;
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create: rank outside the process grid or h0 <= 0");
   if (bd.numbering != MGX_CUBE_NUMBERING_BRICK && bd.numbering != MGX_CUBE_NUMBERING_CELL)
-    return MGX_ERR_INVALID_ARGUMENT;
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create: unknown numbering");
   if (bd.geometry < 0 || bd.geometry > MGX_CUBE_GEOMETRY_SHELL_SECTOR || bd.problem < 0 || bd.problem > MGX_CUBE_PROBLEM_SHELL)
-    return MGX_ERR_INVALID_ARGUMENT;
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create: unknown geometry or problem");
   omp_set_num_threads(effective_threads());
   auto C    = std::make_unique<mgx_cube_s>();
   C->p      = degree;
@@ -1200,9 +1205,9 @@ int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int 
     }
   if (status != MGX_OK)
     {
-      std::string keep = mgx_last_error();
+      const std::string keep = mgx_last_error(); // the destroy calls below must not hide the cause
       mgx_cube_solver_destroy(out);
-      (void)keep;
+      mgx::report_error(status, keep.c_str());
     }
   return status;
 }
