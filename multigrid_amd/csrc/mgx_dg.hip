@@ -43,6 +43,7 @@ namespace
     T S[kMaxN * kMaxN];  // S[q*n+i]   element basis -> values in the Gauss points
     T D[kMaxN * kMaxN];  // D[q*n+r]   derivative of the Gauss-point Lagrange basis in the Gauss points
     T E[kMaxN * kMaxN];  // E[i*n+e]   eigenvector e of (Laplace + penalty, mass) in the element basis
+    T St[kMaxN * kMaxN], Dt[kMaxN * kMaxN], Et[kMaxN * kMaxN]; // their transposes (mul() reads these)
     T w[kMaxN];          // Gauss weights on [0,1]
     T b[2][kMaxN], g[2][kMaxN];   // Gauss-point Lagrange basis at x = 0 / 1: value, derivative
     T fb[2][kMaxN], fg[2][kMaxN]; // element basis at x = 0 / 1: value, derivative
@@ -112,34 +113,44 @@ namespace
       a[base + q * stride] = r[q];
   }
 
-  // out[q] = sum_i M[q*N+i] in[i]   (M wave-uniform: scalar loads)
-  template <int N, typename T>
-  __device__ __forceinline__ void mul(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
-  {
-#pragma unroll
-    for (int q = 0; q < N; ++q)
-      {
-        T s = M[q * N] * in[0];
-#pragma unroll
-        for (int i = 1; i < N; ++i)
-          s += M[q * N + i] * in[i];
-        out[q] = s;
-      }
-  }
-
-  // out[i] = sum_q M[q*N+i] in[q]
+  // out[i] = sum_q M[q*N+i] in[q]   (M wave-uniform: scalar loads).  Two neighbouring outputs share
+  // the input value and take two consecutive matrix entries: written on 2-vectors so that fp32
+  // becomes v_pk_fma_f32 with the matrix pair in a scalar register pair.
   template <int N, typename T>
   __device__ __forceinline__ void mul_t(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
   {
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int H = N / 2;
+    T2            acc[H > 0 ? H : 1];
+    T             last = 0;
 #pragma unroll
-    for (int i = 0; i < N; ++i)
+    for (int q = 0; q < N; ++q)
       {
-        T s = M[i] * in[0];
+        const T2 x = {in[q], in[q]};
 #pragma unroll
-        for (int q = 1; q < N; ++q)
-          s += M[q * N + i] * in[q];
-        out[i] = s;
+        for (int h = 0; h < H; ++h)
+          {
+            const T2 m = {M[q * N + 2 * h], M[q * N + 2 * h + 1]};
+            acc[h]     = q == 0 ? m * x : __builtin_elementwise_fma(m, x, acc[h]);
+          }
+        if (N % 2)
+          last = q == 0 ? M[N - 1] * in[0] : fma(M[q * N + N - 1], in[q], last);
       }
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      {
+        out[2 * h]     = acc[h][0];
+        out[2 * h + 1] = acc[h][1];
+      }
+    if (N % 2)
+      out[N - 1] = last;
+  }
+
+  // out[q] = sum_i M[q*N+i] in[i], given the transposed matrix Mt[i*N+q] = M[q*N+i]
+  template <int N, typename T>
+  __device__ __forceinline__ void mul(const T *__restrict__ Mt, const T (&in)[N], T (&out)[N])
+  {
+    mul_t<N, T>(Mt, in, out);
   }
 
   template <int N, typename T>
@@ -189,21 +200,21 @@ namespace
 #pragma unroll
         for (int k = 0; k < N; ++k)
           q[k] *= inv_diag[(k * N + b) * N + a];
-        mul<N>(c->E, q, r); // out[i] = sum_e E[i][e] q[e]
+        mul<N>(c->Et, q, r); // out[i] = sum_e E[i][e] q[e]
         st_line<N>(U, b * PX + a, N * PX, r);
       }
     __syncthreads();
     if (active)
       {
         ld_line<N>(U, b * N * PX + a, PX, q);
-        mul<N>(c->E, q, r);
+        mul<N>(c->Et, q, r);
         st_line<N>(U, b * N * PX + a, PX, r);
       }
     __syncthreads();
     if (active)
       {
         ld_line<N>(U, (b * N + a) * PX, 1, q);
-        mul<N>(c->E, q, r);
+        mul<N>(c->Et, q, r);
       }
   }
 
@@ -273,7 +284,7 @@ namespace
         for (int i = 0; i < N; ++i)
           xs[i] = src[cbase + (b * N + a) * N + i];
         if constexpr (TYPE != MGX_DG_GAUSS)
-          mul<N>(c->S, xs, u);
+          mul<N>(c->St, xs, u);
         else
           copy_line<N>(xs, u);
         st_line<N>(U, (b * N + a) * PX, 1, u);
@@ -321,13 +332,13 @@ namespace
           {
             T u[N], v[N];
             ld_line<N>(U, b * N * PX + a, PX, u);
-            mul<N>(c->S, u, v);
+            mul<N>(c->St, u, v);
             st_line<N>(U, b * N * PX + a, PX, v);
             for (int L = t; L < 12 * N; L += NN2)
               {
                 T *arr = F + (12 + L / N) * FS + (L % N) * PX;
                 ld_line<N>(arr, 0, 1, u);
-                mul<N>(c->S, u, v);
+                mul<N>(c->St, u, v);
                 st_line<N>(arr, 0, 1, v);
               }
           }
@@ -342,12 +353,12 @@ namespace
         ld_line<N>(U, b * PX + a, N * PX, u);
         if constexpr (TYPE != MGX_DG_GAUSS)
           {
-            mul<N>(c->S, u, v);
+            mul<N>(c->St, u, v);
             st_line<N>(U, b * PX + a, N * PX, v);
           }
         else
           copy_line<N>(u, v);
-        mul<N>(c->D, v, u);
+        mul<N>(c->Dt, v, u);
         st_line<N>(GZ, b * PX + a, N * PX, u);
         Fo(4)[fidx] = dot_line<N>(c->b[0], v);
         Fo(5)[fidx] = dot_line<N>(c->b[1], v);
@@ -358,7 +369,7 @@ namespace
             {
               T *arr = F + (12 + L / N) * FS + (L % N);
               ld_line<N>(arr, 0, PX, u);
-              mul<N>(c->S, u, v);
+              mul<N>(c->St, u, v);
               st_line<N>(arr, 0, PX, v);
             }
       }
@@ -369,7 +380,7 @@ namespace
       {
         T u[N], v[N];
         ld_line<N>(U, b * N * PX + a, PX, u);
-        mul<N>(c->D, u, v);
+        mul<N>(c->Dt, u, v);
         st_line<N>(GY, b * N * PX + a, PX, v);
         Fo(2)[fidx] = dot_line<N>(c->b[0], u);
         Fo(3)[fidx] = dot_line<N>(c->b[1], u);
@@ -417,7 +428,7 @@ namespace
           ld_line<N>(Fo(f), l * PX, 1, st);
           ld_line<N>(Fe(f), l * PX, 1, wj);
           ld_line<N>(Fn(f), l * PX, 1, sn);
-          mul<N>(c->D, st, ds);
+          mul<N>(c->Dt, st, ds);
           mul_t<N>(c->D, wj, dj);
           const T wl = c->w[l] * c->fw[d];
 #pragma unroll
@@ -437,7 +448,7 @@ namespace
           ld_line<N>(Fo(f), l, PX, st);
           ld_line<N>(Fe(f), l, PX, wj);
           ld_line<N>(Fn(f), l, PX, v);
-          mul<N>(c->D, st, ds);
+          mul<N>(c->Dt, st, ds);
           mul_t<N>(c->D, wj, dj);
           const T wl = c->w[l] * c->fw[d];
 #pragma unroll
@@ -463,7 +474,7 @@ namespace
       {
         T u[N], gx[N], gy[N], gz[N], o[N];
         ld_line<N>(U, (b * N + a) * PX, 1, u);
-        mul<N>(c->D, u, gx);
+        mul<N>(c->Dt, u, gx);
         ld_line<N>(GY, (b * N + a) * PX, 1, gy);
         ld_line<N>(GZ, (b * N + a) * PX, 1, gz);
         const T wab = c->w[a] * c->w[b];
@@ -1098,6 +1109,13 @@ namespace
         c.D[i] = (T)h.D[i];
         c.E[i] = (T)h.E[i];
       }
+    for (int r = 0; r < n; ++r)
+      for (int q = 0; q < n; ++q)
+        {
+          c.St[r * n + q] = (T)h.S[q * n + r];
+          c.Dt[r * n + q] = (T)h.D[q * n + r];
+          c.Et[r * n + q] = (T)h.E[q * n + r];
+        }
     for (int i = 0; i < n; ++i)
       {
         c.w[i] = (T)h.wq[i];
