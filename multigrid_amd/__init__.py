@@ -605,7 +605,24 @@ class MultigridSolver:
         self.h = C.c_void_p(self.s.solver)
         self.coarse = None
         if cube.size > 1 and cube.box_desc is not None and os.environ.get("MGX_AGGLOMERATE", "1") != "0":
-            self._agglomerate(degree_pre, n_cycles, vcycle_number)
+            # the set-up is local; whether to use it is decided by all ranks together (a rank that
+            # could not build its copy must not leave the others waiting in the allreduce)
+            prepared = None
+            try:
+                prepared = self._agglomerate(degree_pre, n_cycles, vcycle_number)
+            except Exception as e:  # noqa: BLE001
+                import sys
+                print("mgx MultigridSolver: coarse levels stay decomposed (%r)" % (e,), file=sys.stderr, flush=True)
+            everyone = prepared is not None
+            if comm is not None and hasattr(comm, "allreduce"):
+                everyone = comm.allreduce([1.0 if prepared is not None else 0.0])[0] == cube.size
+            if prepared is not None and everyone:
+                coarse, level, mine, owned = prepared
+                check(self.lib.mgx_solver_set_agglomeration(self.h, level, coarse.h, mine.ctypes.data_as(_lib.u32p),
+                                                            owned.ctypes.data_as(C.POINTER(C.c_uint8)), mine.size))
+                self.coarse, self.coarse_level = coarse, level
+            elif prepared is not None:
+                prepared[0].close()
         if polynomial != "first_kind":
             check(self.lib.mgx_solver_set_polynomial_type(self.h, Chebyshev.POLYNOMIAL[polynomial]))
 
@@ -621,7 +638,7 @@ class MultigridSolver:
             if int(g.prod()) <= limit:
                 level = l
         if level < 0:
-            return
+            return None
         d = cube.box_desc
         whole = Cube(cube.degree, n_refine=level, box=d["box"], procs=(1, 1, 1), rank=0, numbering=d["numbering"],
                      origin=d["origin"], h0=d["h0"], geometry=d["geometry"], problem=d["problem"])
@@ -634,9 +651,7 @@ class MultigridSolver:
         assert (mine != INVALID_INDEX).all()
         owned = np.ones(mine.size, dtype=np.uint8)
         owned[cube.not_owned(level)] = 0
-        check(self.lib.mgx_solver_set_agglomeration(self.h, level, coarse.h, mine.ctypes.data_as(_lib.u32p),
-                                                    owned.ctypes.data_as(C.POINTER(C.c_uint8)), mine.size))
-        self.coarse, self.coarse_level = coarse, level
+        return coarse, level, mine, owned
 
     def matrix_dp(self, level):
         return LaplaceOperator(self.ctx, handle=self.s.matrix_dp[level])

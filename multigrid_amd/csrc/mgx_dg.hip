@@ -6,7 +6,7 @@
 // LocalBasisTransformer :92-350; 1D line kernel with face values common/matrix_vector_kernel.h
 // :30-216.  The bilinear form is the one of common/laplace_operator_dg_face.h:66-160.
 //
-// Design (MI355X): a workgroup of 256 threads takes CPW = 256 / (p+1)^2 consecutive cells; the
+// Design (MI355X): a workgroup of 128 threads takes CPW = 128 / (p+1)^2 consecutive cells; the
 // (p+1)^2 threads of a cell each own one line of the cell per sweep direction (registers) and one
 // quadrature point of each of the 6 faces.  Per cell the LDS holds the values U in the Gauss
 // points, two gradient components, and four (p+1)^2 arrays per face (own trace, own normal
@@ -90,7 +90,10 @@ namespace
     // face points) of neighbouring cells in one half-wave fall on consecutive banks
     static constexpr int CELL0 = 3 * VOL + 24 * FS;
     static constexpr int CELL  = CELL0 + (((NN2 - CELL0) % 32) + 32) % 32;
-    static constexpr int CPW_T = 256 / NN2;
+#ifndef MGX_DG_WG_THREADS
+#define MGX_DG_WG_THREADS 128 // measured: 128-thread workgroups 4-11 % faster than 256 (barriers span two waves)
+#endif
+    static constexpr int CPW_T = (MGX_DG_WG_THREADS / NN2) > 0 ? MGX_DG_WG_THREADS / NN2 : 1;
     static constexpr int CPW_L = 65536 / (CELL * (int)sizeof(T));
     static constexpr int CPW   = CPW_T < CPW_L ? CPW_T : CPW_L;
     static constexpr int THREADS = ((CPW * NN2 + 63) / 64) * 64;
@@ -224,6 +227,15 @@ namespace
     using C         = DGCfg<P, T>;
     constexpr int N = C::N, NN2 = C::NN2, N3 = C::N3, PX = C::PX, VOL = C::VOL, FS = C::FS;
     __shared__ T  lds[C::CPW * C::CELL];
+#ifdef MGX_DG_LDS_PAD // occupancy experiment (tools/experiments): extra LDS per workgroup, in bytes
+    __shared__ char lds_pad[MGX_DG_LDS_PAD];
+    if (A.n_cells == 0xFFFFFFFFu) // never true; keeps the array allocated
+      {
+        lds_pad[threadIdx.x] = 1;
+        __syncthreads();
+        A.dst[0] = (T)lds_pad[(threadIdx.x + 1) % MGX_DG_LDS_PAD];
+      }
+#endif
 
     const DGConst<T> *__restrict__ c = A.c;
     const int  tid    = threadIdx.x;
