@@ -88,7 +88,7 @@ namespace
     // per-cell LDS stride: congruent to the threads per cell modulo the 32 banks (of 4 B for fp32,
     // of 8 B for fp64 accesses), so that accesses of the form "thread index + constant" (z-lines,
     // face points) of neighbouring cells in one half-wave fall on consecutive banks
-    static constexpr int CELL0 = 3 * VOL + 24 * FS;
+    static constexpr int CELL0 = 3 * VOL + 6 * FS;
     static constexpr int CELL  = CELL0 + (((NN2 - CELL0) % 32) + 32) % 32;
 #ifndef MGX_DG_WG_THREADS
 #define MGX_DG_WG_THREADS 128 // measured: 128-thread workgroups 4-11 % faster than 256 (barriers span two waves)
@@ -250,11 +250,7 @@ namespace
 
     T *U  = lds + (active ? cw : 0) * C::CELL;
     T *GY = U + VOL, *GZ = U + 2 * VOL;
-    T *F  = U + 3 * VOL; // [4][6][FS]: own value / own normal derivative / neighbour value / neighbour normal derivative
-    auto Fo = [&](int f) { return F + f * FS; };
-    auto Fn = [&](int f) { return F + (6 + f) * FS; };
-    auto Fe = [&](int f) { return F + (12 + f) * FS; };
-    auto Fd = [&](int f) { return F + (18 + f) * FS; };
+    T *F  = U + 3 * VOL; // face scratch of the direction in work: [2 faces][3][FS]
     const int fidx = b * PX + a;
 
     const T *__restrict__ src = A.src;
@@ -288,7 +284,12 @@ namespace
         return;
       }
 
-    // ---- 1. source x-line -> Gauss values along x; raw neighbour traces
+    // own traces (value, reference normal derivative) of the 6 faces at this thread's face point,
+    // and what the faces give back to the integration (value / normal-derivative test function):
+    // registers -- the line owner (a, b) of a sweep direction is the owner of face point (a, b)
+    T To[6], No[6], Vf[6], Wf[6];
+
+    // ---- 1. source x-line -> Gauss values along x
     if (active)
       {
         T u[N];
@@ -300,44 +301,10 @@ namespace
         else
           copy_line<N>(xs, u);
         st_line<N>(U, (b * N + a) * PX, 1, u);
-
-#pragma unroll
-        for (int f = 0; f < 6; ++f)
-          {
-            const int d = f / 2, s = f % 2;
-            // strides of the normal direction and the two tangential ones (ascending) in a cell
-            const int sd = d == 0 ? 1 : (d == 1 ? N : N * N);
-            const int s1 = d == 0 ? N : 1;
-            const int s2 = d == 2 ? N : N * N;
-            T         ev = 0, ed = 0;
-            if (nb[f] >= 0)
-              {
-                const T *__restrict__ xn = src + (size_t)nb[f] * N3 + a * s1 + b * s2;
-                if constexpr (TYPE == MGX_DG_HERMITE)
-                  {
-                    // the neighbour's face is its upper one for our lower face and vice versa
-                    const T v0 = xn[(s == 0 ? N - 1 : 0) * sd];
-                    const T v1 = xn[(s == 0 ? (N > 1 ? N - 2 : 0) : (N > 1 ? 1 : 0)) * sd];
-                    ev         = v0;
-                    ed         = s == 0 ? c->hderiv * (v1 - v0) : c->hderiv * (v0 - v1);
-                  }
-                else
-                  {
-                    T line[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                      line[i] = xn[i * sd];
-                    ev = dot_line<N>(c->fb[1 - s], line);
-                    ed = dot_line<N>(c->fg[1 - s], line);
-                  }
-              }
-            Fe(f)[fidx] = ev;
-            Fd(f)[fidx] = ed;
-          }
       }
     __syncthreads();
 
-    // ---- 2. Gauss values along y; neighbour traces: in-face basis change, first direction
+    // ---- 2. Gauss values along y
     if constexpr (TYPE != MGX_DG_GAUSS)
       {
         if (active)
@@ -346,19 +313,11 @@ namespace
             ld_line<N>(U, b * N * PX + a, PX, u);
             mul<N>(c->St, u, v);
             st_line<N>(U, b * N * PX + a, PX, v);
-            for (int L = t; L < 12 * N; L += NN2)
-              {
-                T *arr = F + (12 + L / N) * FS + (L % N) * PX;
-                ld_line<N>(arr, 0, 1, u);
-                mul<N>(c->St, u, v);
-                st_line<N>(arr, 0, 1, v);
-              }
           }
         __syncthreads();
       }
 
-    // ---- 3. z-lines: Gauss values along z, z-derivative, traces on the z faces; neighbour
-    //         traces second direction
+    // ---- 3. z-lines: Gauss values along z, z-derivative, traces on the z faces
     if (active)
       {
         T u[N], v[N];
@@ -372,18 +331,10 @@ namespace
           copy_line<N>(u, v);
         mul<N>(c->Dt, v, u);
         st_line<N>(GZ, b * PX + a, N * PX, u);
-        Fo(4)[fidx] = dot_line<N>(c->b[0], v);
-        Fo(5)[fidx] = dot_line<N>(c->b[1], v);
-        Fn(4)[fidx] = dot_line<N>(c->g[0], v);
-        Fn(5)[fidx] = dot_line<N>(c->g[1], v);
-        if constexpr (TYPE != MGX_DG_GAUSS)
-          for (int L = t; L < 12 * N; L += NN2)
-            {
-              T *arr = F + (12 + L / N) * FS + (L % N);
-              ld_line<N>(arr, 0, PX, u);
-              mul<N>(c->St, u, v);
-              st_line<N>(arr, 0, PX, v);
-            }
+        To[4] = dot_line<N>(c->b[0], v);
+        To[5] = dot_line<N>(c->b[1], v);
+        No[4] = dot_line<N>(c->g[0], v);
+        No[5] = dot_line<N>(c->g[1], v);
       }
     __syncthreads();
 
@@ -394,92 +345,169 @@ namespace
         ld_line<N>(U, b * N * PX + a, PX, u);
         mul<N>(c->Dt, u, v);
         st_line<N>(GY, b * N * PX + a, PX, v);
-        Fo(2)[fidx] = dot_line<N>(c->b[0], u);
-        Fo(3)[fidx] = dot_line<N>(c->b[1], u);
-        Fn(2)[fidx] = dot_line<N>(c->g[0], u);
-        Fn(3)[fidx] = dot_line<N>(c->g[1], u);
+        To[2] = dot_line<N>(c->b[0], u);
+        To[3] = dot_line<N>(c->b[1], u);
+        No[2] = dot_line<N>(c->g[0], u);
+        No[3] = dot_line<N>(c->g[1], u);
         ld_line<N>(U, (b * N + a) * PX, 1, u);
-        Fo(0)[fidx] = dot_line<N>(c->b[0], u);
-        Fo(1)[fidx] = dot_line<N>(c->b[1], u);
-        Fn(0)[fidx] = dot_line<N>(c->g[0], u);
-        Fn(1)[fidx] = dot_line<N>(c->g[1], u);
+        To[0] = dot_line<N>(c->b[0], u);
+        To[1] = dot_line<N>(c->b[1], u);
+        No[0] = dot_line<N>(c->g[0], u);
+        No[1] = dot_line<N>(c->g[1], u);
       }
-    __syncthreads();
 
-    // ---- 5. faces.  In the quadrature point: sum and jump of the two traces, sum of the normal
-    // derivatives; a Dirichlet face mirrors the own values (laplace_operator_dg.h:1568-1577).
-    //   Fo <- T_own + T_ext,  Fn <- N_own + N_ext,  Fe <- w * (T_own - T_ext)
-    if (active)
-      {
+    // ---- 5. faces, one direction at a time (two faces): per face three arrays of (p+1)^2 words --
+    // neighbour trace, then sum of the traces | neighbour normal derivative, then weighted jump |
+    // tangential part of the result.  A Dirichlet face mirrors the own values (:1568-1577).
 #pragma unroll
-        for (int f = 0; f < 6; ++f)
+    for (int d = 0; d < 3; ++d)
+      {
+        const int sd = d == 0 ? 1 : (d == 1 ? N : N * N); // stride of the normal direction in a cell
+        const int s1 = d == 0 ? N : 1;                    // ... of the two tangential ones (ascending)
+        const int s2 = d == 2 ? N : N * N;
+        const int t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+        auto      E0 = [&](int s) { return F + (3 * s) * FS; };
+        auto      E1 = [&](int s) { return F + (3 * s + 1) * FS; };
+        auto      AT = [&](int s) { return F + (3 * s + 2) * FS; };
+        if (active)
           {
-            const int d  = f / 2;
-            const T   wq = c->w[a] * c->w[b] * c->fw[d];
-            const T   to = Fo(f)[fidx], no = Fn(f)[fidx];
-            const bool dirichlet = nb[f] < 0;
-            const T   te = dirichlet ? to : Fe(f)[fidx];
-            const T   ne = dirichlet ? no : Fd(f)[fidx];
-            Fo(f)[fidx]  = to + te;
-            Fn(f)[fidx]  = no + ne;
-            Fe(f)[fidx]  = wq * (dirichlet ? T(2) * to : to - te);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              {
+                const int f  = 2 * d + s;
+                T         ev = 0, ed = 0;
+                if (nb[f] >= 0)
+                  {
+                    const T *__restrict__ xn = src + (size_t)nb[f] * N3 + a * s1 + b * s2;
+                    if constexpr (TYPE == MGX_DG_HERMITE)
+                      {
+                        // the neighbour's face is its upper one for our lower face and vice versa
+                        const T v0 = xn[(s == 0 ? N - 1 : 0) * sd];
+                        const T v1 = xn[(s == 0 ? (N > 1 ? N - 2 : 0) : (N > 1 ? 1 : 0)) * sd];
+                        ev         = v0;
+                        ed         = s == 0 ? c->hderiv * (v1 - v0) : c->hderiv * (v0 - v1);
+                      }
+                    else
+                      {
+                        T line[N];
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                          line[i] = xn[i * sd];
+                        ev = dot_line<N>(c->fb[1 - s], line);
+                        ed = dot_line<N>(c->fg[1 - s], line);
+                      }
+                  }
+                E0(s)[fidx] = ev;
+                E1(s)[fidx] = ed;
+              }
+          }
+        __syncthreads();
+        if constexpr (TYPE != MGX_DG_GAUSS)
+          {
+            // neighbour traces: in-face change to the Gauss points, first then second direction
+            if (active)
+              for (int L = t; L < 4 * N; L += NN2)
+                {
+                  T  u[N], v[N];
+                  T *arr = F + ((L / N) / 2 * 3 + (L / N) % 2) * FS + (L % N) * PX;
+                  ld_line<N>(arr, 0, 1, u);
+                  mul<N>(c->St, u, v);
+                  st_line<N>(arr, 0, 1, v);
+                }
+            __syncthreads();
+            if (active)
+              for (int L = t; L < 4 * N; L += NN2)
+                {
+                  T  u[N], v[N];
+                  T *arr = F + ((L / N) / 2 * 3 + (L / N) % 2) * FS + (L % N);
+                  ld_line<N>(arr, 0, PX, u);
+                  mul<N>(c->St, u, v);
+                  st_line<N>(arr, 0, PX, v);
+                }
+            __syncthreads();
+          }
+        // in the quadrature point: sum of the traces -> E0, weighted jump -> E1; sum of the normal
+        // derivatives and the weighted jump stay in registers
+        T sN[2], wJ[2];
+        if (active)
+          {
+            const T wq = c->w[a] * c->w[b] * c->fw[d];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              {
+                const int  f = 2 * d + s;
+                const bool dirichlet = nb[f] < 0;
+                const T    te = dirichlet ? To[f] : E0(s)[fidx];
+                const T    ne = dirichlet ? No[f] : E1(s)[fidx];
+                sN[s]         = No[f] + ne;
+                wJ[s]         = wq * (dirichlet ? T(2) * To[f] : To[f] - te);
+                E0(s)[fidx]   = To[f] + te;
+                E1(s)[fidx]   = wJ[s];
+              }
+          }
+        __syncthreads();
+        // tangential part, lines of the first tangential direction (s = +-1 the side of the face):
+        //   AT = -s/2 c_t1 (w d_t1 sumT + d_t1^T wj)
+        if (active)
+          for (int L = t; L < 2 * N; L += NN2)
+            {
+              const int s = L / N, l = L % N;
+              const T   half_s = s ? T(0.5) : T(-0.5);
+              const T   ct = c->cn[d][t1];
+              T         st[N], wj[N], ds[N], dj[N];
+              ld_line<N>(E0(s), l * PX, 1, st);
+              ld_line<N>(E1(s), l * PX, 1, wj);
+              mul<N>(c->Dt, st, ds);
+              mul_t<N>(c->D, wj, dj);
+              const T wl = c->w[l] * c->fw[d];
+#pragma unroll
+              for (int i = 0; i < N; ++i)
+                ds[i] = -half_s * ct * (c->w[i] * wl * ds[i] + dj[i]);
+              st_line<N>(AT(s), l * PX, 1, ds);
+            }
+        __syncthreads();
+        if (active)
+          for (int L = t; L < 2 * N; L += NN2)
+            {
+              const int s = L / N, l = L % N;
+              const T   half_s = s ? T(0.5) : T(-0.5);
+              const T   ct = c->cn[d][t2];
+              T         st[N], wj[N], v[N], ds[N], dj[N];
+              ld_line<N>(E0(s), l, PX, st);
+              ld_line<N>(E1(s), l, PX, wj);
+              ld_line<N>(AT(s), l, PX, v);
+              mul<N>(c->Dt, st, ds);
+              mul_t<N>(c->D, wj, dj);
+              const T wl = c->w[l] * c->fw[d];
+#pragma unroll
+              for (int i = 0; i < N; ++i)
+                v[i] -= half_s * ct * (c->w[i] * wl * ds[i] + dj[i]);
+              st_line<N>(AT(s), l, PX, v);
+            }
+        __syncthreads();
+        // value test function  V = sigma wj - s/2 w c_n sumN + tangential part,
+        // normal derivative test function  W = -s/2 c_n wj
+        if (active)
+          {
+            const T wq = c->w[a] * c->w[b] * c->fw[d];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              {
+                const int f      = 2 * d + s;
+                const T   half_s = s ? T(0.5) : T(-0.5);
+                Vf[f] = c->sigma[d] * wJ[s] - half_s * wq * c->cn[d][d] * sN[s] + AT(s)[fidx];
+                Wf[f] = -half_s * c->cn[d][d] * wJ[s];
+              }
           }
       }
-    __syncthreads();
-    // lines of the first tangential direction: with s = +-1 the side of the face,
-    //   V = sigma wj - s/2 [ w (c_n sumN + c_t1 d_t1 sumT) + c_t1 d_t1^T wj ]      (Fn <- V)
-    // lines of the second one add  - s/2 c_t2 (w d_t2 sumT + d_t2^T wj)
-    if (active)
-      for (int L = t; L < 6 * N; L += NN2)
-        {
-          const int f = L / N, l = L % N, d = f / 2;
-          const int t1 = d == 0 ? 1 : 0;
-          const T   half_s = (f % 2) ? T(0.5) : T(-0.5);
-          const T   cnn = c->cn[d][d], ct = c->cn[d][t1], sg = c->sigma[d];
-          T         st[N], wj[N], sn[N], ds[N], dj[N];
-          ld_line<N>(Fo(f), l * PX, 1, st);
-          ld_line<N>(Fe(f), l * PX, 1, wj);
-          ld_line<N>(Fn(f), l * PX, 1, sn);
-          mul<N>(c->Dt, st, ds);
-          mul_t<N>(c->D, wj, dj);
-          const T wl = c->w[l] * c->fw[d];
-#pragma unroll
-          for (int i = 0; i < N; ++i)
-            sn[i] = sg * wj[i] - half_s * (c->w[i] * wl * (cnn * sn[i] + ct * ds[i]) + ct * dj[i]);
-          st_line<N>(Fn(f), l * PX, 1, sn);
-        }
-    __syncthreads();
-    if (active)
-      for (int L = t; L < 6 * N; L += NN2)
-        {
-          const int f = L / N, l = L % N, d = f / 2;
-          const int t2 = d == 2 ? 1 : 2;
-          const T   half_s = (f % 2) ? T(0.5) : T(-0.5);
-          const T   ct = c->cn[d][t2];
-          T         st[N], wj[N], v[N], ds[N], dj[N];
-          ld_line<N>(Fo(f), l, PX, st);
-          ld_line<N>(Fe(f), l, PX, wj);
-          ld_line<N>(Fn(f), l, PX, v);
-          mul<N>(c->Dt, st, ds);
-          mul_t<N>(c->D, wj, dj);
-          const T wl = c->w[l] * c->fw[d];
-#pragma unroll
-          for (int i = 0; i < N; ++i)
-            v[i] -= half_s * ct * (c->w[i] * wl * ds[i] + dj[i]);
-          st_line<N>(Fn(f), l, PX, v);
-        }
-    __syncthreads();
 
-    // face contributions to a line's integration: value test function V, normal derivative test
-    // function W = -s/2 c_n wj
+    // face contributions to a line's integration
     auto add_faces = [&](int d, T(&o)[N]) {
-      const T v0 = Fn(2 * d)[fidx], v1 = Fn(2 * d + 1)[fidx];
-      const T w0 = T(0.5) * c->cn[d][d] * Fe(2 * d)[fidx];
-      const T w1 = T(-0.5) * c->cn[d][d] * Fe(2 * d + 1)[fidx];
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        o[i] += c->b[0][i] * v0 + c->b[1][i] * v1 + c->g[0][i] * w0 + c->g[1][i] * w1;
+        o[i] += c->b[0][i] * Vf[2 * d] + c->b[1][i] * Vf[2 * d + 1] + c->g[0][i] * Wf[2 * d] + c->g[1][i] * Wf[2 * d + 1];
     };
+    __syncthreads(); // GY complete; the face scratch is not touched below
 
     // ---- 6. x-lines: gradient, coefficient (laplace_operator_dg.h:1700-1716), integration along x
     if (active)
