@@ -128,6 +128,13 @@ typedef struct
    * finest FE_Q level, coarse tolerance 2e-3) and runs its V-cycle in place. */
   mgx_solver_t      cfe;
   int               degree_pre;   /* Chebyshev degree of the DG smoother (:300) */
+  /* optional, host [n_cells]: a decomposition-independent id of every owned cell (e.g. its
+   * lexicographic position in the whole mesh); the start vector of the eigenvalue estimate is
+   * ((id (p+1)^3 + local index) mod 11) - mean, deal.II's (global DoF index mod 11) - mean.
+   * NULL: the cell's index on this rank.  Decomposed meshes: matrix_dg / matrix_dg_dp carry ghost
+   * cells (all device vectors of the solver interface then have mgx_dg_operator_vector_size
+   * entries), cfe is the decomposed FE_Q solver of the same partition, not agglomerated. */
+  const uint32_t   *cell_global_id;
 } mgx_dg_solver_desc;
 /* ctor (:58-323), incl. smooth_dg.initialize: eigenvalue estimate with JacobiTransformed */
 int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_dg_solver_t *solver);

@@ -21,7 +21,7 @@ from ._lib import F32, F64, INVALID_INDEX, MgxError, check
 
 __all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
            "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError", "DGLaplaceOperator", "dg_cheby_mesh",
-           "dg_box_neighbours", "dg_box_partition", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver"]
+           "dg_box_neighbours", "dg_box_partition", "dg_partition", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver"]
 
 
 def process_grid(size):
@@ -587,7 +587,7 @@ class MultigridSolver:
     `vcycle_number` is the template parameter Number (program.cc:76: float; BASELINE: double)."""
 
     def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64, comm=None,
-                 polynomial="first_kind"):
+                 polynomial="first_kind", agglomerate=True):
         """polynomial: Chebyshev polynomial type of the level smoothers: "first_kind" is what
         MultigridSolver<dim,p,Number,Number2> sets (multigrid_solver.h:277-278), "fourth_kind" what
         the Number == Number2 specialisation sets (:951-952)"""
@@ -604,7 +604,7 @@ class MultigridSolver:
         self.max_level = self.n_levels - 1
         self.h = C.c_void_p(self.s.solver)
         self.coarse = None
-        if cube.size > 1 and cube.box_desc is not None and os.environ.get("MGX_AGGLOMERATE", "1") != "0":
+        if cube.size > 1 and cube.box_desc is not None and agglomerate and os.environ.get("MGX_AGGLOMERATE", "1") != "0":
             # the set-up is local; whether to use it is decided by all ranks together (a rank that
             # could not build its copy must not leave the others waiting in the allreduce)
             prepared = None
@@ -776,18 +776,58 @@ def dg_box_neighbours(cells, ordering="z"):
     return nb, ijk
 
 
+def dg_partition(ijk, cells, procs, rank):
+    """Ghost cells and exchange lists of a block decomposition, for the owned cells `ijk` ([n, 3] global
+    positions, in the local cell order) of the rank whose block of the process grid they fill.
+    Returns a dict: neighbours [n_owned, 6] (entries >= n_owned: ghost cells, -1: boundary), ijk,
+    n_ghost, and exchange = [(rank, send_cells, recv_first, count)] in ascending rank order; the ghosts
+    of one rank and the cells sent to it are in ascending global lexicographic order on both sides."""
+    cells, procs = np.asarray(cells, dtype=np.int64), np.asarray(procs, dtype=np.int64)
+    assert (cells % procs == 0).all(), "the process grid must divide the cells"
+    blk = cells // procs
+    ijk = np.asarray(ijk, dtype=np.int64)
+    n_owned = len(ijk)
+    gid = lambda p: p[..., 0] + cells[0] * (p[..., 1] + cells[1] * p[..., 2])   # noqa: E731
+    owner = lambda p: (p[..., 0] // blk[0]) + procs[0] * ((p[..., 1] // blk[1]) + procs[1] * (p[..., 2] // blk[2]))  # noqa: E731
+    assert (owner(ijk) == rank).all(), "cells outside the rank's block"
+    pos = np.full(int(cells.prod()), -1, dtype=np.int64)   # global cell -> local index (owned, then ghosts)
+    pos[gid(ijk)] = np.arange(n_owned)
+    faces = []
+    ghosts, sends = {}, {}
+    for d in range(3):
+        for s in (-1, 1):
+            q = ijk.copy()
+            q[:, d] += s
+            ok = (q[:, d] >= 0) & (q[:, d] < cells[d])
+            g = np.where(ok, gid(np.where(ok[:, None], q, ijk)), -1)
+            own = np.where(ok, owner(np.where(ok[:, None], q, ijk)), rank)
+            faces.append((ok, g))
+            for rk in np.unique(own[ok & (own != rank)]):
+                m = ok & (own == rk)
+                ghosts.setdefault(int(rk), []).append(g[m])
+                sends.setdefault(int(rk), []).append(gid(ijk[m]))
+    exchange, first = [], n_owned
+    for rk in sorted(ghosts):
+        gl, sl = np.unique(np.concatenate(ghosts[rk])), np.unique(np.concatenate(sends[rk]))
+        assert len(gl) == len(sl)
+        pos[gl] = first + np.arange(len(gl))
+        exchange.append((rk, pos[sl].astype(np.uint32), first, len(gl)))
+        first += len(gl)
+    nb = np.full((n_owned, 6), -1, dtype=np.int32)
+    for f, (ok, g) in enumerate(faces):
+        nb[ok, f] = pos[g[ok]]
+    assert (nb[nb >= 0] < first).all()
+    return dict(neighbours=nb, ijk=ijk.astype(np.int32), n_ghost=first - n_owned, exchange=exchange)
+
+
 def dg_box_partition(cells, procs, rank, ordering="z"):
     """Block decomposition of a box of cells over a process grid (the DG counterpart of the Cube
-    provider's decomposition; stands in for the p4est partition of the reference).  Returns a dict:
-    neighbours [n_owned, 6] (entries >= n_owned: ghost cells, -1: boundary), ijk [n_owned, 3] global
-    positions of the owned cells in local order, n_ghost, and exchange = [(rank, send_cells,
-    recv_first, count)] in ascending rank order; ghosts of one rank and the cells sent to it are in
-    ascending global lexicographic order on both sides."""
+    provider's decomposition; stands in for the p4est partition of the reference): the rank's block
+    in z-order (or lexicographic order), then dg_partition()."""
     cells, procs = np.asarray(cells), np.asarray(procs)
     assert (cells % procs == 0).all(), "the process grid must divide the cells"
     blk = cells // procs
     r3 = np.array([rank % procs[0], (rank // procs[0]) % procs[1], rank // (procs[0] * procs[1])])
-    lo = r3 * blk
     loc = np.stack(np.meshgrid(np.arange(blk[0]), np.arange(blk[1]), np.arange(blk[2]), indexing="ij"), -1).reshape(-1, 3)
     if ordering == "z":
         def spread(v):
@@ -799,39 +839,7 @@ def dg_box_partition(cells, procs, rank, ordering="z"):
     else:
         key = loc[:, 0] + blk[0] * (loc[:, 1] + blk[1] * loc[:, 2])
     loc = loc[np.argsort(key, kind="stable")]
-    ijk = loc + lo
-    n_owned = len(ijk)
-    gid = lambda p: p[..., 0] + cells[0] * (p[..., 1] + cells[1] * p[..., 2])   # noqa: E731
-    owner = lambda p: (p[..., 0] // blk[0]) + procs[0] * ((p[..., 1] // blk[1]) + procs[1] * (p[..., 2] // blk[2]))  # noqa: E731
-    index_of = {int(g): i for i, g in enumerate(gid(ijk))}
-    ghosts, sends = {}, {}
-    for d in range(3):
-        for s in (-1, 1):
-            q = ijk.copy()
-            q[:, d] += s
-            ok = (q[:, d] >= 0) & (q[:, d] < cells[d])
-            own = owner(np.where(ok[:, None], q, ijk))
-            for i in np.nonzero(ok & (own != rank))[0]:
-                ghosts.setdefault(int(own[i]), set()).add(int(gid(q[i])))
-                sends.setdefault(int(own[i]), set()).add(int(gid(ijk[i])))
-    exchange, ghost_index, first = [], {}, n_owned
-    for rk in sorted(ghosts):
-        gl, sl = sorted(ghosts[rk]), sorted(sends[rk])
-        assert len(gl) == len(sl)
-        for g in gl:
-            ghost_index[g] = first + len(ghost_index)
-        exchange.append((rk, np.array([index_of[g] for g in sl], dtype=np.uint32), first + len(ghost_index) - len(gl), len(gl)))
-    nb = np.full((n_owned, 6), -1, dtype=np.int32)
-    for d in range(3):
-        for side, s in enumerate((-1, 1)):
-            q = ijk.copy()
-            q[:, d] += s
-            ok = (q[:, d] >= 0) & (q[:, d] < cells[d])
-            g = gid(q)
-            for i in np.nonzero(ok)[0]:
-                gi = int(g[i])
-                nb[i, 2 * d + side] = index_of[gi] if gi in index_of else ghost_index[gi]
-    return dict(neighbours=nb, ijk=ijk.astype(np.int32), n_ghost=len(ghost_index), exchange=exchange)
+    return dg_partition(loc + r3 * blk, cells, procs, rank)
 
 
 class DGLaplaceOperator:
@@ -929,30 +937,33 @@ class DGMultigridSolver:
     top of the FE_Q(p) hierarchy of the same mesh, V-cycle in `vcycle_number`, outer CG in fp64.
     The DG cells are the cells of the cube's finest level in the provider's order."""
 
-    def __init__(self, ctx, cube, basis=DG_HERMITE, degree_pre=3, vcycle_number=F32):
+    def __init__(self, ctx, cube, basis=DG_HERMITE, degree_pre=3, vcycle_number=F32, comm=None):
+        """comm: Communicator of a decomposed cube (box form): the DG cells get ghost cells, the FE_Q
+        hierarchy is the decomposed one (not agglomerated: its smoothers are re-configured)"""
         self.ctx, self.cube, self.lib = ctx, cube, ctx.lib
-        assert cube.size == 1, "the DG level is single-rank in this slice"
         l = cube.max_level
-        coords = cube.cell_coords(l).astype(np.int64)
-        n1 = int(coords.max()) + 1
-        key = coords[:, 0] + n1 * (coords[:, 1] + n1 * coords[:, 2])
-        inv = np.full(n1 ** 3, -1, dtype=np.int64)
-        inv[key] = np.arange(key.size)
-        nb = np.full((key.size, 6), -1, dtype=np.int32)
-        for d, stride in enumerate((1, n1, n1 * n1)):
-            lo, hi = coords[:, d] > 0, coords[:, d] < n1 - 1
-            nb[lo, 2 * d] = inv[key[lo] - stride]
-            nb[hi, 2 * d + 1] = inv[key[hi] + stride]
-        self.neighbours, self.cell_ijk = nb, coords
+        local, whole = (np.array(v, dtype=np.int64) for v in cube.cells_per_dim3(l))
+        procs = whole // local
+        r3 = np.array([cube.rank % procs[0], (cube.rank // procs[0]) % procs[1], cube.rank // (procs[0] * procs[1])])
+        ijk = cube.cell_coords(l).astype(np.int64) + r3 * local      # global positions, provider's cell order
+        part = dg_partition(ijk, whole, procs, cube.rank)
+        self.neighbours, self.cell_ijk = part["neighbours"], part["ijk"]
+        gid = (ijk[:, 0] + whole[0] * (ijk[:, 1] + whole[1] * ijk[:, 2])).astype(np.uint32)
         jac = np.eye(3) * cube.cell_size(l)
-        self.cfe = MultigridSolver(ctx, cube, degree_pre, degree_pre, 1, vcycle_number)
-        self.matrix_dg = DGLaplaceOperator(ctx, cube.degree, basis, nb, jac, vcycle_number)
-        self.matrix_dg_dp = DGLaplaceOperator(ctx, cube.degree, basis, nb, jac, F64)
-        d = _lib.DGSolverDesc(self.matrix_dg.h, self.matrix_dg_dp.h, self.cfe.h, degree_pre)
+        self.cfe = MultigridSolver(ctx, cube, degree_pre, degree_pre, 1, vcycle_number, comm=comm, agglomerate=False)
+        ng, ex = part["n_ghost"], part["exchange"]
+        self.matrix_dg = DGLaplaceOperator(ctx, cube.degree, basis, part["neighbours"], jac, vcycle_number, ng, ex, plan_id=1001)
+        self.matrix_dg_dp = DGLaplaceOperator(ctx, cube.degree, basis, part["neighbours"], jac, F64, ng, ex, plan_id=1002)
+        d = _lib.DGSolverDesc(self.matrix_dg.h, self.matrix_dg_dp.h, self.cfe.h, degree_pre, gid.ctypes.data_as(_lib.u32p))
         h = C.c_void_p()
         check(self.lib.mgx_dg_solver_create(ctx.h, C.byref(d), C.byref(h)))
         self.h = h
         self.vnumber = vcycle_number
+        self.cell_gid = gid
+
+    def initialize_dof_vector(self, data=None):
+        """fp64 vector of the solver interface (owned DoFs, then the ghost cells of a decomposed mesh)"""
+        return self.matrix_dg_dp.initialize_dof_vector(data)
 
     def m(self):
         return self.matrix_dg.m()

@@ -63,7 +63,8 @@ class DGOperatorDesc(C.Structure):
 
 
 class DGSolverDesc(C.Structure):
-    _fields_ = [("matrix_dg", vp), ("matrix_dg_dp", vp), ("cfe", vp), ("degree_pre", C.c_int)]
+    _fields_ = [("matrix_dg", vp), ("matrix_dg_dp", vp), ("cfe", vp), ("degree_pre", C.c_int),
+                ("cell_global_id", u32p)]
 
 
 class SmootherInfo(C.Structure):

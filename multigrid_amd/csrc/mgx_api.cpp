@@ -660,6 +660,15 @@ int mgx::exchange_buffers(mgx_context_t ctx, int plan_id, int number, int n_neig
 
 int mgx::allreduce_sum(mgx_context_t ctx, double *values, int count) { return comm_allreduce(ctx, values, count); }
 
+// x.y over the first n entries of two vectors whose leading part is owned by this rank without
+// duplicates (DG vectors: owned cells, then ghost cells), summed over the ranks
+int mgx::dot_owned_prefix(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *out)
+{
+  launch_dot(ctx->stream, number, x, y, n, ctx->partial_dev, ctx->result_dev);
+  MGX_TRY(read_result(ctx, out));
+  return comm_allreduce(ctx, out, 1);
+}
+
 bool mgx::context_has_comm(mgx_context_t ctx) { return ctx && ctx->has_comm; }
 
 extern "C" {

@@ -1268,7 +1268,10 @@ struct mgx_dg_solver_s
   mgx_dg_operator_t A = nullptr, A_dp = nullptr;
   mgx_solver_t      cfe = nullptr;
   int               degree = 0, number = MGX_F32;
-  size_t            n = 0;
+  size_t            n = 0;      // owned DoFs
+  size_t            n_vec = 0;  // entries of a vector: owned cells, then ghost cells
+  mgx_operator_t    fe = nullptr; // finest FE_Q operator (interface sum of the restricted defect)
+  bool              decomposed = false;
   mgx_smoother_info info{};
   void             *defect = nullptr, *t = nullptr, *update = nullptr, *old = nullptr; // V-cycle number type
   void             *P1 = nullptr;                                                      // device, V-cycle number type
@@ -1676,6 +1679,31 @@ namespace
 {
   size_t dg_nsz(int number) { return number == MGX_F64 ? 8 : 4; }
 
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_start_vector(T *__restrict__ v, const uint32_t *__restrict__ cell_id, uint32_t n_cells, uint32_t n3, double mean)
+  {
+    const uint64_t total = (uint64_t)n_cells * n3;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+      {
+        const uint32_t c = (uint32_t)(i / n3);
+        const uint64_t g = (uint64_t)(cell_id ? cell_id[c] : c) * n3 + (i - (uint64_t)c * n3);
+        v[i]             = (T)((double)(g % 11u) - mean);
+      }
+  }
+
+  int dg_dot(mgx_dg_solver_t S, int number, const void *x, const void *y, double *out)
+  {
+    return mgx::dot_owned_prefix(S->ctx, number, x, y, S->n, out);
+  }
+
+  int dg_norm(mgx_dg_solver_t S, int number, const void *x, double *out)
+  {
+    MGX_DG_TRY(mgx::dot_owned_prefix(S->ctx, number, x, x, S->n, out));
+    *out = std::sqrt(*out);
+    return MGX_OK;
+  }
+
   // PreconditionChebyshev<LaplaceOperatorCompactCombine, Vector, JacobiTransformed>: vmult (zero start) and
   // step, through the merged operation (deal.II hands iteration index 0 / 1, then k + 1 / k + 2)
   int dg_smoother_apply(mgx_dg_solver_t S, bool is_step)
@@ -1717,6 +1745,8 @@ namespace
     MGX_DG_TRY(mgx_dg_vmult_residual(S->A, S->t, S->defect, S->update));
     DG_HIP(hipMemsetAsync(S->cg_defect, 0, dg_nsz(S->number) * S->n_cg, s));
     mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, S->cg_defect, S->t, S->idx27, S->n_cells, S->P1);
+    if (S->decomposed) // FE_Q DoFs on a rank interface collect the contributions of all sharers
+      MGX_DG_TRY(mgx_exchange_add(S->fe, S->cg_defect));
     MGX_DG_TRY(mgx_solver_v_cycle(S->cfe)); // :622
     // prolongate_add_cg_to_dg (:625; laplace_operator_dg.h:1863-1894)
     mgx::launch_dg_cg_transfer(s, S->number, S->degree, true, S->update, S->cg_update, S->idx27, S->n_cells, S->P1);
@@ -1754,18 +1784,26 @@ int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_
   S->degree = A->degree;
   S->number = A->number;
   S->n = (size_t)mgx_dg_operator_n_dofs(A);
+  S->n_vec = (size_t)mgx_dg_operator_vector_size(A);
+  S->fe = fe;
+  S->decomposed = A->n_ghost > 0;
+  if (A->n_ghost != Ad->n_ghost)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_solver_create: the two DG operators must share the partition");
   S->idx27 = idx27;
   S->n_cells = nc;
   S->n_cg = ncg;
   hipStream_t  s  = (hipStream_t)mgx_context_stream(ctx);
-  const size_t vb = dg_nsz(S->number) * S->n;
+  const size_t vb = dg_nsz(S->number) * S->n_vec;
   for (void **v : {&S->defect, &S->t, &S->update, &S->old})
     {
       DG_HIP(hipMalloc(v, vb));
       DG_HIP(hipMemsetAsync(*v, 0, vb, s));
     }
   for (double **v : {&S->r, &S->z, &S->d, &S->h})
-    DG_HIP(hipMalloc((void **)v, 8 * S->n));
+    {
+      DG_HIP(hipMalloc((void **)v, 8 * S->n_vec));
+      DG_HIP(hipMemsetAsync(*v, 0, 8 * S->n_vec, s));
+    }
   {
     const int n1 = S->degree + 1;
     DG_HIP(hipMalloc(&S->P1, dg_nsz(S->number) * n1 * n1));
@@ -1797,19 +1835,37 @@ int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_
   {
     const size_t n  = S->n;
     void        *r = S->t, *z = S->update, *d = S->old, *h = S->defect; // free until the first cycle
-    const size_t full = n / 11, rem = n % 11;
-    const double mean = (full * 55.0 + rem * (rem - 1) / 2.0) / (double)n;
-    mgx::launch_index_mod11(s, S->number, r, nullptr, mean, n);
+    double ng = (double)n; // global number of DoFs
+    MGX_DG_TRY(mgx::allreduce_sum(ctx, &ng, 1));
+    const uint64_t ngl  = (uint64_t)(ng + 0.5);
+    const uint64_t full = ngl / 11, rem = ngl % 11;
+    const double   mean = (full * 55.0 + rem * (rem - 1) / 2.0) / (double)ngl;
+    uint32_t      *cell_id = nullptr;
+    if (desc->cell_global_id)
+      {
+        DG_HIP(hipMalloc((void **)&cell_id, sizeof(uint32_t) * (size_t)S->n_cells));
+        DG_HIP(hipMemcpy(cell_id, desc->cell_global_id, sizeof(uint32_t) * (size_t)S->n_cells, hipMemcpyHostToDevice));
+      }
+    {
+      const uint32_t n3   = (uint32_t)(n / S->n_cells);
+      const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+      if (S->number == MGX_F64)
+        hipLaunchKernelGGL(k_start_vector<double>, dim3(grid), dim3(256), 0, s, (double *)r, cell_id, S->n_cells, n3, mean);
+      else
+        hipLaunchKernelGGL(k_start_vector<float>, dim3(grid), dim3(256), 0, s, (float *)r, cell_id, S->n_cells, n3, mean);
+      DG_HIP(hipStreamSynchronize(s));
+      (void)hipFree(cell_id);
+    }
     std::vector<double> diag, off;
     double              res = 0, rz = 0, rz_old = 0, alpha = 0, alpha_old = 0, beta = 0;
-    MGX_DG_TRY(mgx_l2_norm(ctx, S->number, r, n, &res));
+    MGX_DG_TRY(dg_norm(S.get(), S->number, r, &res));
     int it = 0;
     while (it < 15 && res > 1e-10)
       {
         ++it;
         rz_old = rz;
         MGX_DG_TRY(mgx_dg_jacobi_vmult(A, z, r));
-        MGX_DG_TRY(mgx_dot(ctx, S->number, r, z, n, &rz));
+        MGX_DG_TRY(dg_dot(S.get(), S->number, r, z, &rz));
         if (it > 1)
           {
             beta = rz / rz_old;
@@ -1820,10 +1876,10 @@ int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_
         alpha_old = alpha;
         MGX_DG_TRY(mgx_dg_vmult(A, h, d));
         double dh = 0;
-        MGX_DG_TRY(mgx_dot(ctx, S->number, d, h, n, &dh));
+        MGX_DG_TRY(dg_dot(S.get(), S->number, d, h, &dh));
         alpha = rz / dh;
         MGX_DG_TRY(mgx_sadd(ctx, S->number, r, 1.0, -alpha, h, n));
-        MGX_DG_TRY(mgx_l2_norm(ctx, S->number, r, n, &res));
+        MGX_DG_TRY(dg_norm(S.get(), S->number, r, &res));
         if (it == 1)
           diag.push_back(1. / alpha);
         else
@@ -1923,10 +1979,10 @@ int mgx_dg_solver_solve_cg(mgx_dg_solver_t S, double tolerance, const double *rh
   const size_t  n   = S->n;
   hipStream_t   s   = (hipStream_t)mgx_context_stream(ctx);
   double       *r = S->r, *z = S->z, *d = S->d, *h = S->h;
-  DG_HIP(hipMemsetAsync(solution, 0, 8 * n, s));
+  DG_HIP(hipMemsetAsync(solution, 0, 8 * S->n_vec, s));
   MGX_DG_TRY(mgx_copy_cast(ctx, r, MGX_F64, rhs, MGX_F64, n));
   double res0 = 0, res = 0, rz = 0, rz_old = 0;
-  MGX_DG_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
+  MGX_DG_TRY(dg_norm(S, MGX_F64, r, &res0));
   res         = res0;
   unsigned it = 0;
   while (res > std::max(1e-16, tolerance * res0) && it < 100)
@@ -1934,18 +1990,18 @@ int mgx_dg_solver_solve_cg(mgx_dg_solver_t S, double tolerance, const double *rh
       ++it;
       MGX_DG_TRY(mgx_dg_solver_vmult(S, z, r));
       rz_old = rz;
-      MGX_DG_TRY(mgx_dot(ctx, MGX_F64, r, z, n, &rz));
+      MGX_DG_TRY(dg_dot(S, MGX_F64, r, z, &rz));
       if (it > 1)
         MGX_DG_TRY(mgx_sadd(ctx, MGX_F64, d, rz / rz_old, 1.0, z, n));
       else
         MGX_DG_TRY(mgx_copy_cast(ctx, d, MGX_F64, z, MGX_F64, n));
       MGX_DG_TRY(mgx_dg_vmult(S->A_dp, h, d));
       double dh = 0;
-      MGX_DG_TRY(mgx_dot(ctx, MGX_F64, d, h, n, &dh));
+      MGX_DG_TRY(dg_dot(S, MGX_F64, d, h, &dh));
       const double alpha = rz / dh;
       MGX_DG_TRY(mgx_sadd(ctx, MGX_F64, solution, 1.0, alpha, d, n));
       MGX_DG_TRY(mgx_sadd(ctx, MGX_F64, r, 1.0, -alpha, h, n));
-      MGX_DG_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res));
+      MGX_DG_TRY(dg_norm(S, MGX_F64, r, &res));
     }
   if (iterations)
     *iterations = it;

@@ -143,6 +143,7 @@ namespace mgx
   int  exchange_buffers(struct ::mgx_context_s *ctx, int plan_id, int number, int n_neighbors, const int *ranks,
                         const uint32_t *counts, void *const *send, void *const *recv);
   int  allreduce_sum(struct ::mgx_context_s *ctx, double *values, int count);
+  int  dot_owned_prefix(struct ::mgx_context_s *ctx, int number, const void *x, const void *y, size_t n, double *out);
   bool context_has_comm(struct ::mgx_context_s *ctx);
 
   // records the message mgx_last_error() returns on the calling thread; returns `code` (used by the

@@ -28,9 +28,11 @@ class Pair:
         self.fe = Oracle(p, 1, nr, degree=degree_pre, vfloat=(number == mg.F32))
         self.ijk = self.solver.cell_ijk
         n = self.solver.m()
+        # deal.II: (global DoF index mod 11) - mean; the global index of a DG DoF is taken from the
+        # lexicographic position of its cell, which is the oracle's own layout
         start = (np.arange(n) % 11).astype(float)
         start -= start.mean()
-        self.orc = dg.DGMultigridOracle(self.dgo, self.fe, degree_pre, self.to_oracle(start))
+        self.orc = dg.DGMultigridOracle(self.dgo, self.fe, degree_pre, start.reshape(self.dgo.shape))
         # FE_Q vectors: provider numbering <-> oracle numbering through the lexicographic grid
         l = self.cube.max_level
         gc, go = self.cube.dof_grid(l), self.fe.dof_grid(l)
@@ -144,3 +146,12 @@ def test_poisson_dg_harness_runs():
         rows.append(lines[-1].split())
     assert int(rows[0][0]) == 64 and int(rows[1][0]) == 512 and int(rows[1][1]) == 512 * 64
     assert 5 <= int(rows[0][6]) <= 10 and 5 <= int(rows[1][6]) <= 10
+
+
+@pytest.mark.parametrize("world,p,nr,basis,number", [(2, 3, 2, 0, "f64"), (4, 2, 2, 0, "f64"), (2, 3, 2, 2, "f32")])
+def test_decomposed_dg_multigrid_matches_single_domain_oracle(world, p, nr, basis, number):
+    """DG level with ghost cells on top of the decomposed FE_Q hierarchy: 2 and 4 ranks over gloo on
+    the one GPU, smoother parameters, V-cycle and CG against the single-domain restatement"""
+    from test_decomposition import launch
+    outs = launch(None, world, None, None, extra=(str(p), str(nr), str(basis), number), worker="dg_mg_dist_worker.py")
+    assert all("dg multigrid ok" in o for o in outs), outs

@@ -2,7 +2,11 @@
 [-0.9, 1]^3, rhs 3 (3 pi)^2 prod sin(3 pi x_d), V-cycle-preconditioned CG with the DG level on top of the
 FE_Q(p) multigrid (fp32 V-cycle inside the fp64 outer iteration, program.cc:72-73).
 
-    python tools/poisson_dg.py [degree=3] [n_refine=5] [n_pre_smooth=3] [tolerance=1e-9] [--vcycle f32|f64]
+    python tools/poisson_dg.py [degree=3] [n_refine=5] [n_pre_smooth=3] [tolerance=1e-9] [--vcycle f32|f64] [--gpus N]
+
+--gpus N: the cube is block-split over N ranks (2x1x1 / 2x2x1 / 2x2x2 coarse cells of the mesh with n_subdiv = 2,
+refined n_refine - 1 times: the same cells as on one GPU), one process per GPU, started by this script or by
+torch.distributed.run; MGX_BENCH_BACKEND=gloo runs the ranks on one GPU (functional test).
 
 Prints the reference's lines ("Time solve CG", "matvec time dp/sp ... DoFs/s", "L2 error with ndof = ...") and
 the row of its convergence table (cells dofs mv_outer mv_inner cg_L2error cg_time cg_its cg_reduction,
@@ -36,16 +40,60 @@ def main():
     ap.add_argument("tolerance", nargs="?", type=float, default=1e-9)
     ap.add_argument("--vcycle", choices=["f32", "f64"], default="f32")
     ap.add_argument("--basis", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn(a.gpus)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    dist = comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if os.environ.get("MGX_BENCH_BACKEND", "nccl") == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            dist.init_process_group(os.environ["MGX_BENCH_BACKEND"])
+    say = print if rank == 0 else (lambda *x, **k: None)
+
+    def total(v):
+        if dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return float(t.item())
+
+    def slowest(v):
+        if dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     vnum = mg.F32 if a.vcycle == "f32" else mg.F64
     t0 = time.time()
-    ctx = mg.Context(0)
-    cube = mg.Cube(a.degree, 1, a.n_refine)
-    solver = mg.DGMultigridSolver(ctx, cube, a.basis, a.n_pre_smooth, vnum)
-    n = solver.m()
+    ctx = mg.Context(local_rank)
+    if world > 1:
+        comm = mg.Communicator(ctx, dist)
+        if comm.native_ready:
+            mg.check(ctx.lib.mgx_context_use_rccl(ctx.h, 1))
+        cube = mg.Cube(a.degree, n_refine=a.n_refine - 1, box=(2, 2, 2), procs=mg.process_grid(world), rank=rank,
+                       origin=-0.9, h0=0.95)
+    else:
+        cube = mg.Cube(a.degree, 1, a.n_refine)
+    solver = mg.DGMultigridSolver(ctx, cube, a.basis, a.n_pre_smooth, vnum, comm=comm)
+    n_own = solver.m()
+    n = int(round(total(n_own)))
     nc = n // (a.degree + 1) ** 3
-    print("Number of degrees of freedom: %d (%d cells, FE_DGQHermite(%d) on FE_Q(%d) multigrid, V-cycle in %s)"
-          % (n, nc, a.degree, a.degree, a.vcycle))
+    nc_own = n_own // (a.degree + 1) ** 3
+    say("Number of degrees of freedom: %d (%d cells, FE_DGQHermite(%d) on FE_Q(%d) multigrid, V-cycle in %s, %d GPU%s)"
+        % (n, nc, a.degree, a.degree, a.vcycle, world, "" if world == 1 else "s"))
     S, xq, wq = solver.matrix_dg.basis_1d()
     h = cube.cell_size(cube.max_level)
     S3 = np.kron(S, np.kron(S, S))
@@ -53,23 +101,23 @@ def main():
     x = quad_points(cube, solver.cell_ijk.astype(float), xq, h)
     u = np.prod(np.sin(np.pi * WAVE * x), axis=-1)
     rhs = ((3 * (np.pi * WAVE) ** 2 * u) * w3) @ S3          # program.cc:137-141, multigrid_solver_dg.h:243-262
-    print("Time setup                    %.3f s   rhs_norm = %.6e" % (time.time() - t0, np.linalg.norm(rhs)))
-    b, sol = ctx.vector(n, data=rhs.ravel()), ctx.vector(n)
+    say("Time setup                    %.3f s   rhs_norm = %.6e" % (time.time() - t0, np.sqrt(total(float(np.sum(rhs ** 2))))))
+    b, sol = solver.initialize_dof_vector(rhs.ravel()), solver.initialize_dof_vector()
     time_cg = 1e10
     for _ in range(4):                                          # program.cc:252-258
         ctx.sync()
         t = time.perf_counter()
         its, red = solver.solve_cg(b, sol, a.tolerance)
         ctx.sync()
-        dt = time.perf_counter() - t
+        dt = slowest(time.perf_counter() - t)
         time_cg = min(time_cg, dt)
-        print("Time solve CG                 %.6f s   (%d iterations, reduction %.4e)" % (dt, its, red))
-    uh = sol.download().reshape(nc, -1) @ S3.T
-    l2 = np.sqrt(np.sum(w3 * (uh - u) ** 2) / (nc * h ** 3))    # multigrid_solver_dg.h:328-367
+        say("Time solve CG                 %.6f s   (%d iterations, reduction %.4e)" % (dt, its, red))
+    uh = sol.download()[:n_own].reshape(nc_own, -1) @ S3.T
+    l2 = np.sqrt(total(float(np.sum(w3 * (uh - u) ** 2))) / (nc * h ** 3))    # multigrid_solver_dg.h:328-367
     A_dp, A_sp = solver.matrix_dg_dp, solver.matrix_dg
     best = {}
     for name, A, number in (("dp", A_dp, mg.F64), ("sp", A_sp, vnum)):
-        v, w = ctx.vector(n, number, np.ones(n)), ctx.vector(n, number)
+        v, w = A.initialize_dof_vector(np.ones(n_own)), A.initialize_dof_vector()
         n_mv = 200 if n < 10000000 else 50
         best[name] = 1e10
         for _ in range(5):
@@ -78,18 +126,40 @@ def main():
             for _ in range(n_mv):
                 A.vmult(w, v)
             ctx.sync()
-            dt = (time.perf_counter() - t) / n_mv
+            dt = slowest((time.perf_counter() - t) / n_mv)
             best[name] = min(best[name], dt)
-            print("matvec time %s %.6e DoFs/s: %.5e" % (name, dt, n / dt))
+            say("matvec time %s %.6e DoFs/s: %.5e" % (name, dt, n / dt))
         v.free(); w.free()
-    print("Best timings for ndof = %d   mv %.6e    mv smooth %.6e   cg-mg %.6e" % (n, best["dp"], best["sp"], time_cg))
-    print("L2 error with ndof = %d  %.6e" % (n, l2))
-    print("cells dofs mv_outer mv_inner cg_L2error cg_time cg_its cg_reduction")
-    print("%d %d %.4e %.4e %.4e %.4e %d %.4e  | %.3e DoFs/s solved per second of CG"
+    say("Best timings for ndof = %d   mv %.6e    mv smooth %.6e   cg-mg %.6e" % (n, best["dp"], best["sp"], time_cg))
+    say("L2 error with ndof = %d  %.6e" % (n, l2))
+    say("cells dofs mv_outer mv_inner cg_L2error cg_time cg_its cg_reduction")
+    say("%d %d %.4e %.4e %.4e %.4e %d %.4e  | %.3e DoFs/s solved per second of CG"
           % (nc, n, best["dp"], best["sp"], l2, time_cg, its, red, n / time_cg))
     solver.close()
     cube.close()
     ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def spawn(n):
+    """start n ranks of this script (the parent never touches the GPU)"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    one_gpu = os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise SystemExit("poisson_dg.py: rank exit codes %s" % codes)
 
 
 if __name__ == "__main__":
