@@ -107,6 +107,7 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.restrict_atomic     = flag("MGX_RESTRICT_ATOMIC");
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
   t.exchange_unfused    = flag("MGX_EXCHANGE_UNFUSED");
+  t.cell_colour_min     = num("MGX_CELL_COLOUR_MIN", t.cell_colour_min);
   t.no_graph            = flag("MGX_NO_GRAPH");
   t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
   t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
@@ -1157,6 +1158,64 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
             }
         }
     }
+  if (general && desc->n_cells >= tun.cell_colour_min)
+    {
+      // Cell colouring for the general branch: greedy over the cells in their order, two cells
+      // conflict if they share a mesh entity that carries DoFs (its first DoF is the key).  On the
+      // structured meshes of the provider this gives the 8 parity classes.  More than 32 colours:
+      // keep the single launch with atomics.
+      const int             pm1 = p - 1;
+      std::vector<uint32_t> used(desc->n_dofs, 0u);
+      std::vector<uint8_t>  colour(desc->n_cells, 0);
+      uint32_t              count[33] = {0};
+      int                   n_colours = 0;
+      bool                  ok        = true;
+      for (uint32_t c = 0; c < desc->n_cells && ok; ++c)
+        {
+          const uint32_t *ix   = desc->idx27 + 27 * (size_t)c;
+          uint32_t        mask = 0;
+          for (int e = 0; e < 27; ++e)
+            {
+              const int inner = (e % 3 == 1) + ((e / 3) % 3 == 1) + (e / 9 == 1);
+              if (inner == 3 || (inner > 0 && pm1 == 0) || ix[e] == MGX_INVALID_INDEX)
+                continue;
+              mask |= used[ix[e]];
+            }
+          int col = 0;
+          while (col < 32 && (mask >> col) & 1u)
+            ++col;
+          if (col == 32)
+            {
+              ok = false;
+              break;
+            }
+          colour[c] = (uint8_t)col;
+          ++count[col];
+          n_colours = std::max(n_colours, col + 1);
+          for (int e = 0; e < 27; ++e)
+            {
+              const int inner = (e % 3 == 1) + ((e / 3) % 3 == 1) + (e / 9 == 1);
+              if (inner == 3 || (inner > 0 && pm1 == 0) || ix[e] == MGX_INVALID_INDEX)
+                continue;
+              used[ix[e]] |= 1u << col;
+            }
+        }
+      if (ok)
+        {
+          std::vector<uint32_t> order(desc->n_cells), fill(33, 0);
+          d.cell_colour_start[0] = 0;
+          for (int k = 0; k < n_colours; ++k)
+            d.cell_colour_start[k + 1] = d.cell_colour_start[k] + count[k];
+          for (int k = 0; k < n_colours; ++k)
+            fill[k] = d.cell_colour_start[k];
+          for (uint32_t c = 0; c < desc->n_cells; ++c)
+            order[fill[colour[c]]++] = c;
+          d.n_cell_colours = n_colours;
+          MGX_HIP(hipMalloc((void **)&d.cell_order, sizeof(uint32_t) * (size_t)desc->n_cells));
+          MGX_HIP(hipMemcpy(d.cell_order, order.data(), sizeof(uint32_t) * (size_t)desc->n_cells, hipMemcpyHostToDevice));
+          MGX_TRACE("operator_create: general branch, %u cells in %d colours", desc->n_cells, n_colours);
+        }
+    }
   // brick schedule for the atomic-free cell loop (mgx_brick.hip); MGX_NO_BRICKS=1 keeps the
   // per-cell kernel (A/B measurements)
   if (!tun.no_bricks && !general && (p <= 4 || d.separable))
@@ -1410,6 +1469,7 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.inv_diag);
   (void)hipFree(op->d.coef_q);
   (void)hipFree(op->d.grad_1d);
+  (void)hipFree(op->d.cell_order);
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);

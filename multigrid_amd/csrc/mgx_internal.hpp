@@ -38,6 +38,7 @@ namespace mgx
     bool     restrict_atomic  = false; // MGX_RESTRICT_ATOMIC  one-launch restriction with atomics on every level
     uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour
     bool     exchange_unfused = false; // MGX_EXCHANGE_UNFUSED one pack / unpack launch per neighbour
+    uint32_t cell_colour_min  = 4096;  // MGX_CELL_COLOUR_MIN  general-coefficient levels from this many cells run colour by colour
     bool     no_graph         = false; // MGX_NO_GRAPH         no HIP-graph replay of the coarse levels
     uint32_t graph_max_dofs   = 600000; // MGX_GRAPH_MAX_DOFS  largest level inside the replayed graph
     bool     rccl_selftest    = false; // MGX_RCCL_SELFTEST    one-rank communicator may name itself as neighbour
@@ -105,6 +106,11 @@ namespace mgx
     bool      full_tensor   = false;   // affine cells with off-diagonal coefficient entries (:473-486)
     void     *coef_q        = nullptr; // device [n_cells][6][n^3], number type: general branch (:493-522)
     void     *grad_1d       = nullptr; // device [n*n], number type: G = D S, nodal derivative at the quadrature points
+    // general branch on levels with many cells: cells sorted by colour (cells of one colour share
+    // no DoF), one launch per colour without atomics; nullptr: one launch with atomic adds
+    uint32_t *cell_order    = nullptr; // device [n_cells]
+    int       n_cell_colours = 0;
+    uint32_t  cell_colour_start[33] = {0};
     BrickData bricks;
     bool      cells_form    = false; // Tunables::cells_form of the context the operator was created on
     uint32_t  wide_max      = 1024;  // Tunables::wide_max

@@ -21,13 +21,16 @@
 
 namespace mgx
 {
-  template <int P>
+#ifndef MGX_GENERAL_WG_THREADS
+#define MGX_GENERAL_WG_THREADS 256 // 128 measured: no gain
+#endif
+  template <int P, int WG = 256>
   struct Cfg
   {
     static constexpr int N        = P + 1;
     static constexpr int LN       = N | 1; // x-line pitch, odd => conflict-free ds_read_b64
     static constexpr int TPC      = N * N; // threads per cell
-    static constexpr int CPB      = (256 / TPC) < 1 ? 1 : (256 / TPC);
+    static constexpr int CPB      = (WG / TPC) < 1 ? 1 : (WG / TPC);
     static constexpr int THREADS  = ((CPB * TPC + 63) / 64) * 64;
     static constexpr int CELL_LDS = N * N * LN;
   };
@@ -120,6 +123,23 @@ namespace mgx
       }
     if (L.b2 != kInvalid)
       unsafeAtomicAdd(&dst[L.b2 + L.off], r[P]);
+  }
+
+  // the same without atomics: for launches over cells of one colour (no two of them share a DoF)
+  template <int P, typename T>
+  __device__ __forceinline__ void scatter_add_line_plain(T *__restrict__ dst, const LineIndex<P> &L,
+                                                         const T (&r)[P + 1])
+  {
+    if (L.b0 != kInvalid)
+      dst[L.b0 + L.off] += r[0];
+    if (L.b1 != kInvalid)
+      {
+#pragma unroll
+        for (int i = 0; i < P - 1; ++i)
+          dst[L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i] += r[1 + i];
+      }
+    if (L.b2 != kInvalid)
+      dst[L.b2 + L.off] += r[P];
   }
 
   // ------------------------------------------------------------------------------------------
@@ -279,13 +299,15 @@ namespace mgx
   // component with unit stride.  109.75 B per DoF at p = 4 against 16 B of the vectors:
   // this kernel is bound by the coefficient stream.
   // ------------------------------------------------------------------------------------------
+  // cell_list != nullptr: the launch covers the n_cells cells cell_list[0 .. n_cells) of one colour
+  // (no shared DoFs among them) and adds to dst without atomics
   template <int P, typename T, bool PERQ>
-  __global__ void __launch_bounds__(Cfg<P>::THREADS)
+  __global__ void __launch_bounds__((Cfg<P, MGX_GENERAL_WG_THREADS>::THREADS))
     cell_loop_general_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
                              uint32_t n_cells, const Basis1D<T> *__restrict__ B, const T *__restrict__ coef_q, T c0,
-                             T c1, T c2, T c3, T c4, T c5)
+                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list)
   {
-    using C           = Cfg<P>;
+    using C           = Cfg<P, MGX_GENERAL_WG_THREADS>;
     constexpr int N   = C::N;
     constexpr int LN  = C::LN;
     constexpr int PL  = N * LN;
@@ -299,8 +321,9 @@ namespace mgx
     const int      t      = tid - lc * C::TPC;
     const int      a      = t % N;
     const int      b      = t / N;
-    const uint32_t cell   = blockIdx.x * C::CPB + lc;
-    const bool     active = (lc < C::CPB) && (cell < n_cells);
+    const uint32_t pos    = blockIdx.x * C::CPB + lc;
+    const bool     active = (lc < C::CPB) && (pos < n_cells);
+    const uint32_t cell   = (cell_list && active) ? cell_list[pos] : pos;
     const int      slot   = lc < C::CPB ? lc : 0;
     T             *Uc = U + slot * C::CELL_LDS, *Xc = GX + slot * C::CELL_LDS, *Yc = GY + slot * C::CELL_LDS;
     const int      xl = (b * N + a) * LN, yl = b * PL + a, zl = b * LN + a;
@@ -436,7 +459,10 @@ namespace mgx
         for (int i = 0; i < N; ++i)
           r[i] = Uc[xl + i];
         mvT<N, T>(B->S, r, q);
-        scatter_add_line<P, T>(dst, L, q);
+        if (cell_list)
+          scatter_add_line_plain<P, T>(dst, L, q);
+        else
+          scatter_add_line<P, T>(dst, L, q);
       }
   }
 
@@ -742,14 +768,30 @@ namespace mgx
   {
     using C            = Cfg<P>;
     const uint32_t nb  = (op.n_cells + C::CPB - 1) / C::CPB;
-    if (op.coef_q)
-      hipLaunchKernelGGL((cell_loop_general_kernel<P, T, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
-                         op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (const T *)op.coef_q, (T)0, (T)0, (T)0, (T)0,
-                         (T)0, (T)0);
-    else if (op.full_tensor)
-      hipLaunchKernelGGL((cell_loop_general_kernel<P, T, false>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
-                         op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (const T *)nullptr, (T)op.coef[0],
-                         (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5]);
+    if (op.coef_q || op.full_tensor)
+      {
+        using C = Cfg<P, MGX_GENERAL_WG_THREADS>;
+        // one launch with atomics, or one launch per cell colour with plain read-modify-writes
+        const int n_launch = op.cell_order ? op.n_cell_colours : 1;
+        for (int k = 0; k < n_launch; ++k)
+          {
+            const uint32_t  first = op.cell_order ? op.cell_colour_start[k] : 0;
+            const uint32_t  count = op.cell_order ? op.cell_colour_start[k + 1] - first : op.n_cells;
+            const uint32_t *list  = op.cell_order ? op.cell_order + first : nullptr;
+            const uint32_t  nbk   = (count + C::CPB - 1) / C::CPB;
+            if (count == 0)
+              continue;
+            if (op.coef_q)
+              hipLaunchKernelGGL((cell_loop_general_kernel<P, T, true>), dim3(nbk), dim3(C::THREADS), 0, s, (T *)dst,
+                                 (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)op.coef_q, (T)0,
+                                 (T)0, (T)0, (T)0, (T)0, (T)0, list);
+            else
+              hipLaunchKernelGGL((cell_loop_general_kernel<P, T, false>), dim3(nbk), dim3(C::THREADS), 0, s, (T *)dst,
+                                 (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)nullptr,
+                                 (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5],
+                                 list);
+          }
+      }
     else
       hipLaunchKernelGGL((cell_loop_kernel<P, T>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
                          op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],

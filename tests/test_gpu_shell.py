@@ -118,3 +118,34 @@ def test_affine_full_tensor(ctx, p):
     assert np.array_equal(inv[cons], np.ones(cons.size))
     op.clear()
     orc.close()
+
+
+@pytest.mark.parametrize("geometry,problem,p,nr", [("shell_sector", "shell", 4, 2), ("sheared", "cube", 2, 3), ("sheared", "shell", 3, 2),
+                                                   ("shell_sector", "shell", 1, 3)])
+def test_colour_by_colour_launches_of_the_general_branch(monkeypatch, geometry, problem, p, nr):
+    """levels with many cells run the general branch colour by colour without atomics (greedy cell
+    colouring from the shared entities; production threshold 4096 cells): forced on every level here,
+    against the oracle, bitwise reproducible, and equal to the atomic form up to the summation order"""
+    monkeypatch.setenv("MGX_CELL_COLOUR_MIN", "1")
+    c = mg.Context(0)
+    monkeypatch.setenv("MGX_CELL_COLOUR_MIN", "4000000000")
+    c_atomic = mg.Context(0)
+    cube = mg.Cube(p, n_refine=nr, box=(1, 1, 1), origin=-0.9, h0=1.9, geometry=geometry, problem=problem)
+    orc = oracle_for(cube, p, 1, nr, geometry=geometry, problem=problem, origin=-0.9, h0=1.9)
+    for l in range(cube.n_levels):
+        op, opa = mg.LaplaceOperator.from_cube(c, cube, l), mg.LaplaceOperator.from_cube(c_atomic, cube, l)
+        x = cube.seeded_vector(l, 3)
+        src, dst, again = c.vector(x.size, data=x), c.vector(x.size), c.vector(x.size)
+        op.vmult(dst, src)
+        op.vmult(again, src)
+        assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+        assert np.array_equal(dst.download(), again.download())
+        sa, da = c_atomic.vector(x.size, data=x), c_atomic.vector(x.size)
+        opa.vmult(da, sa)
+        assert rel(da.download(), dst.download()) < 1e-13
+        op.clear()
+        opa.clear()
+    cube.close()
+    orc.close()
+    c.close()
+    c_atomic.close()
