@@ -25,3 +25,19 @@ dt = (time.perf_counter() - t) / reps
 bpd = 16 + 48 * ((p + 1) / p) ** 3
 print("shell sector p=%d: vmult %.3f ms, %.3e DoFs/s, %.1f B/DoF algorithmic -> %.2f TB/s = %.3f of 8 TB/s"
       % (p, dt * 1e3, n / dt, bpd, bpd * n / dt / 1e12, bpd * n / dt / 8e12))
+# the V-cycle on the same mesh (Chebyshev degree 3): every operator application is the general branch
+t = time.time()
+solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+z = ctx.vector(n)
+rhs = solver.get_vector(l, "rhs")
+for _ in range(2):
+    solver.vmult(z, rhs)
+ctx.sync()
+t1 = time.perf_counter()
+for _ in range(5):
+    solver.vmult(z, rhs)
+ctx.sync()
+dtv = (time.perf_counter() - t1) / 5
+print("shell sector p=%d: V-cycle %.3f ms, %.3e DoFs/s (solver setup %.1f s)" % (p, dtv * 1e3, n / dtv, time.time() - t - 7 * dtv))
+its, red = solver.solve_cg()
+print("shell sector p=%d: PCG %d iterations, reduction %.3e per iteration, L2 error %.3e" % (p, its, red, solver.compute_l2_error()))
