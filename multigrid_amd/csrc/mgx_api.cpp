@@ -95,6 +95,7 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.general_kernel      = flag("MGX_GENERAL_KERNEL");
   t.no_bricks           = flag("MGX_NO_BRICKS");
   t.brick_min           = num("MGX_BRICK_MIN", t.brick_min);
+  t.brick_min_from_env  = flag("MGX_BRICK_MIN");
   t.overlap_min         = num("MGX_OVERLAP_MIN_BRICKS", t.overlap_min);
   t.cells_form          = std::getenv("MGX_BRICK_FORM") && std::string(std::getenv("MGX_BRICK_FORM")) == "cells";
   t.wide_max            = num("MGX_BRICK_WIDE_MAX", t.wide_max);
@@ -1223,10 +1224,12 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       BrickHost   bh;
       std::string why;
       const mgx_exchange_desc *ex = desc->exchange;
-      // A colour launch needs a few hundred bricks to fill 256 CUs; below that the per-cell kernel
-      // (all cells of the level in one launch, atomic scatter) is faster.  Measured cross-over on
-      // MI355X: between 512 and 4096 bricks for p = 4 and p = 8 (tools/vcycle_levels.py).
-      const uint32_t brick_min   = tun.brick_min;
+      // The eight colour launches of a brick loop cost about 80 us however small the level is; below
+      // that the per-cell kernel (all cells of the level in one launch, atomic scatter) is faster.
+      // Measured cross-over with the macro-element kernel on MI355X (tools/time_matvec.py): p = 4 and
+      // p = 8 between 216 and 512 bricks (512: 0.082 vs 0.098 ms, 0.090 vs 0.134 ms), p = 2 between 512
+      // and 1728 bricks (512: 0.042 vs 0.028 ms).  MGX_BRICK_MIN overrides the threshold as given.
+      const uint32_t brick_min   = tun.brick_min_from_env ? tun.brick_min : (p <= 2 ? 2 * tun.brick_min : tun.brick_min);
       const uint32_t brick_cells = p <= 4 ? 64u : 8u;
       // Decomposed mesh: from this many bricks per rank on, the bricks on the rank interface are
       // launched first and the exchange overlaps with the interior bricks.  The split costs one

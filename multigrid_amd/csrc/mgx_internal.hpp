@@ -25,7 +25,8 @@ namespace mgx
     bool     trace            = false; // MGX_TRACE            host control flow on stderr
     bool     general_kernel   = false; // MGX_GENERAL_KERNEL   quadrature-point form instead of the separable one
     bool     no_bricks        = false; // MGX_NO_BRICKS        per-cell kernel on every level
-    uint32_t brick_min        = 2048;  // MGX_BRICK_MIN        bricks per level from which the brick loop is used
+    uint32_t brick_min        = 512;   // MGX_BRICK_MIN        bricks per level from which the brick loop is used (measured crossover with the per-cell kernel: between 216 and 512 bricks)
+    bool     brick_min_from_env = false;
     uint32_t overlap_min      = 16384; // MGX_OVERLAP_MIN_BRICKS  bricks per rank from which interface bricks run first
     bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
     uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads

@@ -4,7 +4,7 @@ import sys
 import pytest
 
 # the parity cases are small: let every level that has at least one brick run the brick cell loop
-# (the production default switches to it from 2048 bricks on; test_gpu_parity.py has one case at the
+# (the production default switches to it from 512 bricks on (1024 for p <= 2); test_gpu_parity.py has one case at the
 # default threshold)
 os.environ.setdefault("MGX_BRICK_MIN", "1")
 # likewise the colour-by-colour (atomic-free) restriction, production default from 16384 coarse cells on

@@ -229,7 +229,7 @@ def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
 
 
 def test_default_brick_threshold(monkeypatch):
-    """With the production threshold (bricks from 2048 per level on) small levels use the per-cell
+    """With the production threshold (bricks from 512 per level on, 1024 for p <= 2) small levels use the per-cell
     kernel and the finest level of a 64^3 mesh (4096 bricks) the brick loop; same results."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
