@@ -109,6 +109,7 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
   t.exchange_unfused    = flag("MGX_EXCHANGE_UNFUSED");
   t.cell_colour_min     = num("MGX_CELL_COLOUR_MIN", t.cell_colour_min);
+  t.fused_general       = flag("MGX_FUSED_GENERAL");
   t.no_graph            = flag("MGX_NO_GRAPH");
   t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
   t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
@@ -1214,6 +1215,40 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
           d.n_cell_colours = n_colours;
           MGX_HIP(hipMalloc((void **)&d.cell_order, sizeof(uint32_t) * (size_t)desc->n_cells));
           MGX_HIP(hipMemcpy(d.cell_order, order.data(), sizeof(uint32_t) * (size_t)desc->n_cells, hipMemcpyHostToDevice));
+          // first / last cell, in colour order, on every entity: the fused Chebyshev update of the
+          // colour-by-colour launches stores instead of adding on FIRST and completes a DoF on LAST
+          std::vector<uint8_t> lo(desc->n_dofs, 255), hi(desc->n_dofs, 0);
+          auto                 carries = [&](int e) {
+            const int inner = (e % 3 == 1) + ((e / 3) % 3 == 1) + (e / 9 == 1);
+            return !(inner > 0 && pm1 == 0);
+          };
+          for (uint32_t c = 0; c < desc->n_cells; ++c)
+            for (int e = 0; e < 27; ++e)
+              {
+                const uint32_t k = desc->idx27[27 * (size_t)c + e];
+                if (e == 13 || !carries(e) || k == MGX_INVALID_INDEX)
+                  continue;
+                lo[k] = std::min(lo[k], colour[c]);
+                hi[k] = std::max(hi[k], colour[c]);
+              }
+          std::vector<uint64_t> fl(desc->n_cells, 0);
+          for (uint32_t c = 0; c < desc->n_cells; ++c)
+            {
+              uint64_t f = (1ull << 13) | (1ull << (27 + 13)); // the cell interior belongs to the cell alone
+              for (int e = 0; e < 27; ++e)
+                {
+                  const uint32_t k = desc->idx27[27 * (size_t)c + e];
+                  if (e == 13 || !carries(e) || k == MGX_INVALID_INDEX)
+                    continue;
+                  if (lo[k] == colour[c])
+                    f |= 1ull << e;
+                  if (hi[k] == colour[c])
+                    f |= 1ull << (27 + e);
+                }
+              fl[c] = f;
+            }
+          MGX_HIP(hipMalloc((void **)&d.cell_flags, sizeof(uint64_t) * (size_t)desc->n_cells));
+          MGX_HIP(hipMemcpy(d.cell_flags, fl.data(), sizeof(uint64_t) * (size_t)desc->n_cells, hipMemcpyHostToDevice));
           MGX_TRACE("operator_create: general branch, %u cells in %d colours", desc->n_cells, n_colours);
         }
     }
@@ -1473,6 +1508,7 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.coef_q);
   (void)hipFree(op->d.grad_1d);
   (void)hipFree(op->d.cell_order);
+  (void)hipFree(op->d.cell_flags);
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);
@@ -1871,6 +1907,15 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
+  if (!op->d.bricks.available())
+    {
+      // colour-by-colour general branch (variable coefficient / full tensor), one rank
+      launch_cell_loop_fused(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old);
+      launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
+                              op->d.n_constrained, nullptr, old, f0);
+      MGX_HIP(hipGetLastError());
+      return MGX_OK;
+    }
   // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the update there
   MGX_TRY(brick_loop_with_exchange(
     op, mode, sm->tmp,
@@ -1905,7 +1950,12 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
   hipStream_t              s  = op->ctx->stream;
   const int                num = op->d.number;
   const size_t             n   = op->d.n_dofs;
-  if (!op->d.bricks.available())
+  // levels without a brick schedule: matvec + elementwise update, unless the general branch runs
+  // colour by colour on one rank and MGX_FUSED_GENERAL asks for the update inside the cell loop (as on
+  // brick levels; off by default: the scattered reads of the update cost more than the streaming kernel)
+  const bool general_fused = !op->d.bricks.available() && op->d.cell_order && op->d.cell_flags && !op->plan &&
+                             op->ctx->tun.fused_general;
+  if (!op->d.bricks.available() && !general_fused)
     {
       if (is_step)
         {

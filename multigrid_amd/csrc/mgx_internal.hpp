@@ -39,6 +39,7 @@ namespace mgx
     bool     restrict_atomic  = false; // MGX_RESTRICT_ATOMIC  one-launch restriction with atomics on every level
     uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour
     bool     exchange_unfused = false; // MGX_EXCHANGE_UNFUSED one pack / unpack launch per neighbour
+    bool     fused_general    = false; // MGX_FUSED_GENERAL    general branch: Chebyshev update inside the colour launches (measured slower than the streaming update kernel: 7.5 vs 7.0 ms per V-cycle on the shell sector)
     uint32_t cell_colour_min  = 4096;  // MGX_CELL_COLOUR_MIN  general-coefficient levels from this many cells run colour by colour
     bool     no_graph         = false; // MGX_NO_GRAPH         no HIP-graph replay of the coarse levels
     uint32_t graph_max_dofs   = 600000; // MGX_GRAPH_MAX_DOFS  largest level inside the replayed graph
@@ -110,6 +111,7 @@ namespace mgx
     // general branch on levels with many cells: cells sorted by colour (cells of one colour share
     // no DoF), one launch per colour without atomics; nullptr: one launch with atomic adds
     uint32_t *cell_order    = nullptr; // device [n_cells]
+    uint64_t *cell_flags    = nullptr; // device [n_cells]: bit e: first, bit 27 + e: last cell (in colour order) on entity e
     int       n_cell_colours = 0;
     uint32_t  cell_colour_start[33] = {0};
     BrickData bricks;
@@ -236,6 +238,8 @@ namespace mgx
   // interface exchange helpers
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
   // DG <-> FE_Q transfer on one mesh (mgx_kernels.hip): to_dg: dg += P cg, else cg += P^T dg
+  void launch_cell_loop_fused(hipStream_t s, const OperatorData &op, int mode, const void *x, const void *b,
+                              const void *dinv, void *out, void *carrier, double f1, double f2, const void *x_old);
   void launch_dg_cg_transfer(hipStream_t s, int number, int p, bool to_dg, void *dst, const void *src,
                              const uint32_t *idx27, uint32_t n_cells, const void *P1);
   void launch_zero_head_copy_tail(hipStream_t s, int number, void *dst, const void *src, uint32_t n_head, uint32_t n);

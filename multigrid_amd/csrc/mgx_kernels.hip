@@ -301,11 +301,26 @@ namespace mgx
   // ------------------------------------------------------------------------------------------
   // cell_list != nullptr: the launch covers the n_cells cells cell_list[0 .. n_cells) of one colour
   // (no shared DoFs among them) and adds to dst without atomics
+  // Fused Chebyshev update of a colour-by-colour launch (the counterpart of the brick loop's
+  // post-operation for the general branch): per cell, bit e of `flags` says that the cell is the
+  // FIRST one (in colour order) to touch its mesh entity e, bit 27 + e that it is the LAST one.
+  // Partial sums of A x travel in `carrier`; a DoF completed by this cell gets
+  //   out = x + f1 (x - x_old) [mode 2] | x + f1 x [mode 4] | x [mode 3]  + f2 D^-1 (b - A x)
+  template <typename T>
+  struct GeneralPost
+  {
+    int             mode; // 0: dst += A src
+    const uint64_t *flags;
+    T              *carrier, *out;
+    const T        *x_old, *rhs, *dinv;
+    T               f1, f2;
+  };
+
   template <int P, typename T, bool PERQ>
   __global__ void __launch_bounds__((Cfg<P, MGX_GENERAL_WG_THREADS>::THREADS))
     cell_loop_general_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
                              uint32_t n_cells, const Basis1D<T> *__restrict__ B, const T *__restrict__ coef_q, T c0,
-                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list)
+                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list, const GeneralPost<T> post)
   {
     using C           = Cfg<P, MGX_GENERAL_WG_THREADS>;
     constexpr int N   = C::N;
@@ -327,12 +342,15 @@ namespace mgx
     const int      slot   = lc < C::CPB ? lc : 0;
     T             *Uc = U + slot * C::CELL_LDS, *Xc = GX + slot * C::CELL_LDS, *Yc = GY + slot * C::CELL_LDS;
     const int      xl = (b * N + a) * LN, yl = b * PL + a, zl = b * LN + a;
-    T              r[N], q[N], gz[N];
+    T              r[N], q[N], gz[N], xs[N];
     LineIndex<P>   L;
     if (active) // nodal -> quadrature along x
       {
         L = line_index<P>(idx27, cell, a, b);
         gather_line<P, T>(src, L, r);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          xs[i] = r[i]; // the fused update needs the source values again
         mv<N, T>(B->S, r, q);
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -459,7 +477,40 @@ namespace mgx
         for (int i = 0; i < N; ++i)
           r[i] = Uc[xl + i];
         mvT<N, T>(B->S, r, q);
-        if (cell_list)
+        if (post.mode != 0)
+          {
+            int cy, oy, cz, oz;
+            node_code<P>(a, cy, oy);
+            node_code<P>(b, cz, oz);
+            const int      e0 = 9 * cz + 3 * cy;
+            const uint64_t fl = post.flags[cell];
+            auto           one = [&](uint32_t g, int e, T v, T xi) {
+              const bool first = (fl >> e) & 1u, last = (fl >> (27 + e)) & 1u;
+              const T    ax    = first ? v : post.carrier[g] + v;
+              if (last)
+                {
+                  T xn = xi + post.f2 * post.dinv[g] * (post.rhs[g] - ax);
+                  if (post.mode == 2)
+                    xn += post.f1 * (xi - post.x_old[g]);
+                  else if (post.mode == 4)
+                    xn += post.f1 * xi;
+                  post.out[g] = xn;
+                }
+              else
+                post.carrier[g] = ax;
+            };
+            if (L.b0 != kInvalid)
+              one(L.b0 + L.off, e0, q[0], xs[0]);
+            if (L.b1 != kInvalid)
+              {
+#pragma unroll
+                for (int i = 0; i < P - 1; ++i)
+                  one(L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i, e0 + 1, q[1 + i], xs[1 + i]);
+              }
+            if (L.b2 != kInvalid)
+              one(L.b2 + L.off, e0 + 2, q[P], xs[P]);
+          }
+        else if (cell_list)
           scatter_add_line_plain<P, T>(dst, L, q);
         else
           scatter_add_line<P, T>(dst, L, q);
@@ -764,7 +815,8 @@ namespace mgx
     }
 
   template <int P, typename T>
-  static void cell_loop_t(hipStream_t s, const OperatorData &op, void *dst, const void *src)
+  static void cell_loop_t(hipStream_t s, const OperatorData &op, void *dst, const void *src,
+                          const GeneralPost<T> post = GeneralPost<T>{})
   {
     using C            = Cfg<P>;
     const uint32_t nb  = (op.n_cells + C::CPB - 1) / C::CPB;
@@ -784,12 +836,12 @@ namespace mgx
             if (op.coef_q)
               hipLaunchKernelGGL((cell_loop_general_kernel<P, T, true>), dim3(nbk), dim3(C::THREADS), 0, s, (T *)dst,
                                  (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)op.coef_q, (T)0,
-                                 (T)0, (T)0, (T)0, (T)0, (T)0, list);
+                                 (T)0, (T)0, (T)0, (T)0, (T)0, list, post);
             else
               hipLaunchKernelGGL((cell_loop_general_kernel<P, T, false>), dim3(nbk), dim3(C::THREADS), 0, s, (T *)dst,
                                  (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)nullptr,
                                  (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5],
-                                 list);
+                                 list, post);
           }
       }
     else
@@ -927,6 +979,24 @@ namespace mgx
     else
       {
         MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src));
+      }
+  }
+
+  // fused Chebyshev iteration of the colour-by-colour general branch (op.cell_order != nullptr)
+  void launch_cell_loop_fused(hipStream_t s, const OperatorData &op, int mode, const void *x, const void *b,
+                              const void *dinv, void *out, void *carrier, double f1, double f2, const void *x_old)
+  {
+    if (op.number == 1)
+      {
+        GeneralPost<double> post{mode, op.cell_flags, (double *)carrier, (double *)out, (const double *)x_old,
+                                 (const double *)b, (const double *)dinv, f1, f2};
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, nullptr, x, post));
+      }
+    else
+      {
+        GeneralPost<float> post{mode, op.cell_flags, (float *)carrier, (float *)out, (const float *)x_old,
+                                (const float *)b, (const float *)dinv, (float)f1, (float)f2};
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, nullptr, x, post));
       }
   }
 
