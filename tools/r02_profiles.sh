@@ -47,7 +47,7 @@ p8)
   python3 $R/tools/summarize_trace.py $(find $O/kt8 -name "*kernel_trace.csv" | head -1) 2.0 > $O/kernel_trace_by_grid_64cube_p8.txt
   rm -rf $O/kt8 ;;
 dg)
-  python3 $R/tools/matvec_dg_cheby.py 4 21 10 --outer 3 --json > $O/matvec_dg_cheby_p4_262M.txt 2>&1
+  python3 $R/tools/matvec_dg_cheby.py 4 21 10 --outer 3 --json --cpu-baseline > $O/matvec_dg_cheby_p4_262M.txt 2>&1
   python3 $R/tools/matvec_dg_cheby.py 3 21 10 --outer 3 --json > $O/matvec_dg_cheby_p3_134M.txt 2>&1
   rm -rf $O/ktdg
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktdg -o t -- python3 $R/tools/matvec_dg_cheby.py 4 18 20 > $O/dg_profiled.log 2>&1
