@@ -104,6 +104,7 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.no_fused_init       = flag("MGX_NO_FUSED_INIT");
   t.no_fused_restrict   = flag("MGX_NO_FUSED_RESTRICT");
   t.no_fused_prolong    = flag("MGX_NO_FUSED_PROLONG");
+  t.force_fused_transfers = flag("MGX_FORCE_FUSED_TRANSFERS");
   t.transfer_v1         = flag("MGX_TRANSFER_V1");
   t.restrict_atomic     = flag("MGX_RESTRICT_ATOMIC");
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
@@ -2235,7 +2236,11 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   // Fused residual + restriction (mgx_brick.hip, mode 7): needs the fine level on the brick
   // schedule in its separable form, children in forest order (cell c is child c % 8 of parent
   // c / 8, so that a brick's cells are the children of PB^3 sibling parents) and a single rank.
-  if (fine->d.bricks.available() && fine->d.separable && !fine->plan && !coarse->plan &&
+  // Degrees 7 and 8: the in-LDS restriction / embedding sweeps of the one-parent bricks cost more than the
+  // transfer kernels they replace (measured V-cycle at 64^3 cells: p = 7 10.4 ms fused, 9.4 ms separate;
+  // p = 8 13.7 / 13.3 ms; p = 5, 6, 9 are 5-8 % faster fused) -- no coarse blocks, so neither fused form runs
+  const bool fused_pays = (p != 7 && p != 8) || coarse->ctx->tun.force_fused_transfers;
+  if (fine->d.bricks.available() && fine->d.separable && !fine->plan && !coarse->plan && fused_pays &&
       !coarse->ctx->tun.no_fused_restrict)
     {
       bool forest = true;

@@ -111,7 +111,7 @@ FALLBACKS = {"MGX_NO_FUSED_RESTRICT": "1", "MGX_NO_FUSED_INIT": "1", "MGX_TRANSF
              "MGX_NO_DIAG_TABLE": "1", "MGX_NO_FUSED_PROLONG": "1"}
 
 
-@pytest.mark.parametrize("p,ns,nr", [(4, 3, 5), (2, 1, 7), (3, 1, 6), (5, 1, 5), (8, 1, 5), (1, 1, 7)])
+@pytest.mark.parametrize("p,ns,nr", [(4, 3, 5), (2, 1, 7), (3, 1, 6), (5, 1, 5), (8, 1, 5), (1, 1, 7), (7, 1, 4), (9, 1, 4)])
 def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     """Meshes the oracle cannot run in seconds (4 - 17 M DoFs; production thresholds, i.e. without
     the test overrides of conftest.py): the default V-cycle -- macro-element brick loop with the
@@ -122,7 +122,11 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     iterate).  The two differ in summation order only."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
+    # degrees 7 and 8 run the separate transfer kernels by default (faster there): their fused forms
+    # stay under test
+    monkeypatch.setenv("MGX_FORCE_FUSED_TRANSFERS", "1")
     ctx = mg.Context(0)
+    monkeypatch.delenv("MGX_FORCE_FUSED_TRANSFERS")
     cube = mg.Cube(p, ns, nr)
     l = cube.max_level
     n = cube.n_dofs(l)
