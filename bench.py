@@ -35,7 +35,7 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (datasheet); tools/microbenc
 # executed by the macro-element brick kernel at p = 4: 289 lines x 628 fp64 instructions (ISA count of
 # the three sweeps: 158 + 279 + 191, ~80 % of them FMA = 2 flop) per 4096-DoF brick (dense 12-sweep form: 270)
 FLOP_PER_DOF_P4 = 80.0
-TRAFFIC_FILE = "r02_pmc_traffic_128cube_p4.json"
+TRAFFIC_FILES = {(4, 128): "r02_pmc_traffic_128cube_p4.json", (8, 64): "r02_pmc_traffic_64cube_p8.json"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
 
 
@@ -330,8 +330,9 @@ def main():
         # cannot run inside this timed process) and committed under profiles/; it is reported here
         # for the configuration it was measured on
         traffic, traffic_note = None, None
+        TRAFFIC_FILE = TRAFFIC_FILES.get((args.degree, args.cells), "")
         pmc_file = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-        if args.degree == 4 and args.cells == 128 and vnum == mg.F64 and world == 1 and os.path.exists(pmc_file):
+        if TRAFFIC_FILE and vnum == mg.F64 and world == 1 and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from make_traffic_json import kernel_source_sha

@@ -1,5 +1,5 @@
 """profiles/*_pmc_traffic_*.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
-tools/matvec_loop.py <cells> <n> cheb.  usage: make_traffic_json.py fetch.csv write.csv cells out.json
+tools/matvec_loop.py <cells> <n> cheb [degree].  usage: make_traffic_json.py fetch.csv write.csv cells out.json [degree=4]
 
 Streaming kernels of the same run with known byte counts calibrate the counters (gfx950:
 FETCH_SIZE reports 1/2 for 8-B-per-lane reads, WRITE_SIZE is exact)."""
@@ -30,11 +30,11 @@ def load(path):
 
 def main():
     fe, wr, cells, out = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    p = 4
+    p = int(sys.argv[5]) if len(sys.argv) > 5 else 4
     n = (cells * p + 1) ** 3
-    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 tools/matvec_loop.py %d 3 cheb"
-                      "   (and a second pass with --pmc WRITE_SIZE)" % cells,
-           "workload": "poisson_cube FE_Q(4) %d^3 cells, %d DoFs, fp64, finest level, per colour launch" % (cells, n),
+    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 tools/matvec_loop.py %d 3 cheb %d"
+                      "   (and a second pass with --pmc WRITE_SIZE)" % (cells, p),
+           "workload": "poisson_cube FE_Q(%d) %d^3 cells, %d DoFs, fp64, finest level, per colour launch" % (p, cells, n),
            "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
                     "(gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md 'HBM')",
            "kernel_source_sha16": kernel_source_sha(), "kernel_sources": KERNEL_SOURCES,
@@ -54,9 +54,9 @@ def main():
     for mode, (nm, alg) in names.items():
         # macro-element form (production; fused Chebyshev forms with the inverse diagonal in registers
         # when the diagonal is uniform), else the cell-by-cell form
-        for k in ("void mgx::brick_macro_kernel<4, double, %d, true>" % mode,
-                  "void mgx::brick_macro_kernel<4, double, %d, false>" % mode,
-                  "void mgx::brick_sep_kernel<4, double, %d, false>" % mode):
+        for k in ("void mgx::brick_macro_kernel<%d, double, %d, true>" % (p, mode),
+                  "void mgx::brick_macro_kernel<%d, double, %d, false>" % (p, mode),
+                  "void mgx::brick_sep_kernel<%d, double, %d, false>" % (p, mode)):
             if k in fe and k in wr:
                 break
         else:

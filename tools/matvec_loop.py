@@ -5,11 +5,12 @@ import multigrid_amd as mg
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 mode = sys.argv[3] if len(sys.argv) > 3 else "vmult"
+deg = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 ns, nr = cells, 0
 while ns % 2 == 0 and ns > 1:
     ns //= 2; nr += 1
 ctx = mg.Context(0)
-cube = mg.Cube(4, ns, nr)
+cube = mg.Cube(deg, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
 x = ctx.vector(cube.n_dofs(l), data=cube.seeded_vector(l, 42))

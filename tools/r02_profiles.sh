@@ -40,6 +40,13 @@ sq)
   rm -rf $O/sq1 $O/sq2 $O/sq3
   head -30 $O/pmc_sq_macro_kernel_128cube_p4.txt ;;
 p8)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/pmc8_$c
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc8_$c -o t -- python3 $R/tools/matvec_loop.py 64 3 cheb 8 > $O/pmc8_$c.log 2>&1
+  done
+  python3 $R/tools/make_traffic_json.py $(find $O/pmc8_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
+      $(find $O/pmc8_WRITE_SIZE -name "*counter_collection.csv" | head -1) 64 $O/pmc_traffic_64cube_p8.json 8
+  rm -rf $O/pmc8_FETCH_SIZE $O/pmc8_WRITE_SIZE
   python3 $R/bench.py --degree 8 --cells 64 --no-cpu-baseline > $O/bench_64cube_p8.json 2> $O/bench_64cube_p8.err
   tail -1 $O/bench_64cube_p8.json | cut -c1-400
   rm -rf $O/kt8
