@@ -1395,6 +1395,8 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
         return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: ghost cells need an exchange plan and a "
                                                  "communicator on the context");
       const mgx_dg_exchange_desc &e = *desc->exchange;
+      if (e.n_neighbors < 1 || !e.neighbor_rank || !e.count || !e.send_cells || !e.recv_first)
+        return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: incomplete exchange plan");
       uint64_t                    covered = 0;
       for (int k = 0; k < e.n_neighbors; ++k)
         {
@@ -1402,6 +1404,8 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
             return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: neighbour ranks must be ascending");
           if (e.recv_first[k] < desc->n_cells || (uint64_t)e.recv_first[k] + e.count[k] > n_all)
             return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: ghost range outside the ghost cells");
+          if (e.count[k] > 0 && !e.send_cells[k])
+            return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: incomplete exchange plan");
           for (uint32_t i = 0; i < e.count[k]; ++i)
             if (e.send_cells[k][i] >= desc->n_cells)
               return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_operator_create: only owned cells can be sent");
