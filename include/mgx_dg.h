@@ -36,7 +36,10 @@ typedef struct mgx_dg_operator_s *mgx_dg_operator_t;
  * owned cell ("ghost cells", whole cells in this slice -- the reference sends two node layers for
  * the Hermite-like basis); neighbour-table entries >= n_cells address them.  Ghosts of one rank
  * are contiguous.  Both sides of a pair exchange the same number of cells (true for block
- * decompositions; checked). */
+ * decompositions; checked).  An operator application runs the cells without a ghost neighbour while
+ * the exchange is in flight on a second stream, the others behind it (the reference waits for the
+ * exchange, :1057, before its cell loop); owned cells ordered interior-first make both parts
+ * contiguous launches. */
 typedef struct
 {
   int                    plan_id;

@@ -839,6 +839,15 @@ def dg_box_partition(cells, procs, rank, ordering="z"):
     else:
         key = loc[:, 0] + blk[0] * (loc[:, 1] + blk[1] * loc[:, 2])
     loc = loc[np.argsort(key, kind="stable")]
+    # cells with a face on another rank last: the library then runs the leading (interior) cells
+    # under the ghost exchange without an index list
+    at_rank_face = np.zeros(len(loc), dtype=bool)
+    for d in range(3):
+        if r3[d] > 0:
+            at_rank_face |= loc[:, d] == 0
+        if r3[d] + 1 < procs[d]:
+            at_rank_face |= loc[:, d] == blk[d] - 1
+    loc = np.concatenate([loc[~at_rank_face], loc[at_rank_face]])
     return dg_partition(loc + r3 * blk, cells, procs, rank)
 
 

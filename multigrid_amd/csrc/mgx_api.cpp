@@ -114,6 +114,7 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.no_graph            = flag("MGX_NO_GRAPH");
   t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
   t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
+  t.dg_no_overlap       = flag("MGX_DG_NO_OVERLAP");
   return t;
 }
 
@@ -492,9 +493,9 @@ namespace
   // apply the fused post-operation to them (they were never flagged LAST).
   // Split schedule (BrickData::n_iface_groups > 0): the bricks on the rank interface run first,
   // colour by colour; the exchange and the list kernels go to the side stream behind an event and
-  // overlap with the interior bricks, which touch no interface DoF -- the pattern of the
-  // reference's explicit version, laplace_operator_dg.h:986-1057 (send-side cells first,
-  // MPI_Waitall after the interior).  With the callback transport the host blocks in the exchange
+  // overlap with the interior bricks, which touch no interface DoF.  (The reference's explicit
+  // exchange, laplace_operator_dg.h:986-1057, packs the send-side data first but waits for all
+  // requests before its cell loop; deal.II's own loops overlap inside MatrixFree.)  With the callback transport the host blocks in the exchange
   // while the interior launches, enqueued before, execute.
   template <typename Launch, typename Fix>
   int brick_loop_with_exchange(mgx_operator_t op, int form, void *carrier, Launch launch, Fix fix)
@@ -637,10 +638,10 @@ namespace
 // on the stream, or the blocking callback), for the parts of the ABI implemented in other
 // translation units (the DG ghost-cell update); allreduce of a few host doubles likewise
 int mgx::exchange_buffers(mgx_context_t ctx, int plan_id, int number, int n_neighbors, const int *ranks,
-                          const uint32_t *counts, void *const *send, void *const *recv)
+                          const uint32_t *counts, void *const *send, void *const *recv, hipStream_t stream)
 {
   MGX_REQUIRE(ctx && ctx->has_comm, "exchange_buffers: no communicator on this context");
-  hipStream_t s = ctx->stream;
+  hipStream_t s = stream ? stream : ctx->stream;
   if (ctx->use_rccl)
     {
       RcclApi             &R  = rccl_api();
@@ -662,6 +663,22 @@ int mgx::exchange_buffers(mgx_context_t ctx, int plan_id, int number, int n_neig
   return MGX_OK;
 }
 
+hipStream_t mgx::side_stream_begin(mgx_context_t ctx)
+{
+  if (!ctx || !ctx->side || hipEventRecord(ctx->ev_iface, ctx->stream) != hipSuccess ||
+      hipStreamWaitEvent(ctx->side, ctx->ev_iface, 0) != hipSuccess)
+    return nullptr;
+  return ctx->side;
+}
+
+int mgx::side_stream_end(mgx_context_t ctx)
+{
+  MGX_REQUIRE(ctx && ctx->side, "side_stream_end: no side stream");
+  MGX_HIP(hipEventRecord(ctx->ev_side, ctx->side));
+  MGX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));
+  return MGX_OK;
+}
+
 int mgx::allreduce_sum(mgx_context_t ctx, double *values, int count) { return comm_allreduce(ctx, values, count); }
 
 // x.y over the first n entries of two vectors whose leading part is owned by this rank without
@@ -674,6 +691,8 @@ int mgx::dot_owned_prefix(mgx_context_t ctx, int number, const void *x, const vo
 }
 
 bool mgx::context_has_comm(mgx_context_t ctx) { return ctx && ctx->has_comm; }
+
+const mgx::Tunables &mgx::context_tunables(mgx_context_t ctx) { return ctx->tun; }
 
 extern "C" {
 

@@ -63,7 +63,9 @@ namespace
     const int32_t    *neigh;
     const DGConst<T> *c;
     const T          *inv_diag; // [64][(p+1)^3]
-    uint32_t          n_cells;
+    const uint32_t   *cell_list; // cells of this launch (nullptr: cells cell_first ... in order)
+    uint32_t          cell_first;
+    uint32_t          n_cells;   // cells of this launch
     T                 f1, f2;
     int               iteration_index;
   };
@@ -247,6 +249,7 @@ namespace
     const bool store  = active && cell < A.n_cells;
     if (cell >= A.n_cells)
       cell = A.n_cells - 1;
+    cell = A.cell_list ? A.cell_list[cell] : cell + A.cell_first;
 
     T *U  = lds + (active ? cw : 0) * C::CELL;
     T *GY = U + VOL, *GZ = U + 2 * VOL;
@@ -1259,6 +1262,11 @@ struct mgx_dg_operator_s
   std::vector<uint32_t>   nb_count, nb_recv_first, nb_entries;
   std::vector<uint32_t *> nb_cells_dev;
   std::vector<void *>     nb_send;
+  // cells without / with a ghost neighbour: the former run while the ghost exchange is in flight
+  // (the reference completes its exchange, laplace_operator_dg.h:986-1057, before the cell loop)
+  uint32_t *interior_cells = nullptr, *boundary_cells = nullptr; // device
+  uint32_t  n_interior = 0, n_boundary = 0;
+  bool      interior_is_prefix = false; // the interior cells are cells 0 ... n_interior - 1
 };
 
 // MultigridSolverDG (common/multigrid_solver_dg.h:55-747): the DG level on top of an FE_Q hierarchy
@@ -1316,15 +1324,13 @@ namespace
       }
   }
 
-  int update_ghosts(mgx_dg_operator_t op, void *vec)
+  // pack kernels on the context's stream; `overlap`: the exchange itself on the side stream, begun
+  // behind the pack kernels -- the caller enqueues independent work and then calls ghosts_finish
+  int ghosts_pack(mgx_dg_operator_t op, const void *vec)
   {
-    if (op->n_ghost == 0)
-      return MGX_OK;
     hipStream_t    s   = (hipStream_t)mgx_context_stream(op->ctx);
     const uint32_t n3  = (uint32_t)(op->degree + 1) * (op->degree + 1) * (op->degree + 1);
-    const size_t   es  = op->number == MGX_F64 ? 8 : 4;
     const int      nnb = (int)op->nb_rank.size();
-    std::vector<void *> recv(nnb);
     for (int k = 0; k < nnb; ++k)
       {
         const uint64_t total = (uint64_t)op->nb_count[k] * n3;
@@ -1335,33 +1341,83 @@ namespace
         else
           hipLaunchKernelGGL(k_pack_cells<float>, dim3(grid), dim3(256), 0, s, (float *)op->nb_send[k], (const float *)vec,
                              op->nb_cells_dev[k], op->nb_count[k], n3);
-        recv[k] = (char *)vec + (size_t)op->nb_recv_first[k] * n3 * es; // straight into the ghost cells
       }
     DG_HIP(hipGetLastError());
-    return mgx::exchange_buffers(op->ctx, op->plan_id, op->number, nnb, op->nb_rank.data(), op->nb_entries.data(),
-                                 op->nb_send.data(), recv.data());
+    return MGX_OK;
   }
 
-  int run(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
-          int iteration_index)
+  int ghosts_exchange(mgx_dg_operator_t op, void *vec, hipStream_t stream)
   {
-    hipStream_t s = (hipStream_t)mgx_context_stream(op->ctx);
+    const uint32_t n3  = (uint32_t)(op->degree + 1) * (op->degree + 1) * (op->degree + 1);
+    const size_t   es  = op->number == MGX_F64 ? 8 : 4;
+    const int      nnb = (int)op->nb_rank.size();
+    std::vector<void *> recv(nnb);
+    for (int k = 0; k < nnb; ++k)
+      recv[k] = (char *)vec + (size_t)op->nb_recv_first[k] * n3 * es; // straight into the ghost cells
+    return mgx::exchange_buffers(op->ctx, op->plan_id, op->number, nnb, op->nb_rank.data(), op->nb_entries.data(),
+                                 op->nb_send.data(), recv.data(), stream);
+  }
+
+  int update_ghosts(mgx_dg_operator_t op, void *vec)
+  {
+    if (op->n_ghost == 0)
+      return MGX_OK;
+    MGX_DG_TRY(ghosts_pack(op, vec));
+    return ghosts_exchange(op, vec, nullptr);
+  }
+
+  int launch_cells(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
+                   int iteration_index, const uint32_t *cell_list, uint32_t n_cells, hipStream_t stream = nullptr,
+                   uint32_t cell_first = 0)
+  {
+    if (n_cells == 0)
+      return MGX_OK;
+    hipStream_t s = stream ? stream : (hipStream_t)mgx_context_stream(op->ctx);
     if (op->number == MGX_F64)
       {
         DGArgs<double> a{(const double *)src, (const double *)rhs, (double *)dst, op->neigh,
-                         (const DGConst<double> *)op->consts, (const double *)op->inv_diag, op->n_cells, f1, f2,
+                         (const DGConst<double> *)op->consts, (const double *)op->inv_diag, cell_list, cell_first, n_cells, f1, f2,
                          iteration_index};
         launch_degree<double>(s, op->degree, op->basis, action, a);
       }
     else
       {
         DGArgs<float> a{(const float *)src, (const float *)rhs, (float *)dst, op->neigh,
-                        (const DGConst<float> *)op->consts, (const float *)op->inv_diag, op->n_cells, (float)f1,
+                        (const DGConst<float> *)op->consts, (const float *)op->inv_diag, cell_list, cell_first, n_cells, (float)f1,
                         (float)f2, iteration_index};
         launch_degree<float>(s, op->degree, op->basis, action, a);
       }
     DG_HIP(hipGetLastError());
     return MGX_OK;
+  }
+
+  // One application.  with_ghosts: the action reads neighbour cells, so the ghost cells of src are
+  // refreshed first; the cells without a ghost neighbour run while that exchange is in flight on the
+  // context's side stream (with the blocking callback transport: while the host waits in it).
+  int run(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
+          int iteration_index, bool with_ghosts = false)
+  {
+    if (!with_ghosts || op->n_ghost == 0)
+      return launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, nullptr, op->n_cells);
+    void *ghosted = const_cast<void *>(src);
+    MGX_DG_TRY(ghosts_pack(op, src));
+    hipStream_t side = (op->n_interior > 0 && !mgx::context_tunables(op->ctx).dg_no_overlap) ? mgx::side_stream_begin(op->ctx)
+                                                                                               : nullptr;
+    if (!side)
+      {
+        MGX_DG_TRY(ghosts_exchange(op, ghosted, nullptr));
+        return launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, nullptr, op->n_cells);
+      }
+    // main stream: interior cells; side stream: exchange, then the cells next to a ghost cell (they
+    // write other cells of dst than the interior launch and share its read-only operands)
+    // (interior cells first in the caller's order: two contiguous ranges, no index lists)
+    const uint32_t *li = op->interior_is_prefix ? nullptr : op->interior_cells;
+    const uint32_t *lb = op->interior_is_prefix ? nullptr : op->boundary_cells;
+    MGX_DG_TRY(launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, li, op->n_interior));
+    MGX_DG_TRY(ghosts_exchange(op, ghosted, side));
+    MGX_DG_TRY(launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, lb, op->n_boundary, side,
+                            op->interior_is_prefix ? op->n_interior : 0));
+    return mgx::side_stream_end(op->ctx);
   }
 } // namespace
 
@@ -1446,6 +1502,8 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
     (void)hipFree(op->neigh);
     (void)hipFree(op->consts);
     (void)hipFree(op->inv_diag);
+    (void)hipFree(op->interior_cells);
+    (void)hipFree(op->boundary_cells);
     for (auto *p : op->nb_cells_dev)
       (void)hipFree(p);
     for (auto *p : op->nb_send)
@@ -1484,6 +1542,24 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
           op->nb_send.push_back(buf);
         }
     }
+  if (op->n_ghost > 0)
+    {
+      std::vector<uint32_t> interior, boundary;
+      for (uint32_t c = 0; c < desc->n_cells; ++c)
+        {
+          bool ghost = false;
+          for (int f = 0; f < 6; ++f)
+            ghost = ghost || (desc->neighbours[(size_t)c * 6 + f] >= 0 && (uint32_t)desc->neighbours[(size_t)c * 6 + f] >= desc->n_cells);
+          (ghost ? boundary : interior).push_back(c);
+        }
+      op->n_interior = (uint32_t)interior.size();
+      op->n_boundary = (uint32_t)boundary.size();
+      op->interior_is_prefix = interior.empty() || interior.back() + 1 == interior.size();
+      DG_HIP_C(hipMalloc((void **)&op->interior_cells, sizeof(uint32_t) * (interior.size() + 1)));
+      DG_HIP_C(hipMalloc((void **)&op->boundary_cells, sizeof(uint32_t) * (boundary.size() + 1)));
+      DG_HIP_C(hipMemcpy(op->interior_cells, interior.data(), sizeof(uint32_t) * interior.size(), hipMemcpyHostToDevice));
+      DG_HIP_C(hipMemcpy(op->boundary_cells, boundary.data(), sizeof(uint32_t) * boundary.size(), hipMemcpyHostToDevice));
+    }
   DG_HIP_C(hipMalloc(&op->inv_diag, nsz * table.size()));
   if (desc->number == MGX_F64)
     {
@@ -1517,6 +1593,8 @@ int mgx_dg_operator_destroy(mgx_dg_operator_t op)
   (void)hipFree(op->neigh);
   (void)hipFree(op->consts);
   (void)hipFree(op->inv_diag);
+  (void)hipFree(op->interior_cells);
+  (void)hipFree(op->boundary_cells);
   for (auto *p : op->nb_cells_dev)
     (void)hipFree(p);
   for (auto *p : op->nb_send)
@@ -1546,16 +1624,14 @@ int mgx_dg_vmult(mgx_dg_operator_t op, void *dst, const void *src)
 {
   if (!op || !dst || !src || dst == src)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult: null or aliased vectors");
-  MGX_DG_TRY(update_ghosts(op, const_cast<void *>(src)));
-  return run(op, kVmult, dst, nullptr, src, 0, 0, 0);
+  return run(op, kVmult, dst, nullptr, src, 0, 0, 0, true);
 }
 
 int mgx_dg_vmult_residual(mgx_dg_operator_t op, void *dst, const void *rhs, const void *src)
 {
   if (!op || !dst || !src || !rhs || dst == src)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_residual: null or aliased vectors");
-  MGX_DG_TRY(update_ghosts(op, const_cast<void *>(src)));
-  return run(op, kResidual, dst, rhs, src, 0, 0, 0);
+  return run(op, kResidual, dst, rhs, src, 0, 0, 0, true);
 }
 
 int mgx_dg_jacobi_vmult(mgx_dg_operator_t op, void *dst, const void *src)
@@ -1574,8 +1650,7 @@ int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, un
     return run(op, kJacobi, solution, nullptr, rhs, 0, factor2, 0);
   if (!solution_old || solution_old == solution)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_with_chebyshev_update: solution_old is null or aliases solution");
-  MGX_DG_TRY(update_ghosts(op, solution));
-  return run(op, kChebyshev, solution_old, rhs, solution, factor1, factor2, (int)iteration_index);
+  return run(op, kChebyshev, solution_old, rhs, solution, factor1, factor2, (int)iteration_index, true);
 }
 
 int mgx_dg_operator_info(mgx_dg_operator_t op, double *hderiv, double penalty[3], double eigenvalues_1d[MGX_MAX_DEGREE + 1])

@@ -30,6 +30,7 @@ namespace mgx
     uint32_t overlap_min      = 16384; // MGX_OVERLAP_MIN_BRICKS  bricks per rank from which interface bricks run first
     bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
     uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads
+    bool     dg_no_overlap    = false; // MGX_DG_NO_OVERLAP        DG ghost exchange before all cells instead of under the interior ones
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
     bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
     bool     no_fused_init    = false; // MGX_NO_FUSED_INIT    store the first Chebyshev iterate
@@ -151,10 +152,16 @@ namespace mgx
   // buffers (counts[k] entries of `number` type with rank ranks[k], both directions), sum of a few
   // host doubles over the ranks (no-op on a single rank)
   int  exchange_buffers(struct ::mgx_context_s *ctx, int plan_id, int number, int n_neighbors, const int *ranks,
-                        const uint32_t *counts, void *const *send, void *const *recv);
+                        const uint32_t *counts, void *const *send, void *const *recv, hipStream_t stream = nullptr);
+  // Overlap of an exchange with work on the context's stream: side_stream_begin returns the context's side stream, ordered
+  // behind everything enqueued on the main stream so far (nullptr: no side stream, run in order);
+  // side_stream_end orders the main stream behind the side stream again.
+  hipStream_t side_stream_begin(struct ::mgx_context_s *ctx);
+  int         side_stream_end(struct ::mgx_context_s *ctx);
   int  allreduce_sum(struct ::mgx_context_s *ctx, double *values, int count);
   int  dot_owned_prefix(struct ::mgx_context_s *ctx, int number, const void *x, const void *y, size_t n, double *out);
   bool context_has_comm(struct ::mgx_context_s *ctx);
+  const Tunables &context_tunables(struct ::mgx_context_s *ctx);
 
   // records the message mgx_last_error() returns on the calling thread; returns `code` (used by the
   // translation units that implement parts of the C ABI outside mgx_api.cpp)
