@@ -32,10 +32,11 @@ typedef struct mgx_dg_operator_s *mgx_dg_operator_t;
 
 /* Ghost-cell exchange of a decomposed DG mesh (replaces the MPI_Isend / MPI_Irecv of face data,
  * laplace_operator_dg.h:986-1057, and the send lists built at :607-723).  A rank stores its owned
- * cells first and, behind them, one copy of every cell of another rank that shares a face with an
- * owned cell ("ghost cells", whole cells in this slice -- the reference sends two node layers for
- * the Hermite-like basis); neighbour-table entries >= n_cells address them.  Ghosts of one rank
- * are contiguous.  Both sides of a pair exchange the same number of cells (true for block
+ * cells first and, behind them, one ghost for every cell of another rank that shares a face with an
+ * owned cell; neighbour-table entries >= n_cells address them.  A ghost holds the reference's
+ * data_per_face (:565): the whole cell for the two Lagrange bases; for the Hermite-like basis two
+ * values per face point, the trace and the normal derivative as the owner computes them from its two
+ * node layers (:1015-1039), [face point][2], 2 (p+1)^2 entries.  Ghosts of one rank are contiguous.  Both sides of a pair exchange the same number of cells (true for block
  * decompositions; checked).  An operator application runs the cells without a ghost neighbour while
  * the exchange is in flight on a second stream, the others behind it (the reference waits for the
  * exchange, :1057, before its cell loop); owned cells ordered interior-first make both parts
@@ -65,7 +66,7 @@ typedef struct
   double jacobian[9];
   /* decomposed mesh (one rank per GPU; the context carries the communicator, mgx.h): number of
    * ghost cells and their exchange; 0 / NULL on a single rank.  Vectors then hold
-   * (n_cells + n_ghost_cells) (p+1)^3 entries, owned cells first, like deal.II's owned | ghost layout */
+   * mgx_dg_operator_vector_size() entries, owned cells first, like deal.II's owned | ghost layout */
   uint32_t                    n_ghost_cells;
   const mgx_dg_exchange_desc *exchange;
 } mgx_dg_operator_desc;

@@ -66,6 +66,7 @@ namespace
     const uint32_t   *cell_list; // cells of this launch (nullptr: cells cell_first ... in order)
     uint32_t          cell_first;
     uint32_t          n_cells;   // cells of this launch
+    uint32_t          n_owned;   // owned cells of the operator: neighbour entries >= n_owned are ghosts
     T                 f1, f2;
     int               iteration_index;
   };
@@ -223,7 +224,8 @@ namespace
       }
   }
 
-  template <int P, typename T, int TYPE, int ACTION>
+  // GHOSTS (Hermite-like basis on a decomposed mesh): neighbour entries >= A.n_owned are ghost faces
+  template <int P, typename T, int TYPE, int ACTION, bool GHOSTS = false>
   __global__ void __launch_bounds__((DGCfg<P, T>::THREADS)) dg_cell_kernel(const DGArgs<T> A)
   {
     using C         = DGCfg<P, T>;
@@ -384,11 +386,28 @@ namespace
                     const T *__restrict__ xn = src + (size_t)nb[f] * N3 + a * s1 + b * s2;
                     if constexpr (TYPE == MGX_DG_HERMITE)
                       {
-                        // the neighbour's face is its upper one for our lower face and vice versa
-                        const T v0 = xn[(s == 0 ? N - 1 : 0) * sd];
-                        const T v1 = xn[(s == 0 ? (N > 1 ? N - 2 : 0) : (N > 1 ? 1 : 0)) * sd];
-                        ev         = v0;
-                        ed         = s == 0 ? c->hderiv * (v1 - v0) : c->hderiv * (v0 - v1);
+                        // owned neighbour: its two node layers next to the face (its upper face for our
+                        // lower one and vice versa); ghost: the (value, normal derivative) pair of the
+                        // face point as its owner computed it (k_pack_faces; laplace_operator_dg.h:1015-1039
+                        // sends the same pair).  Two loads either way, no divergent branch.
+                        const int l0 = s == 0 ? N - 1 : 0, l1 = s == 0 ? (N > 1 ? N - 2 : 0) : (N > 1 ? 1 : 0);
+                        if constexpr (GHOSTS)
+                          {
+                            // 32-bit entry offsets (a vector holds fewer than 2^32 entries): one select
+                            const uint32_t nbu   = (uint32_t)nb[f];
+                            const bool     ghost = nbu >= A.n_owned;
+                            const uint32_t base  = ghost ? A.n_owned * (uint32_t)N3 + ((nbu - A.n_owned) * NN2 + b * N + a) * 2
+                                                         : nbu * (uint32_t)N3 + a * s1 + b * s2;
+                            const T v0 = src[base + (ghost ? 0 : l0 * sd)], v1 = src[base + (ghost ? 1 : l1 * sd)];
+                            ev         = v0;
+                            ed         = ghost ? v1 : (s == 0 ? c->hderiv * (v1 - v0) : c->hderiv * (v0 - v1));
+                          }
+                        else
+                          {
+                            const T v0 = xn[l0 * sd], v1 = xn[l1 * sd];
+                            ev         = v0;
+                            ed         = s == 0 ? c->hderiv * (v1 - v0) : c->hderiv * (v0 - v1);
+                          }
                       }
                     else
                       {
@@ -1183,63 +1202,69 @@ namespace
   }
 
   template <int P, typename T, int TYPE, int ACTION>
-  void launch_one(hipStream_t s, const DGArgs<T> &a)
+  void launch_one(hipStream_t s, const DGArgs<T> &a, bool ghosts)
   {
     using C             = DGCfg<P, T>;
     const uint32_t grid = (a.n_cells + C::CPW - 1) / C::CPW;
+    if constexpr (TYPE == MGX_DG_HERMITE && ACTION != kJacobi)
+      if (ghosts)
+        {
+          hipLaunchKernelGGL((dg_cell_kernel<P, T, TYPE, ACTION, true>), dim3(grid), dim3(C::THREADS), 0, s, a);
+          return;
+        }
     hipLaunchKernelGGL((dg_cell_kernel<P, T, TYPE, ACTION>), dim3(grid), dim3(C::THREADS), 0, s, a);
   }
 
   template <int P, typename T, int TYPE>
-  void launch_action(hipStream_t s, int action, const DGArgs<T> &a)
+  void launch_action(hipStream_t s, int action, const DGArgs<T> &a, bool ghosts)
   {
     switch (action)
       {
         case kVmult:
-          return launch_one<P, T, TYPE, kVmult>(s, a);
+          return launch_one<P, T, TYPE, kVmult>(s, a, ghosts);
         case kChebyshev:
-          return launch_one<P, T, TYPE, kChebyshev>(s, a);
+          return launch_one<P, T, TYPE, kChebyshev>(s, a, ghosts);
         case kResidual:
-          return launch_one<P, T, TYPE, kResidual>(s, a);
+          return launch_one<P, T, TYPE, kResidual>(s, a, ghosts);
         default:
-          return launch_one<P, T, TYPE, kJacobi>(s, a);
+          return launch_one<P, T, TYPE, kJacobi>(s, a, ghosts);
       }
   }
 
   template <int P, typename T>
-  void launch_type(hipStream_t s, int basis, int action, const DGArgs<T> &a)
+  void launch_type(hipStream_t s, int basis, int action, const DGArgs<T> &a, bool ghosts)
   {
     if (basis == MGX_DG_HERMITE)
-      launch_action<P, T, MGX_DG_HERMITE>(s, action, a);
+      launch_action<P, T, MGX_DG_HERMITE>(s, action, a, ghosts);
     else if (basis == MGX_DG_GAUSS_LOBATTO)
-      launch_action<P, T, MGX_DG_GAUSS_LOBATTO>(s, action, a);
+      launch_action<P, T, MGX_DG_GAUSS_LOBATTO>(s, action, a, ghosts);
     else
-      launch_action<P, T, MGX_DG_GAUSS>(s, action, a);
+      launch_action<P, T, MGX_DG_GAUSS>(s, action, a, ghosts);
   }
 
   template <typename T>
-  void launch_degree(hipStream_t s, int p, int basis, int action, const DGArgs<T> &a)
+  void launch_degree(hipStream_t s, int p, int basis, int action, const DGArgs<T> &a, bool ghosts)
   {
     switch (p)
       {
         case 1:
-          return launch_type<1, T>(s, basis, action, a);
+          return launch_type<1, T>(s, basis, action, a, ghosts);
         case 2:
-          return launch_type<2, T>(s, basis, action, a);
+          return launch_type<2, T>(s, basis, action, a, ghosts);
         case 3:
-          return launch_type<3, T>(s, basis, action, a);
+          return launch_type<3, T>(s, basis, action, a, ghosts);
         case 4:
-          return launch_type<4, T>(s, basis, action, a);
+          return launch_type<4, T>(s, basis, action, a, ghosts);
         case 5:
-          return launch_type<5, T>(s, basis, action, a);
+          return launch_type<5, T>(s, basis, action, a, ghosts);
         case 6:
-          return launch_type<6, T>(s, basis, action, a);
+          return launch_type<6, T>(s, basis, action, a, ghosts);
         case 7:
-          return launch_type<7, T>(s, basis, action, a);
+          return launch_type<7, T>(s, basis, action, a, ghosts);
         case 8:
-          return launch_type<8, T>(s, basis, action, a);
+          return launch_type<8, T>(s, basis, action, a, ghosts);
         default:
-          return launch_type<9, T>(s, basis, action, a);
+          return launch_type<9, T>(s, basis, action, a, ghosts);
       }
   }
 } // namespace
@@ -1267,6 +1292,10 @@ struct mgx_dg_operator_s
   uint32_t *interior_cells = nullptr, *boundary_cells = nullptr; // device
   uint32_t  n_interior = 0, n_boundary = 0;
   bool      interior_is_prefix = false; // the interior cells are cells 0 ... n_interior - 1
+  // entries per ghost: a whole cell, or for the Hermite-like basis two values per face point
+  // (data_per_face of laplace_operator_dg.h:565)
+  uint32_t               ghost_stride = 0;
+  std::vector<uint8_t *> nb_faces_dev; // Hermite-like basis: face of every sent cell towards the neighbour rank
 };
 
 // MultigridSolverDG (common/multigrid_solver_dg.h:55-747): the DG level on top of an FE_Q hierarchy
@@ -1324,6 +1353,28 @@ namespace
       }
   }
 
+  // Hermite-like basis: what the neighbour needs of a cell is the value and the normal derivative
+  // on the shared face, from the two node layers next to it (laplace_operator_dg.h:1015-1039)
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_pack_faces(T *__restrict__ buf, const T *__restrict__ vec, const uint32_t *__restrict__ cells,
+                 const uint8_t *__restrict__ faces, uint32_t count, int N, T hderiv)
+  {
+    const uint32_t nn2   = (uint32_t)(N * N);
+    const uint64_t total = (uint64_t)count * nn2;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+      {
+        const uint32_t c = (uint32_t)(i / nn2), j = (uint32_t)(i - (uint64_t)c * nn2);
+        const int      a = (int)(j % N), b = (int)(j / N), f = faces[c], d = f / 2, upper = f % 2;
+        const int      sd = d == 0 ? 1 : (d == 1 ? N : N * N), s1 = d == 0 ? N : 1, s2 = d == 2 ? N : N * N;
+        const T *__restrict__ x = vec + (uint64_t)cells[c] * nn2 * N + a * s1 + b * s2;
+        const T v0 = x[(upper ? N - 1 : 0) * sd];
+        const T v1 = x[(upper ? (N > 1 ? N - 2 : 0) : (N > 1 ? 1 : 0)) * sd];
+        buf[2 * i]     = v0;
+        buf[2 * i + 1] = upper ? hderiv * (v1 - v0) : hderiv * (v0 - v1);
+      }
+  }
+
   // pack kernels on the context's stream; `overlap`: the exchange itself on the side stream, begun
   // behind the pack kernels -- the caller enqueues independent work and then calls ghosts_finish
   int ghosts_pack(mgx_dg_operator_t op, const void *vec)
@@ -1333,9 +1384,17 @@ namespace
     const int      nnb = (int)op->nb_rank.size();
     for (int k = 0; k < nnb; ++k)
       {
-        const uint64_t total = (uint64_t)op->nb_count[k] * n3;
+        const bool     faces = op->basis == MGX_DG_HERMITE;
+        const int      N     = op->degree + 1;
+        const uint64_t total = (uint64_t)op->nb_count[k] * (faces ? (uint32_t)(N * N) : n3);
         const uint32_t grid  = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
-        if (op->number == MGX_F64)
+        if (faces && op->number == MGX_F64)
+          hipLaunchKernelGGL(k_pack_faces<double>, dim3(grid), dim3(256), 0, s, (double *)op->nb_send[k], (const double *)vec,
+                             op->nb_cells_dev[k], op->nb_faces_dev[k], op->nb_count[k], N, op->h.hderiv);
+        else if (faces)
+          hipLaunchKernelGGL(k_pack_faces<float>, dim3(grid), dim3(256), 0, s, (float *)op->nb_send[k], (const float *)vec,
+                             op->nb_cells_dev[k], op->nb_faces_dev[k], op->nb_count[k], N, (float)op->h.hderiv);
+        else if (op->number == MGX_F64)
           hipLaunchKernelGGL(k_pack_cells<double>, dim3(grid), dim3(256), 0, s, (double *)op->nb_send[k], (const double *)vec,
                              op->nb_cells_dev[k], op->nb_count[k], n3);
         else
@@ -1353,7 +1412,8 @@ namespace
     const int      nnb = (int)op->nb_rank.size();
     std::vector<void *> recv(nnb);
     for (int k = 0; k < nnb; ++k)
-      recv[k] = (char *)vec + (size_t)op->nb_recv_first[k] * n3 * es; // straight into the ghost cells
+      recv[k] = (char *)vec + ((size_t)op->n_cells * n3 + (size_t)(op->nb_recv_first[k] - op->n_cells) * op->ghost_stride) *
+                                es; // straight into the ghosts
     return mgx::exchange_buffers(op->ctx, op->plan_id, op->number, nnb, op->nb_rank.data(), op->nb_entries.data(),
                                  op->nb_send.data(), recv.data(), stream);
   }
@@ -1376,16 +1436,16 @@ namespace
     if (op->number == MGX_F64)
       {
         DGArgs<double> a{(const double *)src, (const double *)rhs, (double *)dst, op->neigh,
-                         (const DGConst<double> *)op->consts, (const double *)op->inv_diag, cell_list, cell_first, n_cells, f1, f2,
+                         (const DGConst<double> *)op->consts, (const double *)op->inv_diag, cell_list, cell_first, n_cells, op->n_cells, f1, f2,
                          iteration_index};
-        launch_degree<double>(s, op->degree, op->basis, action, a);
+        launch_degree<double>(s, op->degree, op->basis, action, a, op->n_ghost > 0);
       }
     else
       {
         DGArgs<float> a{(const float *)src, (const float *)rhs, (float *)dst, op->neigh,
-                        (const DGConst<float> *)op->consts, (const float *)op->inv_diag, cell_list, cell_first, n_cells, (float)f1,
+                        (const DGConst<float> *)op->consts, (const float *)op->inv_diag, cell_list, cell_first, n_cells, op->n_cells, (float)f1,
                         (float)f2, iteration_index};
-        launch_degree<float>(s, op->degree, op->basis, action, a);
+        launch_degree<float>(s, op->degree, op->basis, action, a, op->n_ghost > 0);
       }
     DG_HIP(hipGetLastError());
     return MGX_OK;
@@ -1478,6 +1538,7 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
   op->number  = desc->number;
   op->n_cells = desc->n_cells;
   op->n_ghost = desc->n_ghost_cells;
+  op->ghost_stride = desc->basis == MGX_DG_HERMITE ? 2u * (desc->degree + 1) * (desc->degree + 1) : (uint32_t)n3;
   std::string why;
   int         status = build_1d(desc->degree, desc->basis, op->h, why);
   if (status == MGX_OK)
@@ -1508,6 +1569,8 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
       (void)hipFree(p);
     for (auto *p : op->nb_send)
       (void)hipFree(p);
+    for (auto *p : op->nb_faces_dev)
+      (void)hipFree(p);
   };
 #define DG_HIP_C(call)                                                                      \
   do                                                                                        \
@@ -1531,15 +1594,44 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
         {
           op->nb_rank.push_back(e.neighbor_rank[k]);
           op->nb_count.push_back(e.count[k]);
-          op->nb_entries.push_back((uint32_t)((uint64_t)e.count[k] * n3));
+          op->nb_entries.push_back((uint32_t)((uint64_t)e.count[k] * op->ghost_stride));
           op->nb_recv_first.push_back(e.recv_first[k]);
           uint32_t *cells = nullptr;
           void     *buf   = nullptr;
           DG_HIP_C(hipMalloc((void **)&cells, sizeof(uint32_t) * ((size_t)e.count[k] + 1)));
           op->nb_cells_dev.push_back(cells);
           DG_HIP_C(hipMemcpyAsync(cells, e.send_cells[k], sizeof(uint32_t) * e.count[k], hipMemcpyHostToDevice, s));
-          DG_HIP_C(hipMalloc(&buf, nsz * ((size_t)e.count[k] * n3 + 1)));
+          DG_HIP_C(hipMalloc(&buf, nsz * ((size_t)e.count[k] * op->ghost_stride + 1)));
           op->nb_send.push_back(buf);
+          if (op->basis == MGX_DG_HERMITE)
+            {
+              // the face of every sent cell that looks at this neighbour's cells
+              std::vector<uint8_t> face(e.count[k]);
+              for (uint32_t i = 0; i < e.count[k]; ++i)
+                {
+                  int found = -1, n_found = 0;
+                  for (int f = 0; f < 6; ++f)
+                    {
+                      const int32_t nbr = desc->neighbours[(size_t)e.send_cells[k][i] * 6 + f];
+                      if (nbr >= 0 && (uint32_t)nbr >= e.recv_first[k] && (uint32_t)nbr < e.recv_first[k] + e.count[k])
+                        {
+                          found = f;
+                          ++n_found;
+                        }
+                    }
+                  if (n_found != 1)
+                    {
+                      cleanup();
+                      return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: a sent cell must touch the cells of the "
+                                                          "receiving rank through exactly one face");
+                    }
+                  face[i] = (uint8_t)found;
+                }
+              uint8_t *fd = nullptr;
+              DG_HIP_C(hipMalloc((void **)&fd, face.size() + 1));
+              op->nb_faces_dev.push_back(fd);
+              DG_HIP_C(hipMemcpy(fd, face.data(), face.size(), hipMemcpyHostToDevice));
+            }
         }
     }
   if (op->n_ghost > 0)
@@ -1599,13 +1691,16 @@ int mgx_dg_operator_destroy(mgx_dg_operator_t op)
     (void)hipFree(p);
   for (auto *p : op->nb_send)
     (void)hipFree(p);
+  for (auto *p : op->nb_faces_dev)
+    (void)hipFree(p);
   delete op;
   return MGX_OK;
 }
 
 uint64_t mgx_dg_operator_vector_size(mgx_dg_operator_t op)
 {
-  return op ? ((uint64_t)op->n_cells + op->n_ghost) * (op->degree + 1) * (op->degree + 1) * (op->degree + 1) : 0;
+  return op ? (uint64_t)op->n_cells * (op->degree + 1) * (op->degree + 1) * (op->degree + 1) + (uint64_t)op->n_ghost * op->ghost_stride
+            : 0;
 }
 
 int mgx_dg_update_ghost_values(mgx_dg_operator_t op, void *vec)
