@@ -148,6 +148,22 @@ def test_poisson_dg_harness_runs():
     assert 5 <= int(rows[0][6]) <= 10 and 5 <= int(rows[1][6]) <= 10
 
 
+def test_poisson_dg_discretisation_error_converges():
+    """the solve itself, checked end to end: for a solution that vanishes on the boundary (the benchmark's
+    own does not, see tools/poisson_dg.py) the L2 error of FE_DGQHermite(3) falls with h^4"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    err = []
+    for nr in (3, 4):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "poisson_dg.py"), "3", str(nr), "--solution",
+                              "vanishing", "--vcycle", "f64"], cwd=root, capture_output=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        err.append(float(out.stdout.decode().strip().splitlines()[-1].split()[4]))
+    assert err[0] < 2e-3 and 11 < err[0] / err[1] < 20, err
+
+
 @pytest.mark.parametrize("world,p,nr,basis,number", [(2, 3, 2, 0, "f64"), (4, 2, 2, 0, "f64"), (2, 3, 2, 2, "f32")])
 def test_decomposed_dg_multigrid_matches_single_domain_oracle(world, p, nr, basis, number):
     """DG level with ghost cells on top of the decomposed FE_Q hierarchy: 2 and 4 ranks over gloo on
