@@ -2,11 +2,11 @@
 # Round-2 evidence, collected on the MI355X box into gpurun_out/r02/ (copied to profiles/ afterwards):
 #   bench line, rocprofv3 kernel trace + stats of the same command, HBM traffic (FETCH_SIZE / WRITE_SIZE in
 #   separate passes) and SQ counters of the macro-element brick kernel, the p = 8 bench line, the DG harness.
-# usage: tools/r02_profiles.sh [stage ...]   stages: bench trace pmc sq p8 dg shell   (default: all)
+# usage: tools/r02_profiles.sh [stage ...]   stages: bench trace forms pmc sq p8 dg shell   (default: all)
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-stages=${@:-bench trace pmc sq p8 dg shell}
+stages=${@:-bench trace forms pmc sq p8 dg shell}
 for s in $stages; do
 case $s in
 bench)
@@ -61,6 +61,14 @@ dg)
   cp $(find $O/ktdg -name "*kernel_stats.csv" | head -1) $O/kernel_stats_matvec_dg_cheby_p4_33M.csv
   rm -rf $O/ktdg
   grep Best $O/matvec_dg_cheby_p4_262M.txt | cut -c1-200 ;;
+forms)
+  # only the finest level runs here: the per-symbol averages of --stats are per colour launch of the 135 M DoF level
+  # (in the bench trace a symbol also covers the launches of the coarser brick levels with the same persistent grid)
+  rm -rf $O/ktf
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktf -o t -- python3 $R/tools/matvec_loop.py 128 10 cheb > $O/forms_profiled.log 2>&1
+  cp $(find $O/ktf -name "*kernel_stats.csv" | head -1) $O/kernel_stats_finest_level_forms_128cube_p4.csv
+  rm -rf $O/ktf
+  head -8 $O/kernel_stats_finest_level_forms_128cube_p4.csv | cut -c1-60,200-330 ;;
 shell)
   python3 $R/tools/shell_bench.py 4 6 > $O/shell_sector_matvec_p4.txt 2>&1
   tail -1 $O/shell_sector_matvec_p4.txt ;;
