@@ -28,6 +28,8 @@ def main():
     mode, p, nr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     vfloat = "f32" in sys.argv[4:]  # V-cycle number type (reference default: float)
     strong = "strong" in sys.argv[4:]  # block-split of the square mesh with n_subdiv = 2 (bench.py --scaling strong)
+    # poisson_shell slice: shell sector (or sheared box) with the variable coefficient, block-split like "strong"
+    mapped = [g for g in ("shell_sector", "sheared") if g in sys.argv[4:]]
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
@@ -41,7 +43,13 @@ def main():
     from oracle import Oracle
 
     procs = mg.process_grid(world)
-    if strong:
+    if mapped:
+        problem = "shell" if mapped[0] == "shell_sector" else "cube"
+        cube = mg.Cube(p, n_refine=nr, box=(2, 2, 2), procs=procs, rank=rank, origin=-0.9, h0=0.95, geometry=mapped[0],
+                       problem=problem)
+        orc = Oracle(p, n_subdiv=2, n_refine=nr, degree=3, n_cycles=1, vfloat=vfloat, geometry=mapped[0], problem=problem,
+                     origin=-0.9, h0=0.95)
+    elif strong:
         cube = mg.Cube(p, n_refine=nr, box=(2, 2, 2), procs=procs, rank=rank, origin=-0.9, h0=0.95)
         orc = Oracle(p, n_subdiv=2, n_refine=nr, degree=3, n_cycles=1, vfloat=vfloat)
     else:

@@ -120,3 +120,10 @@ def test_gloo_exchange_protocol_block_split_cube(world):
     rhs and unique ownership on every level against the single-domain oracle"""
     outs = launch("host", world, 2, 2, extra=("strong",))
     assert all("host ok" in o for o in outs), outs
+
+
+def test_gloo_exchange_protocol_shell_sector():
+    """the poisson_shell slice block-split over two ranks: right-hand side of the mapped mesh with the variable
+    coefficient's solution, summed over the rank interface, against the single-domain oracle"""
+    outs = launch("host", 2, 3, 2, extra=("shell_sector",))
+    assert all("host ok" in o for o in outs), outs

@@ -22,6 +22,15 @@ def test_block_split_cube_matches_oracle(world, p, nr):
     assert all("gpu ok" in o for o in outs), outs
 
 
+@pytest.mark.parametrize("world,p,nr,geometry", [(2, 4, 2, "shell_sector"), (4, 3, 2, "shell_sector"), (2, 2, 2, "sheared")])
+def test_decomposed_variable_coefficient_on_mapped_mesh(world, p, nr, geometry):
+    """BASELINE config 4 on several ranks: the general tensor branch (six coefficients per quadrature point,
+    shell sector with the poisson_shell coefficient; full constant tensor on the sheared box) block-split
+    over the ranks, operator / smoother parameters / V-cycle / FMG / PCG against the single-domain oracle"""
+    outs = launch("gpu", world, p, nr, extra=(geometry,))
+    assert all("gpu ok" in o for o in outs), outs
+
+
 @pytest.mark.parametrize("world,p,nr,extra", [(2, 4, 3, ()), (4, 4, 3, ("strong",)), (2, 8, 2, ()), (2, 4, 3, ("f32",))])
 def test_interface_bricks_first_with_overlapped_exchange(monkeypatch, world, p, nr, extra):
     """split schedule forced on every brick level (MGX_OVERLAP_MIN_BRICKS=1): the bricks on the rank
