@@ -124,8 +124,33 @@ def spawn(args):
         env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // args.gpus))))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that dies leaves the others waiting in a collective: once one has failed, the rest get
+    # 30 s to finish and are then ended (exactly the processes started here), so the run fails instead of hanging
+    import time
+    failed_at, out = None, None
+    while True:
+        try:
+            out, _ = procs[0].communicate(timeout=1.0)  # drains the pipe while waiting; a timed-out call loses nothing
+        except subprocess.TimeoutExpired:
+            pass
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10.0)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+    codes = [p.wait() for p in procs]
+    if out is None:
+        out, _ = procs[0].communicate()
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     if any(codes):
