@@ -21,7 +21,44 @@ from ._lib import F32, F64, INVALID_INDEX, MgxError, check
 
 __all__ = ["Context", "DeviceVector", "Cube", "LaplaceOperator", "Chebyshev", "Transfer", "MultigridSolver",
            "Communicator", "process_grid", "F32", "F64", "INVALID_INDEX", "MgxError", "DGLaplaceOperator", "dg_cheby_mesh",
-           "dg_box_neighbours", "dg_box_partition", "dg_partition", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver"]
+           "dg_box_neighbours", "dg_box_partition", "dg_partition", "DG_HERMITE", "DG_GAUSS_LOBATTO", "DG_GAUSS", "DGMultigridSolver",
+           "spawn_ranks"]
+
+
+def spawn_ranks(script, argv, n, one_gpu=False, grace=30.0):
+    """Start n ranks of `script` (fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the
+    calling process never touches the GPU) and wait for them.  Once a rank has failed the others get `grace`
+    seconds -- they may sit in a collective the failed rank never joins -- and are then ended (exactly the
+    processes started here).  Returns the exit codes."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.5)
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10.0)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    return [p.wait() for p in procs]
 
 
 def process_grid(size):

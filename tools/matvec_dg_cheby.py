@@ -188,20 +188,8 @@ def main():
 
 
 def spawn(n):
-    """start n ranks of this script (the parent never touches the GPU), relay rank 0's output"""
-    import socket
-    import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    one_gpu = os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl"
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
+    """start n ranks of this script (the parent never touches the GPU)"""
+    codes = mg.spawn_ranks(__file__, sys.argv[1:], n, one_gpu=os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl")
     if any(codes):
         raise SystemExit("matvec_dg_cheby.py: rank exit codes %s" % codes)
 
