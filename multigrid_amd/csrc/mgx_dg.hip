@@ -100,6 +100,12 @@ namespace
     static constexpr int CPW_L = 65536 / (CELL * (int)sizeof(T));
     static constexpr int CPW   = CPW_T < CPW_L ? CPW_T : CPW_L;
     static constexpr int THREADS = ((CPW * NN2 + 63) / 64) * 64;
+    // Waves per SIMD the register allocation is asked to allow (fp32; the fp64 kernels are bound by their
+    // LDS at 3 waves).  One more than the compiler takes by itself where the LDS admits it and the cut is
+    // below ~10 registers -- measured on the merged Chebyshev step: p = 4 76 -> 72 VGPRs, 6 -> 7 waves,
+    // +3...7 % (8 waves = 64 VGPRs spill: -10 %); p = 5 89 -> 80, 5 -> 6 waves, +8...11 %; p = 6 +1...2 %;
+    // p = 8 112 -> 96, 4 -> 5 waves, +7...8 %.
+    static constexpr int MINW = sizeof(T) != 4 ? 1 : (P == 4 ? 7 : (P == 5 || P == 6 ? 6 : (P == 8 ? 5 : 1)));
     static_assert(CPW >= 1, "cell does not fit the LDS");
   };
 
@@ -226,7 +232,7 @@ namespace
 
   // GHOSTS (Hermite-like basis on a decomposed mesh): neighbour entries >= A.n_owned are ghost faces
   template <int P, typename T, int TYPE, int ACTION, bool GHOSTS = false>
-  __global__ void __launch_bounds__((DGCfg<P, T>::THREADS)) dg_cell_kernel(const DGArgs<T> A)
+  __global__ void __launch_bounds__((DGCfg<P, T>::THREADS), (DGCfg<P, T>::MINW)) dg_cell_kernel(const DGArgs<T> A)
   {
     using C         = DGCfg<P, T>;
     constexpr int N = C::N, NN2 = C::NN2, N3 = C::N3, PX = C::PX, VOL = C::VOL, FS = C::FS;
