@@ -1326,6 +1326,7 @@ struct mgx_dg_solver_s
   void             *P1 = nullptr;                                                      // device, V-cycle number type
   const uint32_t   *idx27 = nullptr;
   uint32_t          n_cells = 0, n_cg = 0;
+  bool              cg_eight_colours = false; // cells c, c + 8, ... of the FE_Q level share no DoF
   void             *cg_defect = nullptr, *cg_update = nullptr; // the FE_Q solver's finest-level vectors
   double           *r = nullptr, *z = nullptr, *d = nullptr, *h = nullptr; // PCG, fp64
 };
@@ -1930,7 +1931,8 @@ namespace
     // vmult_residual_and_restrict_to_cg (:616-618; laplace_operator_dg.h:1798-1819)
     MGX_DG_TRY(mgx_dg_vmult_residual(S->A, S->t, S->defect, S->update));
     DG_HIP(hipMemsetAsync(S->cg_defect, 0, dg_nsz(S->number) * S->n_cg, s));
-    mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, S->cg_defect, S->t, S->idx27, S->n_cells, S->P1);
+    mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, S->cg_defect, S->t, S->idx27, S->n_cells, S->P1,
+                               S->cg_eight_colours);
     if (S->decomposed) // FE_Q DoFs on a rank interface collect the contributions of all sharers
       MGX_DG_TRY(mgx_exchange_add(S->fe, S->cg_defect));
     MGX_DG_TRY(mgx_solver_v_cycle(S->cfe)); // :622
@@ -1978,6 +1980,25 @@ int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_
   S->idx27 = idx27;
   S->n_cells = nc;
   S->n_cg = ncg;
+  {
+    // forest order (the same child of every parent in one class): checked, not assumed
+    std::vector<uint32_t> h27(27 * (size_t)nc), stamp(ncg, 0xFFFFFFFFu);
+    DG_HIP(hipMemcpy(h27.data(), idx27, sizeof(uint32_t) * h27.size(), hipMemcpyDeviceToHost));
+    bool ok = nc >= 64;
+    for (uint32_t k = 0; k < 8 && ok; ++k)
+      for (uint32_t c = k; c < nc && ok; c += 8)
+        for (int e = 0; e < 27 && ok; ++e)
+          {
+            const uint32_t v = h27[27 * (size_t)c + e];
+            if (v == 0xFFFFFFFFu || v >= ncg)
+              continue;
+            // an entity's first DoF identifies it; stamp = class * nc + cell would overflow: class and cell apart
+            const uint32_t mark = k * 0x10000000u + (c >> 3);
+            ok                  = stamp[v] == 0xFFFFFFFFu || (stamp[v] >> 28) != k || stamp[v] == mark;
+            stamp[v]            = mark;
+          }
+    S->cg_eight_colours = ok && nc < 0x80000000u;
+  }
   hipStream_t  s  = (hipStream_t)mgx_context_stream(ctx);
   const size_t vb = dg_nsz(S->number) * S->n_vec;
   for (void **v : {&S->defect, &S->t, &S->update, &S->old})
@@ -2130,7 +2151,7 @@ int mgx_dg_restrict_to_cg(mgx_dg_solver_t S, void *cg_dst, const void *dg_src)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_restrict_to_cg: null argument");
   hipStream_t s = (hipStream_t)mgx_context_stream(S->ctx);
   DG_HIP(hipMemsetAsync(cg_dst, 0, dg_nsz(S->number) * S->n_cg, s));
-  mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, cg_dst, dg_src, S->idx27, S->n_cells, S->P1);
+  mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, cg_dst, dg_src, S->idx27, S->n_cells, S->P1, S->cg_eight_colours);
   DG_HIP(hipGetLastError());
   return MGX_OK;
 }

@@ -248,8 +248,10 @@ namespace mgx
   // DG <-> FE_Q transfer on one mesh (mgx_kernels.hip): to_dg: dg += P cg, else cg += P^T dg
   void launch_cell_loop_fused(hipStream_t s, const OperatorData &op, int mode, const void *x, const void *b,
                               const void *dinv, void *out, void *carrier, double f1, double f2, const void *x_old);
+  // eight_colours (restriction only): cells c and c' with c % 8 == c' % 8 share no DoF -- eight launches with
+  // plain read-modify-writes instead of one with atomics
   void launch_dg_cg_transfer(hipStream_t s, int number, int p, bool to_dg, void *dst, const void *src,
-                             const uint32_t *idx27, uint32_t n_cells, const void *P1);
+                             const uint32_t *idx27, uint32_t n_cells, const void *P1, bool eight_colours = false);
   void launch_zero_head_copy_tail(hipStream_t s, int number, void *dst, const void *src, uint32_t n_head, uint32_t n);
   void launch_scatter_map(hipStream_t s, int number, void *dst, const void *src, const uint32_t *map,
                           const uint8_t *mask, uint32_t n);

@@ -862,8 +862,10 @@ namespace mgx
   template <int P, typename T, bool TO_DG>
   __global__ void __launch_bounds__(Cfg<P>::THREADS)
     dg_cg_transfer_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
-                          uint32_t n_cells, const T *__restrict__ P1)
+                          uint32_t n_cells, const T *__restrict__ P1, uint32_t cell_first, uint32_t cell_stride, int plain)
   {
+    // cells cell_first + cell_stride * i, i < n_cells; plain: no two cells of the launch share a DoF,
+    // the restriction adds without atomics
     using C         = Cfg<P>;
     constexpr int N = C::N, LN = C::LN, N3 = N * N * N;
     __shared__ T  tile[C::CPB * C::CELL_LDS];
@@ -874,6 +876,7 @@ namespace mgx
     const bool    active  = lane_ok && cell < n_cells;
     if (cell >= n_cells)
       cell = n_cells - 1;
+    cell = cell_first + cell_stride * cell;
     T *U = tile + (lane_ok ? cw : 0) * C::CELL_LDS;
     T  r[N], o[N];
     // x-lines (j = a, k = b)
@@ -936,6 +939,8 @@ namespace mgx
             for (int i = 0; i < N; ++i)
               dst[(size_t)cell * N3 + (b * N + a) * N + i] += r[i];
           }
+        else if (plain)
+          scatter_add_line_plain<P, T>(dst, line_index<P>(idx27, cell, a, b), r);
         else
           scatter_add_line<P, T>(dst, line_index<P>(idx27, cell, a, b), r);
       }
@@ -943,30 +948,42 @@ namespace mgx
 
   template <int P, typename T>
   static void dg_cg_transfer_t(hipStream_t s, bool to_dg, void *dst, const void *src, const uint32_t *idx27,
-                               uint32_t n_cells, const void *P1)
+                               uint32_t n_cells, const void *P1, bool eight_colours)
   {
-    using C           = Cfg<P>;
-    const uint32_t nb = (n_cells + C::CPB - 1) / C::CPB;
+    using C = Cfg<P>;
     if (to_dg)
-      hipLaunchKernelGGL((dg_cg_transfer_kernel<P, T, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
-                         idx27, n_cells, (const T *)P1);
-    else
-      hipLaunchKernelGGL((dg_cg_transfer_kernel<P, T, false>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
-                         idx27, n_cells, (const T *)P1);
+      {
+        const uint32_t nb = (n_cells + C::CPB - 1) / C::CPB;
+        hipLaunchKernelGGL((dg_cg_transfer_kernel<P, T, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                           idx27, n_cells, (const T *)P1, 0u, 1u, 0);
+        return;
+      }
+    // restriction: cells c, c + 8, c + 16, ... share no DoF when the caller says so (forest order: the same
+    // child of every parent) -- eight launches with plain read-modify-writes instead of one with atomics
+    const uint32_t stride = eight_colours ? 8u : 1u;
+    for (uint32_t k = 0; k < stride; ++k)
+      {
+        const uint32_t count = (n_cells - k + stride - 1) / stride;
+        if (k >= n_cells || count == 0)
+          continue;
+        const uint32_t nb = (count + C::CPB - 1) / C::CPB;
+        hipLaunchKernelGGL((dg_cg_transfer_kernel<P, T, false>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                           idx27, count, (const T *)P1, k, stride, eight_colours ? 1 : 0);
+      }
   }
 
   void launch_dg_cg_transfer(hipStream_t s, int number, int p, bool to_dg, void *dst, const void *src,
-                             const uint32_t *idx27, uint32_t n_cells, const void *P1)
+                             const uint32_t *idx27, uint32_t n_cells, const void *P1, bool eight_colours)
   {
     if (n_cells == 0)
       return;
     if (number == 1)
       {
-        MGX_DISPATCH_P(p, dg_cg_transfer_t<P, double>(s, to_dg, dst, src, idx27, n_cells, P1));
+        MGX_DISPATCH_P(p, dg_cg_transfer_t<P, double>(s, to_dg, dst, src, idx27, n_cells, P1, eight_colours));
       }
     else
       {
-        MGX_DISPATCH_P(p, dg_cg_transfer_t<P, float>(s, to_dg, dst, src, idx27, n_cells, P1));
+        MGX_DISPATCH_P(p, dg_cg_transfer_t<P, float>(s, to_dg, dst, src, idx27, n_cells, P1, eight_colours));
       }
   }
 
