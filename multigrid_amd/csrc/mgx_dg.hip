@@ -92,13 +92,16 @@ namespace
     // of 8 B for fp64 accesses), so that accesses of the form "thread index + constant" (z-lines,
     // face points) of neighbouring cells in one half-wave fall on consecutive banks
     static constexpr int CELL0 = 3 * VOL + 6 * FS;
-    static constexpr int CELL  = CELL0 + (((NN2 - CELL0) % 32) + 32) % 32;
+    static constexpr int CELLP = CELL0 + (((NN2 - CELL0) % 32) + 32) % 32;
 #ifndef MGX_DG_WG_THREADS
 #define MGX_DG_WG_THREADS 128 // measured: 128-thread workgroups 4-11 % faster than 256 (barriers span two waves)
 #endif
     static constexpr int CPW_T = (MGX_DG_WG_THREADS / NN2) > 0 ? MGX_DG_WG_THREADS / NN2 : 1;
-    static constexpr int CPW_L = 65536 / (CELL * (int)sizeof(T));
+    static constexpr int CPW_L = 65536 / (CELLP * (int)sizeof(T));
     static constexpr int CPW   = CPW_T < CPW_L ? CPW_T : CPW_L;
+    // ... unless the padding costs a workgroup per CU (p = 3: 13 instead of 14; measured +4.7 % without it,
+    // while p = 4 and 5, where the count stays, are 1 % faster with it)
+    static constexpr int CELL = (163840 / (CPW * CELL0 * (int)sizeof(T)) > 163840 / (CPW * CELLP * (int)sizeof(T))) ? CELL0 : CELLP;
     static constexpr int THREADS = ((CPW * NN2 + 63) / 64) * 64;
     // Waves per SIMD the register allocation is asked to allow (fp32; the fp64 kernels are bound by their
     // LDS at 3 waves).  One more than the compiler takes by itself where the LDS admits it and the cut is
