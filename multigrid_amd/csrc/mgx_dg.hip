@@ -96,7 +96,11 @@ namespace
 #ifndef MGX_DG_WG_THREADS
 #define MGX_DG_WG_THREADS 128 // measured: 128-thread workgroups 4-11 % faster than 256 (barriers span two waves)
 #endif
-    static constexpr int CPW_T = (MGX_DG_WG_THREADS / NN2) > 0 ? MGX_DG_WG_THREADS / NN2 : 1;
+    // fp32, higher degrees: the size that fills its lanes best (p = 8: one cell = 81 of 128 lanes, three
+    // cells = 243 of 256).  Measured on the merged Chebyshev step against 128 threads: p = 5 192 threads +3 %
+    // (256: -4 %), p = 6 256 threads +7 % (192: -7 %), p = 8 256 threads +13 % (192: +9 %), p = 9 256: -11 %.
+    static constexpr int WG    = sizeof(T) != 4 ? MGX_DG_WG_THREADS : (P == 5 ? 192 : (P == 6 || P == 8 ? 256 : MGX_DG_WG_THREADS));
+    static constexpr int CPW_T = (WG / NN2) > 0 ? WG / NN2 : 1;
     static constexpr int CPW_L = 65536 / (CELLP * (int)sizeof(T));
     static constexpr int CPW   = CPW_T < CPW_L ? CPW_T : CPW_L;
     // ... unless the padding costs a workgroup per CU (p = 3: 13 instead of 14; measured +4.7 % without it,
