@@ -352,6 +352,10 @@ int mgx_solver_solve_hooked(mgx_solver_t solver, int do_analyze, double *reducti
                             mgx_level_hook hook, void *user);
 /* MultigridSolver::solve_cg() :483-493: SolverCG with ReductionControl(1000,1e-16,1e-9) */
 int mgx_solver_solve_cg(mgx_solver_t solver, unsigned int *iterations, double *reduction_rate);
+/* The residual norms SolverCG handed to its ReductionControl (:486) during the last
+ * mgx_solver_solve_cg / mgx_solver_solve_cg_fused: history[0] at the start, history[k] after
+ * iteration k.  *count receives their number (iterations + 1); at most `capacity` are written. */
+int mgx_solver_cg_history(mgx_solver_t solver, double *history, int capacity, int *count);
 /* MultigridSolver::vmult(dst, src) :498-510: one V-cycle; dst/src fp64 device vectors */
 int mgx_solver_vmult(mgx_solver_t solver, double *dst, const double *src);
 /* Decomposed hierarchies only (no counterpart in the reference, whose MPI ranks keep exchanging on

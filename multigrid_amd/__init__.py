@@ -726,6 +726,13 @@ class MultigridSolver:
         check(self.lib.mgx_solver_solve_cg(self.h, C.byref(its), C.byref(red)))
         return its.value, red.value
 
+    def cg_history(self):
+        """residual norms of the last solve_cg / solve_cg_fused: [0] at the start, [k] after iteration k"""
+        out = np.zeros(1001)
+        n = C.c_int()
+        check(self.lib.mgx_solver_cg_history(self.h, out.ctypes.data_as(_lib.f64p), out.size, C.byref(n)))
+        return out[:n.value].copy()
+
     def vmult(self, dst, src):
         check(self.lib.mgx_solver_vmult(self.h, dst.ptr, src.ptr))
 

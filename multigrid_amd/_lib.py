@@ -141,6 +141,7 @@ SIGNATURES = {
     "mgx_solver_solve": (C.c_int, [vp, C.c_int, f64p, f64p]),
     "mgx_solver_solve_hooked": (C.c_int, [vp, C.c_int, f64p, f64p, LEVEL_HOOK_FN, vp]),
     "mgx_solver_solve_cg": (C.c_int, [vp, C.POINTER(C.c_uint), f64p]),
+    "mgx_solver_cg_history": (C.c_int, [vp, f64p, C.c_int, C.POINTER(C.c_int)]),
     "mgx_solver_solve_cg_fused": (C.c_int, [vp, C.POINTER(C.c_uint), f64p]),
     "mgx_solver_vmult_with_residual_update": (C.c_int, [vp, vp, vp, C.c_double, f64p]),
     "mgx_vmult_with_cg_update": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, f64p]),

@@ -110,7 +110,6 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
   t.exchange_unfused    = flag("MGX_EXCHANGE_UNFUSED");
   t.cell_colour_min     = num("MGX_CELL_COLOUR_MIN", t.cell_colour_min);
-  t.fused_general       = flag("MGX_FUSED_GENERAL");
   t.no_graph            = flag("MGX_NO_GRAPH");
   t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
   t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
@@ -301,6 +300,7 @@ struct mgx_solver_s
   uint8_t        *agg_owned  = nullptr; // device: 1 where this rank owns the DoF
   hipEvent_t      agg_in = nullptr, agg_out = nullptr;
   std::vector<double> agg_host;         // callback transport: staging of the allreduce
+  std::vector<double> cg_history;       // residual norms of the last solve_cg: start, then one per iteration
 };
 
 namespace
@@ -547,6 +547,16 @@ namespace
         },
         [](hipStream_t) {});
     ProfileBracket pb(op, 0);
+    if (op->d.asm_start)
+      {
+        // ordered assembly: the cell loop writes every entry of dst (and the identity rows with it when
+        // the constrained DoFs are the tail of the vector)
+        const bool tail = identity_rows && identity_done && op->constrained_last;
+        launch_cell_loop(s, op->d, dst, src, tail ? src : nullptr, op->d.n_dofs - op->d.n_constrained);
+        if (tail)
+          *identity_done = true;
+        return exchange_add(op, dst);
+      }
     // "zero dst within the loop" (laplace_operator.h:590)
     if (identity_rows && identity_done && op->constrained_last && op->d.n_dofs < (1u << 22))
       {
@@ -1235,40 +1245,6 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
           d.n_cell_colours = n_colours;
           MGX_HIP(hipMalloc((void **)&d.cell_order, sizeof(uint32_t) * (size_t)desc->n_cells));
           MGX_HIP(hipMemcpy(d.cell_order, order.data(), sizeof(uint32_t) * (size_t)desc->n_cells, hipMemcpyHostToDevice));
-          // first / last cell, in colour order, on every entity: the fused Chebyshev update of the
-          // colour-by-colour launches stores instead of adding on FIRST and completes a DoF on LAST
-          std::vector<uint8_t> lo(desc->n_dofs, 255), hi(desc->n_dofs, 0);
-          auto                 carries = [&](int e) {
-            const int inner = (e % 3 == 1) + ((e / 3) % 3 == 1) + (e / 9 == 1);
-            return !(inner > 0 && pm1 == 0);
-          };
-          for (uint32_t c = 0; c < desc->n_cells; ++c)
-            for (int e = 0; e < 27; ++e)
-              {
-                const uint32_t k = desc->idx27[27 * (size_t)c + e];
-                if (e == 13 || !carries(e) || k == MGX_INVALID_INDEX)
-                  continue;
-                lo[k] = std::min(lo[k], colour[c]);
-                hi[k] = std::max(hi[k], colour[c]);
-              }
-          std::vector<uint64_t> fl(desc->n_cells, 0);
-          for (uint32_t c = 0; c < desc->n_cells; ++c)
-            {
-              uint64_t f = (1ull << 13) | (1ull << (27 + 13)); // the cell interior belongs to the cell alone
-              for (int e = 0; e < 27; ++e)
-                {
-                  const uint32_t k = desc->idx27[27 * (size_t)c + e];
-                  if (e == 13 || !carries(e) || k == MGX_INVALID_INDEX)
-                    continue;
-                  if (lo[k] == colour[c])
-                    f |= 1ull << e;
-                  if (hi[k] == colour[c])
-                    f |= 1ull << (27 + e);
-                }
-              fl[c] = f;
-            }
-          MGX_HIP(hipMalloc((void **)&d.cell_flags, sizeof(uint64_t) * (size_t)desc->n_cells));
-          MGX_HIP(hipMemcpy(d.cell_flags, fl.data(), sizeof(uint64_t) * (size_t)desc->n_cells, hipMemcpyHostToDevice));
           MGX_TRACE("operator_create: general branch, %u cells in %d colours", desc->n_cells, n_colours);
         }
     }
@@ -1326,6 +1302,53 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       else
         MGX_TRACE("operator_create: per-cell kernel (%s)", why.c_str());
     }
+  // Ordered assembly for the per-cell kernels: levels without a brick schedule and without cell
+  // colours.  For every DoF the positions (cell (p+1)^3 + local index) of its contributions in
+  // ascending cell order, from the compressed index table (read_dof_values_compressed,
+  // vector_access_reduced.h:153-229; constrained entities contribute nothing).  Larger levels than
+  // kAssemblyMaxEntries keep the one launch with atomic adds (last bits not reproducible).
+  {
+    constexpr size_t kAssemblyMaxEntries = (size_t)1 << 26;
+    const size_t     n3 = (size_t)n * n * n, n_local = n3 * desc->n_cells;
+    if (!d.bricks.available() && !d.cell_order && n_local <= kAssemblyMaxEntries)
+      {
+        std::vector<uint32_t> start((size_t)desc->n_dofs + 1, 0), pos;
+        auto for_each_local = [&](auto &&f) {
+          for (uint32_t c = 0; c < desc->n_cells; ++c)
+            {
+              const uint32_t *ix = desc->idx27 + 27 * (size_t)c;
+              for (int k = 0; k < n; ++k)
+                for (int j = 0; j < n; ++j)
+                  {
+                    const int       cz = k == 0 ? 0 : (k == p ? 2 : 1), oz = cz == 1 ? k - 1 : 0;
+                    const int       cy = j == 0 ? 0 : (j == p ? 2 : 1), oy = cy == 1 ? j - 1 : 0;
+                    const uint32_t *e  = ix + 3 * (3 * cz + cy);
+                    const uint32_t  off = (uint32_t)((cy == 1 ? p - 1 : 1) * oz + oy);
+                    const uint32_t  l0  = (uint32_t)(c * n3 + (size_t)(k * n + j) * n);
+                    if (e[0] != MGX_INVALID_INDEX)
+                      f(e[0] + off, l0);
+                    if (e[1] != MGX_INVALID_INDEX)
+                      for (int i = 1; i < p; ++i)
+                        f(e[1] + off * (uint32_t)(p - 1) + (uint32_t)(i - 1), l0 + (uint32_t)i);
+                    if (e[2] != MGX_INVALID_INDEX)
+                      f(e[2] + off, l0 + (uint32_t)p);
+                  }
+            }
+        };
+        for_each_local([&](uint32_t dof, uint32_t) { ++start[dof + 1]; });
+        for (size_t i = 0; i < desc->n_dofs; ++i)
+          start[i + 1] += start[i];
+        pos.resize(start.back() + 1);
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+        for_each_local([&](uint32_t dof, uint32_t l) { pos[fill[dof]++] = l; });
+        MGX_HIP(hipMalloc((void **)&d.asm_start, sizeof(uint32_t) * start.size()));
+        MGX_HIP(hipMalloc((void **)&d.asm_pos, sizeof(uint32_t) * pos.size()));
+        MGX_HIP(hipMalloc(&d.cell_scratch, number_size(d.number) * n_local));
+        MGX_HIP(hipMemcpy(d.asm_start, start.data(), sizeof(uint32_t) * start.size(), hipMemcpyHostToDevice));
+        MGX_HIP(hipMemcpy(d.asm_pos, pos.data(), sizeof(uint32_t) * pos.size(), hipMemcpyHostToDevice));
+        MGX_TRACE("operator_create: ordered assembly of the per-cell kernel (%zu contributions)", pos.size() - 1);
+      }
+  }
   // smoother start vector statistics over the DoFs this rank owns
   {
     std::vector<uint8_t> skip(desc->n_dofs, 0);
@@ -1528,7 +1551,9 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.coef_q);
   (void)hipFree(op->d.grad_1d);
   (void)hipFree(op->d.cell_order);
-  (void)hipFree(op->d.cell_flags);
+  (void)hipFree(op->d.asm_start);
+  (void)hipFree(op->d.asm_pos);
+  (void)hipFree(op->d.cell_scratch);
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);
@@ -1709,7 +1734,35 @@ int mgx_compute_diagonal(mgx_operator_t op)
       m1d[i] = m;
     }
   MGX_HIP(hipMemsetAsync(op->d.inv_diag, 0, number_size(op->d.number) * op->d.n_dofs, s));
-  launch_cell_diagonal(s, op->d, op->d.inv_diag, a1d, m1d);
+  // The cell contributions are added up without atomics, in an order that does not depend on the run:
+  // brick levels colour by colour (bricks of one launch group share no DoF; inside a brick the cells
+  // with the same position m mod 8 in Morton order -- the same child of every parent -- do not touch),
+  // cell-coloured levels colour by colour, the others through the ordered assembly.
+  if (op->d.bricks.available())
+    {
+      const BrickData      &bd = op->d.bricks;
+      const uint32_t        cb = op->d.n_cells / bd.n_bricks; // cells per brick: 64 or 8
+      std::vector<uint32_t> lists, list_start(1, 0);
+      lists.reserve(op->d.n_cells);
+      for (int g = 0; g < bd.n_colours; ++g)
+        for (uint32_t q = 0; q < 8; ++q)
+          {
+            for (uint32_t pos = bd.colour_start[g]; pos < bd.colour_start[g + 1]; ++pos)
+              for (uint32_t m = q; m < cb; m += 8)
+                lists.push_back(bd.order[pos] * cb + m);
+            list_start.push_back((uint32_t)lists.size());
+          }
+      uint32_t *lists_dev = nullptr;
+      MGX_HIP(hipMalloc((void **)&lists_dev, sizeof(uint32_t) * (lists.size() + 1)));
+      MGX_HIP(hipMemcpyAsync(lists_dev, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice, s));
+      launch_cell_diagonal(s, op->d, op->d.inv_diag, a1d, m1d, lists_dev, list_start.data(), (int)list_start.size() - 1);
+      MGX_HIP(hipStreamSynchronize(s));
+      MGX_HIP(hipFree(lists_dev));
+    }
+  else if (op->d.cell_order)
+    launch_cell_diagonal(s, op->d, op->d.inv_diag, a1d, m1d, op->d.cell_order, op->d.cell_colour_start, op->d.n_cell_colours);
+  else
+    launch_cell_diagonal(s, op->d, op->d.inv_diag, a1d, m1d);
   MGX_TRY(exchange_add(op, op->d.inv_diag)); // Vector::compress(add) of the reference's cell_loop
   // set_constrained_entries_to_one + invert (laplace_operator.h:757-765)
   launch_constrained_set(s, op->d.number, op->d.inv_diag, 1.0, op->d.constrained, op->d.n_constrained);
@@ -1927,15 +1980,6 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
-  if (!op->d.bricks.available())
-    {
-      // colour-by-colour general branch (variable coefficient / full tensor), one rank
-      launch_cell_loop_fused(s, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old);
-      launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
-                              op->d.n_constrained, nullptr, old, f0);
-      MGX_HIP(hipGetLastError());
-      return MGX_OK;
-    }
   // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the update there
   MGX_TRY(brick_loop_with_exchange(
     op, mode, sm->tmp,
@@ -1970,12 +2014,8 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
   hipStream_t              s  = op->ctx->stream;
   const int                num = op->d.number;
   const size_t             n   = op->d.n_dofs;
-  // levels without a brick schedule: matvec + elementwise update, unless the general branch runs
-  // colour by colour on one rank and MGX_FUSED_GENERAL asks for the update inside the cell loop (as on
-  // brick levels; off by default: the scattered reads of the update cost more than the streaming kernel)
-  const bool general_fused = !op->d.bricks.available() && op->d.cell_order && op->d.cell_flags && !op->plan &&
-                             op->ctx->tun.fused_general;
-  if (!op->d.bricks.available() && !general_fused)
+  // levels without a brick schedule: matvec + elementwise update
+  if (!op->d.bricks.available())
     {
       if (is_step)
         {
@@ -2879,6 +2919,7 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
   MGX_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
   double       res = res0, rz = 0, rz_old = 0;
   unsigned int it  = 0;
+  S->cg_history.assign(1, res0);
   // SolverCG with ReductionControl(1000, 1e-16, 1e-9) (:486)
   while (res > 1e-16 && res > 1e-9 * res0 && it < 1000)
     {
@@ -2899,6 +2940,7 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
       else
         MGX_TRY(read_result(ctx, &res));
       res = std::sqrt(res);
+      S->cg_history.push_back(res);
     }
   if (iterations)
     *iterations = it;
@@ -2977,6 +3019,7 @@ int mgx_solver_solve_cg_fused(mgx_solver_t S, unsigned int *iterations, double *
   MGX_TRY(dot(ctx, MGX_F64, r, q, n, &rz));
   double       alpha = 0., beta = 0., res = res0;
   unsigned int it = 0;
+  S->cg_history.assign(1, res0);
   while (res > 1e-16 && res > 1e-9 * res0 && it < 1000) // ReductionControl(1000, 1e-16, 1e-9), :486
     {
       ++it;
@@ -2990,6 +3033,7 @@ int mgx_solver_solve_cg_fused(mgx_solver_t S, unsigned int *iterations, double *
       MGX_HIP(hipMemcpyAsync(h, A->cg_result, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
       MGX_TRY(dot(ctx, MGX_F64, r, q, n, &rz_new)); // synchronises the stream
       res  = std::sqrt(h[2]);
+      S->cg_history.push_back(res);
       beta = rz_new / rz;
       rz   = rz_new;
     }
@@ -3001,6 +3045,15 @@ int mgx_solver_solve_cg_fused(mgx_solver_t S, unsigned int *iterations, double *
   MGX_HIP(hipGetLastError());
   if (it >= 1000)
     return fail(MGX_ERR_NOT_CONVERGED, "mgx_solver_solve_cg_fused: no convergence in 1000 iterations");
+  return MGX_OK;
+}
+
+int mgx_solver_cg_history(mgx_solver_t S, double *history, int capacity, int *count)
+{
+  MGX_REQUIRE(S && count && (history || capacity == 0), "mgx_solver_cg_history: null argument");
+  for (int i = 0; i < capacity && i < (int)S->cg_history.size(); ++i)
+    history[i] = S->cg_history[i];
+  *count = (int)S->cg_history.size();
   return MGX_OK;
 }
 

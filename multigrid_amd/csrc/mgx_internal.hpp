@@ -41,7 +41,6 @@ namespace mgx
     bool     restrict_atomic  = false; // MGX_RESTRICT_ATOMIC  one-launch restriction with atomics on every level
     uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour
     bool     exchange_unfused = false; // MGX_EXCHANGE_UNFUSED one pack / unpack launch per neighbour
-    bool     fused_general    = false; // MGX_FUSED_GENERAL    general branch: Chebyshev update inside the colour launches (measured slower than the streaming update kernel: 7.5 vs 7.0 ms per V-cycle on the shell sector)
     uint32_t cell_colour_min  = 4096;  // MGX_CELL_COLOUR_MIN  general-coefficient levels from this many cells run colour by colour
     bool     no_graph         = false; // MGX_NO_GRAPH         no HIP-graph replay of the coarse levels
     uint32_t graph_max_dofs   = 600000; // MGX_GRAPH_MAX_DOFS  largest level inside the replayed graph
@@ -113,9 +112,15 @@ namespace mgx
     // general branch on levels with many cells: cells sorted by colour (cells of one colour share
     // no DoF), one launch per colour without atomics; nullptr: one launch with atomic adds
     uint32_t *cell_order    = nullptr; // device [n_cells]
-    uint64_t *cell_flags    = nullptr; // device [n_cells]: bit e: first, bit 27 + e: last cell (in colour order) on entity e
     int       n_cell_colours = 0;
     uint32_t  cell_colour_start[33] = {0};
+    // Ordered assembly of the per-cell kernels (levels without a brick schedule and without cell
+    // colours): the kernels store each cell's (p+1)^3 local results in cell_scratch and
+    // assemble_kernel adds, for every DoF d, the entries asm_pos[asm_start[d] .. asm_start[d+1]) in
+    // ascending cell order -- no atomics, bitwise reproducible.  nullptr: not built.
+    uint32_t *asm_start     = nullptr; // device [n_dofs + 1]
+    uint32_t *asm_pos       = nullptr; // device: cell (p+1)^3 + local index (k n + j) n + i
+    void     *cell_scratch  = nullptr; // device [n_cells (p+1)^3], number type
     BrickData bricks;
     bool      cells_form    = false; // Tunables::cells_form of the context the operator was created on
     uint32_t  wide_max      = 1024;  // Tunables::wide_max
@@ -174,7 +179,12 @@ namespace mgx
 
   // ---- cell loops (mgx_kernels.hip) ----
   // dst += A_cells * src  (MatrixFree::cell_loop(local_apply), laplace_operator.h:527-558)
-  void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src);
+  // op.asm_start (ordered assembly): dst is WRITTEN (no zeroing by the caller), and dst[d] = tail_src[d] for
+  // d >= n_head if tail_src is given; otherwise dst must be zero on entry
+  void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src = nullptr,
+                        uint32_t n_head = 0);
+  // mode 0: dst = ordered sums of op.cell_scratch (tail as above), mode 1: dst += them
+  void launch_assemble(hipStream_t s, const OperatorData &op, int mode, void *dst, const void *tail_src, uint32_t n_head);
   // brick cell loop with fused post-operation (mgx_brick.hip); mode = BrickMode
   //   0: out = A src          1: out = a - A src
   //   2: out = src + f1 (src - out) + f2 b (a - A src)      3: same without the f1 term
@@ -208,8 +218,11 @@ namespace mgx
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)
   // a1d[i] = sum_q w_q (dphi_i(x_q))^2, m1d[i] = sum_q w_q phi_i(x_q)^2 (host arrays, n entries)
+  // lists / list_start / n_lists: device cell lists of launches whose cells share no DoF (plain adds);
+  // n_lists == 0: ordered assembly if op.asm_start, else one launch with atomic adds
   void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a1d,
-                            const double *m1d);
+                            const double *m1d, const uint32_t *lists = nullptr, const uint32_t *list_start = nullptr,
+                            int n_lists = 0);
   // transfers
   void launch_prolongate(hipStream_t s, const TransferData &t, void *fine, const void *coarse, bool add,
                          bool with_constraints);
@@ -246,8 +259,6 @@ namespace mgx
   // interface exchange helpers
   void launch_pack(hipStream_t s, int number, void *buf, const void *v, const uint32_t *list, uint32_t count);
   // DG <-> FE_Q transfer on one mesh (mgx_kernels.hip): to_dg: dg += P cg, else cg += P^T dg
-  void launch_cell_loop_fused(hipStream_t s, const OperatorData &op, int mode, const void *x, const void *b,
-                              const void *dinv, void *out, void *carrier, double f1, double f2, const void *x_old);
   // eight_colours (restriction only): cells c and c' with c % 8 == c' % 8 share no DoF -- eight launches with
   // plain read-modify-writes instead of one with atomics
   void launch_dg_cg_transfer(hipStream_t s, int number, int p, bool to_dg, void *dst, const void *src,

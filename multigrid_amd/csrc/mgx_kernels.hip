@@ -142,6 +142,46 @@ namespace mgx
       dst[L.b2 + L.off] += r[P];
   }
 
+  // Ordered assembly (levels without a brick schedule): instead of adding into the vector, a cell
+  // stores its (p+1)^3 local results at scratch[cell (p+1)^3 + (k n + j) n + i]; assemble_kernel
+  // below then adds, for every DoF, its contributions in ascending cell order -- no atomics, the
+  // sum does not depend on the order in which the workgroups happen to run
+  template <int P, typename T>
+  __device__ __forceinline__ void store_line_local(T *__restrict__ scratch, uint32_t cell, int j, int k,
+                                                   const T (&r)[P + 1])
+  {
+    constexpr int N = P + 1;
+    T            *o = scratch + (size_t)cell * (N * N * N) + (size_t)((k * N + j) * N);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      o[i] = r[i];
+  }
+
+  // mode 0: dst[d] = sum of the contributions of DoF d (DoFs without contributions, i.e. the
+  //         constrained ones, get 0 -- or tail_src[d] for d >= n_head: the identity rows of
+  //         LaplaceOperator::vmult, laplace_operator.h:592-593, when they are the tail of the vector)
+  // mode 1: dst[d] += sum (DoFs without contributions untouched)
+  template <typename T, int MODE>
+  __global__ void __launch_bounds__(256)
+    assemble_kernel(T *__restrict__ dst, const T *__restrict__ scratch, const uint32_t *__restrict__ start,
+                    const uint32_t *__restrict__ pos, uint32_t n_dofs, const T *__restrict__ tail_src, uint32_t n_head)
+  {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dofs)
+      return;
+    const uint32_t b = start[d], e = start[d + 1];
+    T              sum = T(0);
+    for (uint32_t k = b; k < e; ++k)
+      sum += scratch[pos[k]];
+    if (MODE == 1)
+      {
+        if (e > b)
+          dst[d] += sum;
+      }
+    else
+      dst[d] = (tail_src && d >= n_head) ? tail_src[d] : sum;
+  }
+
   // ------------------------------------------------------------------------------------------
   // Cell loop: dst += sum_cells  S^T [ sum_d D_d^T (c_d w) D_d ] S  src   (diagonal coefficient)
   // = local_apply of laplace_operator.h:527-558 with the quadrature-point operation :471-487.
@@ -149,7 +189,7 @@ namespace mgx
   template <int P, typename T>
   __global__ void __launch_bounds__(Cfg<P>::THREADS)
     cell_loop_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
-                     uint32_t n_cells, const Basis1D<T> *__restrict__ B, T c0, T c1, T c2)
+                     uint32_t n_cells, const Basis1D<T> *__restrict__ B, T c0, T c1, T c2, T *__restrict__ scratch)
   {
     using C           = Cfg<P>;
     constexpr int N   = C::N;
@@ -283,7 +323,10 @@ namespace mgx
         for (int i = 0; i < N; ++i)
           r[i] = Vc[xl + i];
         mvT<N, T>(B->S, r, q);
-        scatter_add_line<P, T>(dst, L, q);
+        if (scratch)
+          store_line_local<P, T>(scratch, cell, a, b, q);
+        else
+          scatter_add_line<P, T>(dst, L, q);
       }
   }
 
@@ -301,26 +344,11 @@ namespace mgx
   // ------------------------------------------------------------------------------------------
   // cell_list != nullptr: the launch covers the n_cells cells cell_list[0 .. n_cells) of one colour
   // (no shared DoFs among them) and adds to dst without atomics
-  // Fused Chebyshev update of a colour-by-colour launch (the counterpart of the brick loop's
-  // post-operation for the general branch): per cell, bit e of `flags` says that the cell is the
-  // FIRST one (in colour order) to touch its mesh entity e, bit 27 + e that it is the LAST one.
-  // Partial sums of A x travel in `carrier`; a DoF completed by this cell gets
-  //   out = x + f1 (x - x_old) [mode 2] | x + f1 x [mode 4] | x [mode 3]  + f2 D^-1 (b - A x)
-  template <typename T>
-  struct GeneralPost
-  {
-    int             mode; // 0: dst += A src
-    const uint64_t *flags;
-    T              *carrier, *out;
-    const T        *x_old, *rhs, *dinv;
-    T               f1, f2;
-  };
-
   template <int P, typename T, bool PERQ>
   __global__ void __launch_bounds__((Cfg<P, MGX_GENERAL_WG_THREADS>::THREADS))
     cell_loop_general_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
                              uint32_t n_cells, const Basis1D<T> *__restrict__ B, const T *__restrict__ coef_q, T c0,
-                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list, const GeneralPost<T> post)
+                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list, T *__restrict__ scratch)
   {
     using C           = Cfg<P, MGX_GENERAL_WG_THREADS>;
     constexpr int N   = C::N;
@@ -342,15 +370,12 @@ namespace mgx
     const int      slot   = lc < C::CPB ? lc : 0;
     T             *Uc = U + slot * C::CELL_LDS, *Xc = GX + slot * C::CELL_LDS, *Yc = GY + slot * C::CELL_LDS;
     const int      xl = (b * N + a) * LN, yl = b * PL + a, zl = b * LN + a;
-    T              r[N], q[N], gz[N], xs[N];
+    T              r[N], q[N], gz[N];
     LineIndex<P>   L;
     if (active) // nodal -> quadrature along x
       {
         L = line_index<P>(idx27, cell, a, b);
         gather_line<P, T>(src, L, r);
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-          xs[i] = r[i]; // the fused update needs the source values again
         mv<N, T>(B->S, r, q);
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -477,39 +502,8 @@ namespace mgx
         for (int i = 0; i < N; ++i)
           r[i] = Uc[xl + i];
         mvT<N, T>(B->S, r, q);
-        if (post.mode != 0)
-          {
-            int cy, oy, cz, oz;
-            node_code<P>(a, cy, oy);
-            node_code<P>(b, cz, oz);
-            const int      e0 = 9 * cz + 3 * cy;
-            const uint64_t fl = post.flags[cell];
-            auto           one = [&](uint32_t g, int e, T v, T xi) {
-              const bool first = (fl >> e) & 1u, last = (fl >> (27 + e)) & 1u;
-              const T    ax    = first ? v : post.carrier[g] + v;
-              if (last)
-                {
-                  T xn = xi + post.f2 * post.dinv[g] * (post.rhs[g] - ax);
-                  if (post.mode == 2)
-                    xn += post.f1 * (xi - post.x_old[g]);
-                  else if (post.mode == 4)
-                    xn += post.f1 * xi;
-                  post.out[g] = xn;
-                }
-              else
-                post.carrier[g] = ax;
-            };
-            if (L.b0 != kInvalid)
-              one(L.b0 + L.off, e0, q[0], xs[0]);
-            if (L.b1 != kInvalid)
-              {
-#pragma unroll
-                for (int i = 0; i < P - 1; ++i)
-                  one(L.b1 + L.off * (uint32_t)(P - 1) + (uint32_t)i, e0 + 1, q[1 + i], xs[1 + i]);
-              }
-            if (L.b2 != kInvalid)
-              one(L.b2 + L.off, e0 + 2, q[P], xs[P]);
-          }
+        if (scratch)
+          store_line_local<P, T>(scratch, cell, a, b, q);
         else if (cell_list)
           scatter_add_line_plain<P, T>(dst, L, q);
         else
@@ -524,13 +518,17 @@ namespace mgx
   __global__ void __launch_bounds__(256)
     cell_diagonal_general_kernel(T *__restrict__ diag, const uint32_t *__restrict__ idx27, uint32_t n_cells,
                                  const Basis1D<T> *__restrict__ B, const T *__restrict__ G1,
-                                 const T *__restrict__ coef_q, T c0, T c1, T c2, T c3, T c4, T c5)
+                                 const T *__restrict__ coef_q, T c0, T c1, T c2, T c3, T c4, T c5,
+                                 const uint32_t *__restrict__ cell_list, T *__restrict__ scratch)
   {
+    // cell_list: the launch covers cells of one colour (no shared DoF), plain adds; scratch: local
+    // results for the ordered assembly; neither: atomic adds (non-reproducible last bits, fallback)
     constexpr int  N = P + 1, N3 = N * N * N;
     const uint32_t gid  = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t cell = gid / (N * N);
-    if (cell >= n_cells)
+    const uint32_t pos  = gid / (N * N);
+    if (pos >= n_cells)
       return;
+    const uint32_t cell = cell_list ? cell_list[pos] : pos;
     const int t = gid % (N * N), j = t % N, k = t / N;
     T         r[N];
 #pragma unroll
@@ -560,8 +558,13 @@ namespace mgx
                 }
             }
         }
+    if (scratch)
+      return store_line_local<P, T>(scratch, cell, j, k, r);
     const LineIndex<P> L = line_index<P>(idx27, cell, j, k);
-    scatter_add_line<P, T>(diag, L, r);
+    if (cell_list)
+      scatter_add_line_plain<P, T>(diag, L, r);
+    else
+      scatter_add_line<P, T>(diag, L, r);
   }
 
   // diagonal of the cell matrix (local_compute_diagonal, laplace_operator.h:770-800).  For the
@@ -577,21 +580,27 @@ namespace mgx
   template <int P, typename T>
   __global__ void __launch_bounds__(256)
     cell_diagonal_kernel(T *__restrict__ diag, const uint32_t *__restrict__ idx27, uint32_t n_cells,
-                         Diag1D<T> d1, T c0, T c1, T c2)
+                         Diag1D<T> d1, T c0, T c1, T c2, const uint32_t *__restrict__ cell_list, T *__restrict__ scratch)
   {
     constexpr int  N    = P + 1;
     const uint32_t gid  = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t cell = gid / (N * N);
-    if (cell >= n_cells)
+    const uint32_t pos  = gid / (N * N);
+    if (pos >= n_cells)
       return;
+    const uint32_t cell = cell_list ? cell_list[pos] : pos;
     const int t = gid % (N * N), j = t % N, k = t / N;
     T         r[N];
 #pragma unroll
     for (int i = 0; i < N; ++i)
       r[i] = c0 * d1.a[i] * d1.m[j] * d1.m[k] + c1 * d1.m[i] * d1.a[j] * d1.m[k] +
              c2 * d1.m[i] * d1.m[j] * d1.a[k];
+    if (scratch)
+      return store_line_local<P, T>(scratch, cell, j, k, r);
     const LineIndex<P> L = line_index<P>(idx27, cell, j, k);
-    scatter_add_line<P, T>(diag, L, r);
+    if (cell_list)
+      scatter_add_line_plain<P, T>(diag, L, r);
+    else
+      scatter_add_line<P, T>(diag, L, r);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -814,40 +823,66 @@ namespace mgx
       default: break;                          \
     }
 
+  template <typename T>
+  static void assemble_t(hipStream_t s, const OperatorData &op, int mode, void *dst, const void *tail_src, uint32_t n_head)
+  {
+    const uint32_t nb = (op.n_dofs + 255) / 256;
+    if (mode == 1)
+      hipLaunchKernelGGL((assemble_kernel<T, 1>), dim3(nb), dim3(256), 0, s, (T *)dst, (const T *)op.cell_scratch,
+                         op.asm_start, op.asm_pos, op.n_dofs, (const T *)nullptr, 0u);
+    else
+      hipLaunchKernelGGL((assemble_kernel<T, 0>), dim3(nb), dim3(256), 0, s, (T *)dst, (const T *)op.cell_scratch,
+                         op.asm_start, op.asm_pos, op.n_dofs, (const T *)tail_src, n_head);
+  }
+
+  void launch_assemble(hipStream_t s, const OperatorData &op, int mode, void *dst, const void *tail_src, uint32_t n_head)
+  {
+    if (op.number == 1)
+      assemble_t<double>(s, op, mode, dst, tail_src, n_head);
+    else
+      assemble_t<float>(s, op, mode, dst, tail_src, n_head);
+  }
+
+  // Three ways to add the cell contributions up (op decides): ordered assembly through the scratch
+  // array (op.asm_start; dst is written, not added to), one launch per cell colour with plain
+  // read-modify-writes (op.cell_order), or one launch with atomic adds (fallback).
   template <int P, typename T>
-  static void cell_loop_t(hipStream_t s, const OperatorData &op, void *dst, const void *src,
-                          const GeneralPost<T> post = GeneralPost<T>{})
+  static void cell_loop_t(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src,
+                          uint32_t n_head)
   {
     using C            = Cfg<P>;
     const uint32_t nb  = (op.n_cells + C::CPB - 1) / C::CPB;
+    T             *scratch = op.asm_start ? (T *)op.cell_scratch : nullptr;
     if (op.coef_q || op.full_tensor)
       {
         using C = Cfg<P, MGX_GENERAL_WG_THREADS>;
-        // one launch with atomics, or one launch per cell colour with plain read-modify-writes
-        const int n_launch = op.cell_order ? op.n_cell_colours : 1;
+        const bool coloured = op.cell_order && !scratch;
+        const int  n_launch = coloured ? op.n_cell_colours : 1;
         for (int k = 0; k < n_launch; ++k)
           {
-            const uint32_t  first = op.cell_order ? op.cell_colour_start[k] : 0;
-            const uint32_t  count = op.cell_order ? op.cell_colour_start[k + 1] - first : op.n_cells;
-            const uint32_t *list  = op.cell_order ? op.cell_order + first : nullptr;
+            const uint32_t  first = coloured ? op.cell_colour_start[k] : 0;
+            const uint32_t  count = coloured ? op.cell_colour_start[k + 1] - first : op.n_cells;
+            const uint32_t *list  = coloured ? op.cell_order + first : nullptr;
             const uint32_t  nbk   = (count + C::CPB - 1) / C::CPB;
             if (count == 0)
               continue;
             if (op.coef_q)
               hipLaunchKernelGGL((cell_loop_general_kernel<P, T, true>), dim3(nbk), dim3(C::THREADS), 0, s, (T *)dst,
                                  (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)op.coef_q, (T)0,
-                                 (T)0, (T)0, (T)0, (T)0, (T)0, list, post);
+                                 (T)0, (T)0, (T)0, (T)0, (T)0, list, scratch);
             else
               hipLaunchKernelGGL((cell_loop_general_kernel<P, T, false>), dim3(nbk), dim3(C::THREADS), 0, s, (T *)dst,
                                  (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)nullptr,
                                  (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5],
-                                 list, post);
+                                 list, scratch);
           }
       }
     else
       hipLaunchKernelGGL((cell_loop_kernel<P, T>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
                          op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
-                         (T)op.coef[2]);
+                         (T)op.coef[2], scratch);
+    if (scratch)
+      assemble_t<T>(s, op, 0, dst, tail_src, n_head);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -987,38 +1022,24 @@ namespace mgx
       }
   }
 
-  void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src)
+  void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src,
+                        uint32_t n_head)
   {
     if (op.number == 1)
       {
-        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, dst, src));
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, dst, src, tail_src, n_head));
       }
     else
       {
-        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src));
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src, tail_src, n_head));
       }
   }
 
-  // fused Chebyshev iteration of the colour-by-colour general branch (op.cell_order != nullptr)
-  void launch_cell_loop_fused(hipStream_t s, const OperatorData &op, int mode, const void *x, const void *b,
-                              const void *dinv, void *out, void *carrier, double f1, double f2, const void *x_old)
-  {
-    if (op.number == 1)
-      {
-        GeneralPost<double> post{mode, op.cell_flags, (double *)carrier, (double *)out, (const double *)x_old,
-                                 (const double *)b, (const double *)dinv, f1, f2};
-        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, nullptr, x, post));
-      }
-    else
-      {
-        GeneralPost<float> post{mode, op.cell_flags, (float *)carrier, (float *)out, (const float *)x_old,
-                                (const float *)b, (const float *)dinv, (float)f1, (float)f2};
-        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, nullptr, x, post));
-      }
-  }
-
+  // lists[k] .. lists[k + 1]: device cell lists of n_lists launches whose cells share no DoF (plain
+  // adds); n_lists == 0: ordered assembly if the operator has the tables, else one launch with atomics
   template <int P, typename T>
-  static void cell_diag_t(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m)
+  static void cell_diag_t(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m,
+                          const uint32_t *lists, const uint32_t *list_start, int n_lists)
   {
     constexpr int N = P + 1;
     Diag1D<T>     d1;
@@ -1027,30 +1048,42 @@ namespace mgx
         d1.a[i] = (T)a[i];
         d1.m[i] = (T)m[i];
       }
-    const uint64_t nthreads = (uint64_t)op.n_cells * N * N;
-    const uint32_t nb       = (uint32_t)((nthreads + 255) / 256);
-    if (op.coef_q)
-      hipLaunchKernelGGL((cell_diagonal_general_kernel<P, T, true>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27,
-                         op.n_cells, (const Basis1D<T> *)op.basis, (const T *)op.grad_1d, (const T *)op.coef_q, (T)0, (T)0,
-                         (T)0, (T)0, (T)0, (T)0);
-    else if (op.full_tensor)
-      hipLaunchKernelGGL((cell_diagonal_general_kernel<P, T, false>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27,
-                         op.n_cells, (const Basis1D<T> *)op.basis, (const T *)op.grad_1d, (const T *)nullptr, (T)op.coef[0],
-                         (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5]);
-    else
-      hipLaunchKernelGGL((cell_diagonal_kernel<P, T>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, op.n_cells,
-                         d1, (T)op.coef[0], (T)op.coef[1], (T)op.coef[2]);
+    T        *scratch  = (n_lists == 0 && op.asm_start) ? (T *)op.cell_scratch : nullptr;
+    const int n_launch = n_lists > 0 ? n_lists : 1;
+    for (int k = 0; k < n_launch; ++k)
+      {
+        const uint32_t  count = n_lists > 0 ? list_start[k + 1] - list_start[k] : op.n_cells;
+        const uint32_t *list  = n_lists > 0 ? lists + list_start[k] : nullptr;
+        if (count == 0)
+          continue;
+        const uint64_t nthreads = (uint64_t)count * N * N;
+        const uint32_t nb       = (uint32_t)((nthreads + 255) / 256);
+        if (op.coef_q)
+          hipLaunchKernelGGL((cell_diagonal_general_kernel<P, T, true>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, count,
+                             (const Basis1D<T> *)op.basis, (const T *)op.grad_1d, (const T *)op.coef_q, (T)0, (T)0, (T)0,
+                             (T)0, (T)0, (T)0, list, scratch);
+        else if (op.full_tensor)
+          hipLaunchKernelGGL((cell_diagonal_general_kernel<P, T, false>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, count,
+                             (const Basis1D<T> *)op.basis, (const T *)op.grad_1d, (const T *)nullptr, (T)op.coef[0],
+                             (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5], list, scratch);
+        else
+          hipLaunchKernelGGL((cell_diagonal_kernel<P, T>), dim3(nb), dim3(256), 0, s, (T *)diag, op.idx27, count, d1,
+                             (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], list, scratch);
+      }
+    if (scratch)
+      assemble_t<T>(s, op, 0, diag, nullptr, 0u);
   }
 
-  void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m)
+  void launch_cell_diagonal(hipStream_t s, const OperatorData &op, void *diag, const double *a, const double *m,
+                            const uint32_t *lists, const uint32_t *list_start, int n_lists)
   {
     if (op.number == 1)
       {
-        MGX_DISPATCH_P(op.p, cell_diag_t<P, double>(s, op, diag, a, m));
+        MGX_DISPATCH_P(op.p, cell_diag_t<P, double>(s, op, diag, a, m, lists, list_start, n_lists));
       }
     else
       {
-        MGX_DISPATCH_P(op.p, cell_diag_t<P, float>(s, op, diag, a, m));
+        MGX_DISPATCH_P(op.p, cell_diag_t<P, float>(s, op, diag, a, m, lists, list_start, n_lists));
       }
   }
 

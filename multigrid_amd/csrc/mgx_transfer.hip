@@ -117,8 +117,10 @@ namespace mgx
   __global__ void __launch_bounds__(TPCfg<P>::THREADS)
     restrict_pipe_kernel(T *__restrict__ coarse, const T *__restrict__ fine, const uint32_t *__restrict__ patch_,
                          const uint32_t *__restrict__ idx_c_, uint32_t n_parents_, const Basis1D<T> *__restrict__ B,
-                         uint32_t colour)
+                         uint32_t colour, T *__restrict__ scratch)
   {
+    // scratch (uncoloured launch only): the parent's (p+1)^3 sums go to scratch[parent (p+1)^3 + .] for the
+    // ordered assembly of the coarse level (mgx_kernels.hip, assemble_kernel) instead of atomic adds
     // a coloured launch sees the table rows of its parents as a strided array
     const uint32_t  n_parents = COLOURED ? n_parents_ / 8u : n_parents_;
     const uint32_t  pstride   = COLOURED ? 8u : 1u;
@@ -288,6 +290,13 @@ namespace mgx
                   }
                 if (b2 != kInvalid)
                   coarse[b2 + coff] = cur[COLOURED ? P : 0] + r[P];
+              }
+            else if (scratch)
+              {
+                T *o = scratch + (size_t)pc * (N * N * N) + (size_t)(l * N);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                  o[i] = r[i];
               }
             else
               {
@@ -521,13 +530,21 @@ namespace mgx
         const uint32_t g = std::min<uint32_t>(c.n_cells / 8u, grid_of(3, (const void *)restrict_pipe_kernel<P, T, true>));
         for (uint32_t colour = 0; colour < 8; ++colour)
           hipLaunchKernelGGL((restrict_pipe_kernel<P, T, true>), dim3(g), dim3(C::THREADS), 0, s, (T *)coarse_out,
-                             (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis, colour);
+                             (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis, colour,
+                             (T *)nullptr);
       }
     else
-      hipLaunchKernelGGL((restrict_pipe_kernel<P, T, false>),
-                         dim3(grid_of(2, (const void *)restrict_pipe_kernel<P, T, false>)), dim3(C::THREADS), 0, s,
-                         (T *)coarse_out, (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis,
-                         0u);
+      {
+        // coarse levels with the tables of the ordered assembly (built from the constrained index table):
+        // per-parent sums to the scratch array, then coarse += their ordered sum; else atomic adds
+        T *scratch = (c.asm_start && with_constraints) ? (T *)c.cell_scratch : nullptr;
+        hipLaunchKernelGGL((restrict_pipe_kernel<P, T, false>),
+                           dim3(grid_of(2, (const void *)restrict_pipe_kernel<P, T, false>)), dim3(C::THREADS), 0, s,
+                           (T *)coarse_out, (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis,
+                           0u, scratch);
+        if (scratch)
+          launch_assemble(s, c, 1, coarse_out, nullptr, 0u);
+      }
   }
 
 #define MGX_TP_DISPATCH(p, ...)                            \

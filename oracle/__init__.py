@@ -91,6 +91,8 @@ def lib():
     L.orc_solve.argtypes = [vp, C.c_int, _f64p]
     L.orc_solve_cg.restype = C.c_int
     L.orc_solve_cg.argtypes = [vp, _f64p]
+    L.orc_cg_history.restype = C.c_int
+    L.orc_cg_history.argtypes = [vp, _f64p, C.c_int]
     L.orc_l2_error.restype = C.c_double
     L.orc_l2_error.argtypes = [vp, C.c_int]
     L.orc_time_vmult.restype = C.c_double
@@ -311,6 +313,12 @@ class Oracle:
         red = C.c_double()
         its = self.L.orc_solve_cg(self.h, C.byref(red))
         return its, red.value
+
+    def cg_history(self):
+        """residual norms of the last solve_cg: [0] at the start, [k] after iteration k"""
+        out = np.zeros(1001)
+        n = self.L.orc_cg_history(self.h, _p(out), out.size)
+        return out[:n].copy()
 
     def l2_error(self, l=None):
         return self.L.orc_l2_error(self.h, self.max_level if l is None else l)

@@ -253,6 +253,10 @@ struct orc_problem
   uint32_t *bc_count;
   uint32_t **bc_idx;
   double  **bc_val;
+  /* residual norms of the last orc_solve_cg: [0] = start, [k] = after iteration k (what SolverCG
+   * hands to its ReductionControl); test infrastructure for comparing iteration histories */
+  double cg_history[1001];
+  int    cg_history_n;
 };
 
 static inline uint32_t morton_compact(uint32_t m)
@@ -1375,6 +1379,8 @@ int orc_solve_cg(orc_problem *P, double *reduction)
   const double res0 = l2_norm(n, r);
   double       res  = res0, rz = 0, rz_old;
   int          it   = 0;
+  P->cg_history[0] = res0;
+  P->cg_history_n  = 1;
   while (res > 1e-16 && res > 1e-9 * res0 && it < 1000)
     {
       ++it;
@@ -1397,6 +1403,7 @@ int orc_solve_cg(orc_problem *P, double *reduction)
           r[i] -= alpha * h[i];
         }
       res = l2_norm(n, r);
+      P->cg_history[P->cg_history_n++] = res;
     }
   if (reduction)
     *reduction = it > 0 ? pow(res / res0, 1. / it) : 1.; /* :491-492 */
@@ -1405,6 +1412,14 @@ int orc_solve_cg(orc_problem *P, double *reduction)
   free(d);
   free(h);
   return it;
+}
+
+/* residual norms of the last orc_solve_cg (start + one per iteration); returns their number */
+int orc_cg_history(const orc_problem *P, double *out, int capacity)
+{
+  for (int i = 0; i < P->cg_history_n && i < capacity; ++i)
+    out[i] = P->cg_history[i];
+  return P->cg_history_n;
 }
 
 /* ---- timing helpers for the cpu_baseline leg of bench.py ---- */

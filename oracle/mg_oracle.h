@@ -121,6 +121,8 @@ void orc_vcycle_apply(orc_problem *P, double *dst, const double *src);
 double orc_solve(orc_problem *P, int do_analyze, double *trace);
 /* MultigridSolver::solve_cg (multigrid_solver.h:483-493) */
 int orc_solve_cg(orc_problem *P, double *reduction);
+/* residual norms of that solve: [0] start, [k] after iteration k; returns their number */
+int orc_cg_history(const orc_problem *P, double *out, int capacity);
 /* MultigridSolver::compute_l2_error (multigrid_solver.h:298-343) */
 double orc_l2_error(orc_problem *P, int level);
 const double *orc_solution(orc_problem *P, int level);

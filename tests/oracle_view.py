@@ -104,3 +104,28 @@ class OracleView:
 
 def oracle_for(cube, *args, **kwargs):
     return OracleView(Oracle(*args, **kwargs), cube)
+
+
+def assert_same_cg(solver, orc, rtol=1e-6):
+    """solver.solve_cg() against orc.solve_cg() (multigrid_solver.h:483-493) through the residual history
+    SolverCG hands to its ReductionControl(1000, 1e-16, 1e-9): every common entry to `rtol`, relative.
+    The iteration counts must be equal -- except that they may differ by one when the oracle's residual at
+    the deciding iteration lies within 1 % of the stopping threshold, where the last bits of an
+    ill-conditioned problem (summation order of the device's reductions) decide which side of the
+    threshold an iterate falls on.  Returns (iterations, reduction rate) of the solver."""
+    import numpy as np
+
+    its, red = solver.solve_cg()
+    oits, _ = orc.solve_cg()
+    h, oh = np.asarray(solver.cg_history()), np.asarray(orc.cg_history())
+    assert len(h) == its + 1 and len(oh) == oits + 1
+    n = min(len(h), len(oh))
+    err = np.abs(h[:n] - oh[:n]) / oh[:n]
+    assert err.max() <= rtol, "PCG residual histories differ: %g at iteration %d" % (err.max(), int(err.argmax()))
+    if its != oits:
+        k = min(its, oits)  # the iteration after which one of the two stopped
+        threshold = max(1e-9 * oh[0], 1e-16)
+        assert abs(its - oits) == 1 and abs(oh[k] - threshold) <= 0.01 * threshold, (
+            "PCG iteration counts %d (device) vs %d (oracle); oracle residual %g at iteration %d, threshold %g"
+            % (its, oits, oh[k], k, threshold))
+    return its, red

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 mg = pytest.importorskip("multigrid_amd")
 from oracle import Oracle  # noqa: E402
-from oracle_view import oracle_for  # noqa: E402
+from oracle_view import assert_same_cg, oracle_for  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -218,9 +218,8 @@ def test_vcycle_fmg_pcg(ctx, p, ns, nr, degree, ncyc):
         np.testing.assert_allclose(trace[1:, 1], otrace[1:, 2], rtol=1e-6)  # residual end
     assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-8)
     assert rel(solver.get_solution().download(), orc.solution(lmax)) < 1e-9
-    its, red = solver.solve_cg()
-    oits, ored = orc.solve_cg()
-    assert its == oits
+    its, red = assert_same_cg(solver, orc)
+    ored = orc.solve_cg()[1]
     assert red == pytest.approx(ored, rel=1e-5)
     assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-8)
     solver.close()
@@ -285,6 +284,63 @@ def test_production_thresholds_p4_against_oracle(monkeypatch):
     cube.close()
     orc.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("p,nr,brick_min", [(4, 4, None), (3, 3, "4000000000"), (2, 4, "4000000000"), (8, 2, None)])
+def test_per_cell_levels_are_reproducible_and_match_the_oracle(monkeypatch, p, nr, brick_min):
+    """Levels below the brick threshold (production: < 512 bricks; "4000000000": every level) run the per-cell
+    kernel with the ordered assembly instead of atomic adds, their restriction and diagonal likewise:
+    operator, diagonal, smoother parameters, V-cycle and PCG against the oracle, and every result bitwise
+    the same when computed twice on two solvers (nothing on the path depends on the order in which
+    workgroups run)."""
+    if brick_min is None:
+        monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
+    else:
+        monkeypatch.setenv("MGX_BRICK_MIN", brick_min)
+    monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
+    c = mg.Context(0)
+    cube = mg.Cube(p, 1, nr)
+    orc = oracle_for(cube, p, 1, nr, degree=3, n_cycles=1)
+    results = []
+    for attempt in range(2):
+        solver = mg.MultigridSolver(c, cube, 3, 3, 1, mg.F64)
+        out = []
+        for l in range(cube.n_levels):
+            A = solver.matrix_dp(l)
+            x, b = cube.seeded_vector(l, 11), cube.seeded_vector(l, 12)
+            src, rhs, dst = c.vector(x.size, data=x), c.vector(x.size, data=b), c.vector(x.size)
+            dst.upload(np.full(x.size, np.nan))
+            A.vmult(dst, src)
+            assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+            out.append(dst.download())
+            A.vmult_residual(rhs, src, dst)
+            assert rel(dst.download(), orc.vmult_residual(l, b, x)) < 1e-12
+            out.append(dst.download())
+            out.append(A.get_matrix_diagonal_inverse().download())
+            assert rel(out[-1], orc.inv_diag(l)) < 1e-12
+            gi, oi = solver.smoother(l).info(), orc.cheb_info(l)
+            assert gi["degree"] == oi["degree"] and gi["cg_its"] == oi["cg_its"]
+            assert gi["lambda_max"] == pytest.approx(oi["lambda_max"], rel=1e-8)
+            out.append(np.array([gi["lambda_max"], gi["lambda_min"]]))
+            for v in (src, rhs, dst):
+                v.free()
+        lmax = cube.max_level
+        x = cube.seeded_vector(lmax, 5)
+        src, dst = c.vector(x.size, data=x), c.vector(x.size)
+        for _ in range(3):  # eager, captured, replayed
+            solver.vmult(dst, src)
+            assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+            out.append(dst.download())
+        assert_same_cg(solver, orc)
+        out.append(solver.cg_history())
+        out.append(solver.get_solution().download())
+        results.append(out)
+        solver.close()
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    cube.close()
+    orc.close()
+    c.close()
 
 
 def test_level_errors_of_the_analysed_solve(ctx):
@@ -477,8 +533,7 @@ def test_fourth_kind_chebyshev_smoother(ctx, p, ns, nr, degree):
     assert rate == pytest.approx(orate, rel=1e-6)
     np.testing.assert_allclose(trace[1:, 0], otrace[1:, 1], rtol=1e-9)
     assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-8)
-    its, _ = solver.solve_cg()
-    assert its == orc.solve_cg()[0]
+    assert_same_cg(solver, orc)
     mg.check(ctx.lib.mgx_solver_set_polynomial_type(solver.h, 0))
     solver.vmult(dst, src)
     assert rel(dst.download(), first.vcycle(x)) < 1e-9

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 mg = pytest.importorskip("multigrid_amd")
 from oracle import Oracle  # noqa: E402
-from oracle_view import oracle_for  # noqa: E402
+from oracle_view import assert_same_cg, oracle_for  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -69,9 +69,7 @@ def test_mapped_multigrid_solver(ctx, geometry, problem):
     orate, otrace = orc.solve(True)
     assert rate == pytest.approx(orate, rel=1e-6)
     assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-7)
-    its, red = solver.solve_cg()
-    oits, ored = orc.solve_cg()
-    assert its == oits
+    assert_same_cg(solver, orc)  # 1e6 coefficient contrast: residual history, not a bare iteration count
     assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-7)
     solver.close()
     cube.close()
@@ -149,51 +147,3 @@ def test_colour_by_colour_launches_of_the_general_branch(monkeypatch, geometry, 
     orc.close()
     c.close()
     c_atomic.close()
-
-
-@pytest.mark.parametrize("geometry,problem,p,nr,degree", [("shell_sector", "shell", 4, 2, 3), ("sheared", "cube", 2, 3, 3),
-                                                          ("sheared", "shell", 3, 2, 2), ("shell_sector", "shell", 4, 2, 1),
-                                                          ("sheared", "cube", 3, 2, 4)])
-def test_fused_chebyshev_of_the_general_branch(monkeypatch, geometry, problem, p, nr, degree):
-    """MGX_FUSED_GENERAL: colour-by-colour levels of the general branch apply the Chebyshev update inside
-    the cell loop (FIRST / LAST cell per entity in colour order, as the brick loop does) -- correct, but
-    measured slower than the streaming update kernel and therefore not the default: smoother, V-cycle,
-    FMG and PCG against the oracle with the colouring forced on every level, and against the default"""
-    monkeypatch.setenv("MGX_CELL_COLOUR_MIN", "1")
-    c_plain = mg.Context(0)
-    monkeypatch.setenv("MGX_FUSED_GENERAL", "1")
-    c = mg.Context(0)
-    cube = mg.Cube(p, n_refine=nr, box=(1, 1, 1), origin=-0.9, h0=1.9, geometry=geometry, problem=problem)
-    orc = oracle_for(cube, p, 1, nr, degree=degree, n_cycles=1, geometry=geometry, problem=problem, origin=-0.9, h0=1.9)
-    solver = mg.MultigridSolver(c, cube, degree, degree, 1, mg.F64)
-    plain = mg.MultigridSolver(c_plain, cube, degree, degree, 1, mg.F64)
-    for l in range(cube.n_levels):
-        sm = solver.smoother(l)
-        b = cube.seeded_vector(l, 7)
-        bd, xd = c.vector(b.size, data=b), c.vector(b.size)
-        sm.vmult(xd, bd)
-        x_ref = orc.cheb_vmult(l, b)
-        assert rel(xd.download(), x_ref) < 1e-10
-        sm.step(xd, bd)
-        assert rel(xd.download(), orc.cheb_step(l, x_ref, b)) < 1e-10
-    lmax = cube.max_level
-    x = cube.seeded_vector(lmax, 5)
-    src, dst = c.vector(x.size, data=x), c.vector(x.size)
-    for _ in range(3):
-        solver.vmult(dst, src)
-        assert rel(dst.download(), orc.vcycle(x)) < 1e-9
-    sp, dp = c_plain.vector(x.size, data=x), c_plain.vector(x.size)
-    plain.vmult(dp, sp)
-    assert rel(dp.download(), dst.download()) < 1e-11
-    rate, trace = solver.solve(True)
-    orate, otrace = orc.solve(True)
-    assert rate == pytest.approx(orate, rel=1e-6)
-    its, _ = solver.solve_cg()
-    assert its == orc.solve_cg()[0]
-    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=1e-7)
-    solver.close()
-    plain.close()
-    cube.close()
-    orc.close()
-    c.close()
-    c_plain.close()
