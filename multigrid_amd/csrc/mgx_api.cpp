@@ -110,6 +110,8 @@ mgx::Tunables mgx::Tunables::from_environment()
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
   t.exchange_unfused    = flag("MGX_EXCHANGE_UNFUSED");
   t.cell_colour_min     = num("MGX_CELL_COLOUR_MIN", t.cell_colour_min);
+  t.free_max_bricks     = num("MGX_FREE_MAX_BRICKS", t.free_max_bricks);
+  t.free_one_max        = num("MGX_FREE_ONE_MAX", t.free_one_max);
   t.no_graph            = flag("MGX_NO_GRAPH");
   t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
   t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
@@ -497,17 +499,25 @@ namespace
   // exchange, laplace_operator_dg.h:986-1057, packs the send-side data first but waits for all
   // requests before its cell loop; deal.II's own loops overlap inside MatrixFree.)  With the callback transport the host blocks in the exchange
   // while the interior launches, enqueued before, execute.
-  template <typename Launch, typename Fix>
-  int brick_loop_with_exchange(mgx_operator_t op, int form, void *carrier, Launch launch, Fix fix)
+  // Finish(stream, first, count) (colour-free schedule only, `free_schedule`): completes the DoFs
+  // [first, first + count) of the operator's list of brick-surface DoFs (launch_surf_finish); the
+  // first n_surf_shared of them are the rank-interface DoFs, whose sums go to the carrier.
+  template <typename Launch, typename Fix, typename Finish>
+  int brick_loop_with_exchange(mgx_operator_t op, int form, void *carrier, Launch launch, Fix fix, bool free_schedule,
+                               Finish finish)
   {
-    mgx_context_t ctx = op->ctx;
-    hipStream_t   s   = ctx->stream;
-    const int     ng = op->d.bricks.n_colours, ni = op->d.bricks.n_iface_groups;
+    mgx_context_t    ctx = op->ctx;
+    hipStream_t      s   = ctx->stream;
+    const BrickData &bd  = op->d.bricks;
+    const int        ng = free_schedule ? bd.fr.n_groups : bd.n_colours, ni = free_schedule ? bd.fr.n_iface_groups : bd.n_iface_groups;
+    const uint32_t   n_sh = bd.fr.n_surf_shared, n_all = bd.fr.n_surf_dofs;
     if (!op->plan || ni == 0 || !ctx->side)
       {
         {
           ProfileBracket pb(op, form);
           launch(s, 0, ng);
+          if (free_schedule)
+            finish(s, 0u, n_all);
         }
         if (op->plan)
           {
@@ -519,15 +529,24 @@ namespace
     {
       ProfileBracket pb(op, form);
       launch(s, 0, ni);
+      if (free_schedule)
+        finish(s, 0u, n_sh); // the interface sums are complete after the interface bricks
       MGX_HIP(hipEventRecord(ctx->ev_iface, s));
       MGX_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_iface, 0));
       launch(s, ni, ng); // enqueued before the (possibly host-blocking) exchange
+      if (free_schedule)
+        finish(s, n_sh, n_all - n_sh);
     }
     MGX_TRY(exchange_add(op, carrier, ctx->side));
     fix(ctx->side);
     MGX_HIP(hipEventRecord(ctx->ev_side, ctx->side));
     MGX_HIP(hipStreamWaitEvent(s, ctx->ev_side, 0));
     return MGX_OK;
+  }
+  template <typename Launch, typename Fix>
+  int brick_loop_with_exchange(mgx_operator_t op, int form, void *carrier, Launch launch, Fix fix)
+  {
+    return brick_loop_with_exchange(op, form, carrier, launch, fix, false, [](hipStream_t, uint32_t, uint32_t) {});
   }
 
   // dst = A src on the unconstrained rows (constrained rows untouched).  identity_rows (per-cell
@@ -540,12 +559,18 @@ namespace
       *identity_done = false;
     hipStream_t s = op->ctx->stream;
     if (op->d.bricks.available())
-      return brick_loop_with_exchange(
-        op, 0, dst,
-        [&](hipStream_t st, int g0, int g1) {
-          launch_brick_loop(st, op->d, 0, src, nullptr, nullptr, dst, dst, 0., 0., nullptr, 0., nullptr, nullptr, g0, g1);
-        },
-        [](hipStream_t) {});
+      {
+        const bool fr = op->d.bricks.fr.available();
+        return brick_loop_with_exchange(
+          op, 0, dst,
+          [&](hipStream_t st, int g0, int g1) {
+            launch_brick_loop(st, op->d, 0, src, nullptr, nullptr, dst, dst, 0., 0., nullptr, 0., nullptr, nullptr, g0, g1, fr);
+          },
+          [](hipStream_t) {}, fr,
+          [&](hipStream_t st, uint32_t first, uint32_t count) {
+            launch_surf_finish(st, op->d, 0, first, count, dst, src, dst, nullptr, nullptr, nullptr, 0., 0., 0.);
+          });
+      }
     ProfileBracket pb(op, 0);
     if (op->d.asm_start)
       {
@@ -1296,6 +1321,42 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
               build_item_map(p, map);
               MGX_HIP(hipMalloc((void **)&b.item_map, sizeof(uint32_t) * map.size()));
               MGX_HIP(hipMemcpy(b.item_map, map.data(), sizeof(uint32_t) * map.size(), hipMemcpyHostToDevice));
+              // Reduced-colour schedule of the plain / residual / Chebyshev forms (mgx_macro.hip, FREE): one
+              // class (one launch per level) on levels with at most free_one_max bricks, two classes up to
+              // free_max_bricks
+              const int n_classes = b.n_bricks <= tun.free_one_max ? 1 : 2;
+              FreeHost  fh;
+              if (!MGX_MACRO_PAIRS && !tun.cells_form && b.n_bricks <= tun.free_max_bricks &&
+                  (uint64_t)desc->n_dofs * number_size(d.number) < 0xFFFFFFF0ull &&
+                  build_free_schedule(p, bh, desc->n_dofs, ex ? ex->shared : nullptr, ex ? ex->n_shared : 0,
+                                      bh.n_iface_groups > 0, n_classes, map, fh) &&
+                  (size_t)b.n_bricks * fh.n_surf * number_size(d.number) < 0xFFFFFFF0ull && fh.n_groups <= 8)
+                {
+                  FreeSchedule &fr  = b.fr;
+                  fr.n_classes      = n_classes;
+                  fr.n_groups       = fh.n_groups;
+                  fr.n_iface_groups = fh.n_iface_groups;
+                  for (int g = 0; g <= fh.n_groups; ++g)
+                    fr.group_start[g] = fh.group_start[g];
+                  fr.n_surf        = fh.n_surf;
+                  fr.n_surf_dofs   = (uint32_t)fh.surf_dof.size();
+                  fr.n_surf_shared = fh.n_surf_shared;
+                  fh.surf_dof.push_back(0);
+                  fh.surf_pos.push_back(0);
+                  auto up = [&](uint32_t *&dev, const std::vector<uint32_t> &v) {
+                    if (hipMalloc((void **)&dev, sizeof(uint32_t) * v.size()) != hipSuccess)
+                      return false;
+                    return hipMemcpy(dev, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice) == hipSuccess;
+                  };
+                  MGX_REQUIRE(up(fr.surf_off, fh.surf_off) && up(fr.surf_dof, fh.surf_dof) && up(fr.surf_start, fh.surf_start) &&
+                                up(fr.surf_pos, fh.surf_pos),
+                              "mgx_operator_create: out of device memory (reduced-colour schedule)");
+                  MGX_HIP(hipMalloc(&fr.priv, (size_t)b.n_bricks * fh.n_surf * number_size(d.number) + 16));
+                  MGX_REQUIRE(up(fr.ent, fh.ent), "mgx_operator_create: out of device memory (reduced-colour schedule)");
+                  MGX_TRACE("operator_create: reduced-colour schedule, %d classes, %d groups, %u private values per brick, %u "
+                            "private DoFs (%u shared)",
+                            n_classes, fr.n_groups, fr.n_surf, fr.n_surf_dofs, fr.n_surf_shared);
+                }
             }
           MGX_TRACE("operator_create: %u bricks, %d colours", b.n_bricks, b.n_colours);
         }
@@ -1557,6 +1618,12 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);
+  (void)hipFree(op->d.bricks.fr.ent);
+  (void)hipFree(op->d.bricks.fr.surf_off);
+  (void)hipFree(op->d.bricks.fr.priv);
+  (void)hipFree(op->d.bricks.fr.surf_dof);
+  (void)hipFree(op->d.bricks.fr.surf_start);
+  (void)hipFree(op->d.bricks.fr.surf_pos);
   (void)hipFree(op->d.diag_items);
   (void)hipFree(op->cg_partials);
   (void)hipFree(op->cg_result);
@@ -1623,13 +1690,18 @@ int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void
     {
       // zeroing (:617-623) and rhs - A lhs (:624-631) are fused into the brick loop; interface
       // DoFs hold partial sums of A lhs: complete them, then rhs - (.)
+      const bool fr = op->d.bricks.fr.available();
       MGX_TRY(brick_loop_with_exchange(
         op, 1, res,
         [&](hipStream_t st, int g0, int g1) {
-          launch_brick_loop(st, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0., nullptr, 0., nullptr, nullptr, g0, g1);
+          launch_brick_loop(st, op->d, 1, lhs, rhs, nullptr, res, res, 0., 0., nullptr, 0., nullptr, nullptr, g0, g1, fr);
         },
         [&](hipStream_t st) {
           launch_list_residual(st, op->d.number, res, rhs, op->plan->shared_dev, op->plan->n_shared);
+        },
+        fr,
+        [&](hipStream_t st, uint32_t first, uint32_t count) {
+          launch_surf_finish(st, op->d, 1, first, count, res, lhs, res, rhs, nullptr, nullptr, 0., 0., 0.);
         }));
     }
   else
@@ -1981,15 +2053,20 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
   // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the update there
+  const bool fr = op->d.bricks.fr.available() && mode >= 2 && mode <= 6;
   MGX_TRY(brick_loop_with_exchange(
     op, mode, sm->tmp,
     [&](hipStream_t st, int g0, int g1) {
       launch_brick_loop(st, op->d, mode, cur, b, op->d.inv_diag, out, sm->tmp, f1, f2, old, f0, const_cast<void *>(coarse),
-                        coarse_blocks, g0, g1);
+                        coarse_blocks, g0, g1, fr);
     },
     [&](hipStream_t st) {
       launch_cheb_constrained(st, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
                               op->plan->n_shared, sm->tmp, old, f0);
+    },
+    fr,
+    [&](hipStream_t st, uint32_t first, uint32_t count) {
+      launch_surf_finish(st, op->d, mode, first, count, sm->tmp, cur, out, b, op->d.inv_diag, old, f1, f2, f0);
     }));
   launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
                           op->d.n_constrained, nullptr, old, f0);
@@ -2746,7 +2823,11 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
         else
           MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true));
       }
-      if (S->transfer[level]->d.coarse_blocks)
+      // Levels on the one-launch schedule run the residual as one launch and the transfers as kernels of
+      // their own: the fused forms below need the eight colour launches, each as long as a brick's
+      // whole latency chain on such a level (2 M DoFs: 63 instead of 147 us, 52 instead of 180 us)
+      const bool one_launch = S->matrix[level]->d.bricks.fr.available() && S->matrix[level]->d.bricks.fr.n_classes == 1;
+      if (S->transfer[level]->d.coarse_blocks && !one_launch)
         {
           // residual and restriction in one pass of the cell loop: t only carries the partial sums
           // of brick-surface DoFs between the colour launches, the residual is never stored
@@ -2774,7 +2855,7 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
       // its own: the first post-smoothing iteration forms x + P x_coarse while it gathers x
       mgx_operator_t Af = S->matrix[level];
       const bool     fused_prolong = S->transfer[level]->d.coarse_blocks && Af->d.bricks.item_map && !Af->d.cells_form &&
-                                 Af->d.separable && !S->ctx->tun.no_fused_prolong && S->smooth[level]->info.degree >= 1 &&
+                                 Af->d.separable && !S->ctx->tun.no_fused_prolong && S->smooth[level]->info.degree >= 1 && !one_launch &&
                                  (uint64_t)Af->d.n_dofs * number_size(Af->d.number) < 0xFFFFFFF0ull;
       if (fused_prolong)
         {

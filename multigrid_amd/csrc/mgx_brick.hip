@@ -895,7 +895,7 @@ namespace mgx
 
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0,
-                         void *coarse, const uint32_t *coarse_blocks, int g0, int g1)
+                         void *coarse, const uint32_t *coarse_blocks, int g0, int g1, bool free_schedule)
   {
     if (g1 < 0)
       g1 = op.bricks.n_colours;
@@ -908,11 +908,12 @@ namespace mgx
     if (op.separable && op.bricks.item_map && !op.cells_form)
       {
         const bool done = op.number == 1
-                            ? launch_macro_loop_f64(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1)
-                            : launch_macro_loop_f32(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
+                            ? launch_macro_loop_f64(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1, free_schedule)
+                            : launch_macro_loop_f32(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1, free_schedule);
         if (done)
           return;
       }
+    // (the caller asks for the colour-free schedule only where the macro-element kernel runs)
     if (op.number == 1)
       brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
     else

@@ -83,6 +83,12 @@ namespace mgx
     T              *src_w;         // kCgUpdate: the source vector p, written at completion
     T              *x_w;           // kCgUpdate: x, updated at completion
     double         *sums;          // kCgUpdate: [gridDim.x * 4] partial sums of this launch
+    // reduced-colour schedules (mgx_macro.hip, FREE): priv = the bricks' blocks of private values,
+    // [brick][n_surf], priv_bytes in all; surf_off[slot] = offset of the private entity `slot` inside a
+    // block (0xFFFFFFFF: not private, the entity follows its FIRST / LAST flags)
+    T              *priv;
+    const uint32_t *surf_off;
+    uint32_t        n_surf, priv_bytes;
   };
 
   // Entity table word: bits 0..29 first DoF of the entity, bit 30 FIRST, bit 31 LAST;

@@ -281,6 +281,218 @@ namespace mgx
     return true;
   }
 
+  bool build_free_schedule(int p, const BrickHost &bh, uint32_t n_dofs, const uint32_t *shared, uint32_t n_shared,
+                           bool split_interface, int n_classes, const std::vector<uint32_t> &item_map, FreeHost &out)
+  {
+    out = FreeHost();
+    const int      NBd = p <= 4 ? 4 : 2, E1 = 2 * NBd + 1, NE = E1 * E1 * E1;
+    const uint32_t nb  = bh.n_bricks;
+    if (nb == 0 || bh.n_entities != NE || (n_classes != 1 && n_classes != 2))
+      return false;
+    auto coords = [&](int slot, int(&e)[3]) {
+      e[0] = slot % E1;
+      e[1] = (slot / E1) % E1;
+      e[2] = slot / (E1 * E1);
+    };
+    auto n_boundary = [&](int slot) {
+      int e[3];
+      coords(slot, e);
+      return (e[0] == 0 || e[0] == E1 - 1) + (e[1] == 0 || e[1] == E1 - 1) + (e[2] == 0 || e[2] == E1 - 1);
+    };
+    auto ent_size = [&](int slot) {
+      int e[3];
+      coords(slot, e);
+      return (uint32_t)(((e[0] & 1) ? p - 1 : 1) * ((e[1] & 1) ? p - 1 : 1) * ((e[2] & 1) ? p - 1 : 1));
+    };
+    // face f = 2 axis + side of a surface entity with exactly one boundary coordinate
+    auto face_of = [&](int slot) {
+      int e[3];
+      coords(slot, e);
+      for (int a = 0; a < 3; ++a)
+        if (e[a] == 0 || e[a] == E1 - 1)
+          return 2 * a + (e[a] == 0 ? 0 : 1);
+      return -1;
+    };
+    // 1. the brick across each face, through a vertex in the interior of the face
+    std::vector<uint32_t> partner((size_t)nb * 6, kInvalid);
+    {
+      std::vector<std::pair<uint32_t, uint32_t>> keys; // (first DoF of the vertex, 6 brick + face)
+      keys.reserve((size_t)nb * 6);
+      for (uint32_t b = 0; b < nb; ++b)
+        for (int f = 0; f < 6; ++f)
+          {
+            int e[3] = {2, 2, 2};
+            e[f / 2]  = (f & 1) ? E1 - 1 : 0;
+            const uint32_t v = bh.ent_base[(size_t)b * NE + (e[2] * E1 + e[1]) * E1 + e[0]];
+            if (v != kInvalid)
+              keys.push_back({v & 0x3FFFFFFFu, 6 * b + (uint32_t)f});
+          }
+      std::sort(keys.begin(), keys.end());
+      for (size_t i = 0; i + 1 < keys.size(); ++i)
+        if (keys[i].first == keys[i + 1].first)
+          {
+            if (i + 2 < keys.size() && keys[i + 2].first == keys[i].first)
+              return false; // a face vertex in three bricks: not a brick mesh
+            partner[keys[i].second]     = keys[i + 1].second / 6;
+            partner[keys[i + 1].second] = keys[i].second / 6;
+          }
+    }
+    // 2. classes: two-colouring over the faces (breadth first), or one class
+    std::vector<uint8_t> cls(nb, n_classes == 1 ? 0 : 255);
+    if (n_classes == 2)
+      {
+        std::vector<uint32_t> queue;
+        for (uint32_t seed = 0; seed < nb; ++seed)
+          {
+            if (cls[seed] != 255)
+              continue;
+            cls[seed] = 0;
+            queue.assign(1, seed);
+            for (size_t q = 0; q < queue.size(); ++q)
+              {
+                const uint32_t b = queue[q];
+                for (int f = 0; f < 6; ++f)
+                  {
+                    const uint32_t o = partner[(size_t)b * 6 + f];
+                    if (o == kInvalid)
+                      continue;
+                    if (cls[o] == 255)
+                      {
+                        cls[o] = (uint8_t)(1 - cls[b]);
+                        queue.push_back(o);
+                      }
+                    else if (cls[o] == cls[b])
+                      return false; // not bipartite
+                  }
+              }
+          }
+      }
+    // 3. launch groups: class, interface bricks first on a decomposed mesh
+    std::vector<uint8_t> is_shared;
+    if (n_shared > 0)
+      {
+        is_shared.assign(n_dofs, 0);
+        for (uint32_t i = 0; i < n_shared; ++i)
+          is_shared[shared[i]] = 1;
+      }
+    std::vector<uint8_t> group(cls);
+    int                  n_groups = n_classes;
+    if (split_interface && n_shared > 0)
+      {
+        uint32_t n_iface = 0;
+        for (uint32_t b = 0; b < nb; ++b)
+          {
+            bool iface = false;
+            for (int slot = 0; slot < NE && !iface; ++slot)
+              {
+                const uint32_t v = bh.ent_base[(size_t)b * NE + slot];
+                iface            = v != kInvalid && is_shared[v & 0x3FFFFFFFu];
+              }
+            if (!iface)
+              group[b] = (uint8_t)(cls[b] + n_classes);
+            else
+              ++n_iface;
+          }
+        if (n_iface > 0 && n_iface < nb)
+          {
+            n_groups           = 2 * n_classes;
+            out.n_iface_groups = n_classes;
+          }
+        else
+          group = cls;
+      }
+    out.n_groups = n_groups;
+    out.group_start.assign(n_groups + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b)
+      out.group_start[group[b] + 1]++;
+    for (int g = 0; g < n_groups; ++g)
+      out.group_start[g + 1] += out.group_start[g];
+    std::vector<uint32_t> order(nb);
+    {
+      std::vector<uint32_t> pos(out.group_start.begin(), out.group_start.end() - 1);
+      for (uint32_t b = 0; b < nb; ++b)
+        order[pos[group[b]]++] = b;
+    }
+    // 4. private entities and their offsets inside a block, in item order (consecutive items of the
+    //    write-out then store to consecutive addresses)
+    out.surf_off.assign(NE, kInvalid);
+    for (const uint32_t m : item_map)
+      {
+        const int slot = (int)(m & 1023u);
+        const int nbd  = n_boundary(slot);
+        if ((n_classes == 1 ? nbd >= 1 : nbd >= 2) && out.surf_off[slot] == kInvalid && ent_size(slot) > 0)
+          {
+            out.surf_off[slot] = out.n_surf;
+            out.n_surf += ent_size(slot);
+          }
+      }
+    // 5. entity table in group order with the flags of this schedule
+    out.ent.assign((size_t)nb * NE, kInvalid);
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < nb; ++i)
+      {
+        const uint32_t b = order[i];
+        for (int slot = 0; slot < NE; ++slot)
+          {
+            const uint32_t v = bh.ent_base[(size_t)b * NE + slot];
+            if (v == kInvalid)
+              continue;
+            const uint32_t idx = v & 0x3FFFFFFFu;
+            const int      nbd = n_boundary(slot);
+            uint32_t       flags = 3u; // interior: FIRST | LAST
+            if (out.surf_off[slot] != kInvalid)
+              flags = 1u; // private
+            else if (nbd == 1)
+              {
+                const uint32_t o = partner[(size_t)b * 6 + face_of(slot)];
+                if (o != kInvalid)
+                  flags = group[b] < group[o] ? 1u : 2u;
+              }
+            if (!is_shared.empty() && is_shared[idx])
+              flags &= ~2u; // complete only after the exchange
+            out.ent[(size_t)i * NE + slot] = idx | (flags << 30);
+          }
+      }
+    // 6. private DoFs -> positions of their partial sums, ascending (the fixed order of the sum);
+    //    counting sort by DoF; the DoFs shared with other ranks first
+    if (out.n_surf > 0)
+      {
+        auto for_each_ref = [&](auto &&f) {
+          for (uint32_t i = 0; i < nb; ++i)
+            for (int slot = 0; slot < NE; ++slot)
+              {
+                const uint32_t w = out.ent[(size_t)i * NE + slot];
+                if (out.surf_off[slot] == kInvalid || w == kInvalid)
+                  continue;
+                for (uint32_t o = 0; o < ent_size(slot); ++o)
+                  f((w & 0x3FFFFFFFu) + o, i * out.n_surf + out.surf_off[slot] + o);
+              }
+        };
+        std::vector<uint32_t> cnt((size_t)n_dofs + 1, 0);
+        for_each_ref([&](uint32_t dof, uint32_t) { ++cnt[dof + 1]; });
+        std::vector<uint32_t> slot_of((size_t)n_dofs, kInvalid);
+        out.surf_start.assign(1, 0);
+        for (int pass = 0; pass < 2; ++pass)
+          {
+            for (uint32_t dof = 0; dof < n_dofs; ++dof)
+              if (cnt[dof + 1] > 0 && (!is_shared.empty() && is_shared[dof]) == (pass == 0))
+                {
+                  slot_of[dof] = (uint32_t)out.surf_dof.size();
+                  out.surf_dof.push_back(dof);
+                  out.surf_start.push_back(out.surf_start.back() + cnt[dof + 1]);
+                }
+            if (pass == 0)
+              out.n_surf_shared = (uint32_t)out.surf_dof.size();
+          }
+        out.surf_pos.assign((size_t)out.surf_start.back(), 0);
+        std::vector<uint32_t> fill(out.surf_start.begin(), out.surf_start.end() - 1);
+        for_each_ref([&](uint32_t dof, uint32_t pos) { out.surf_pos[fill[slot_of[dof]]++] = pos; });
+      }
+    else
+      out.surf_start.assign(1, 0);
+    return true;
+  }
+
   void build_item_map(int p, std::vector<uint32_t> &map)
   {
     const int NB = p <= 4 ? 4 : 2, G = NB * p + 1, E1 = 2 * NB + 1;

@@ -27,6 +27,25 @@ namespace mgx
                     const uint8_t *colour_hint, const uint32_t *shared, uint32_t n_shared, bool split_interface,
                     BrickHost &out, std::string &why);
 
+  // Reduced-colour schedule of the macro-element kernel (mgx_macro.hip, FREE; FreeSchedule in
+  // mgx_internal.hpp).  n_classes = 1: one launch group, every entity on a brick surface is private;
+  // n_classes = 2: bricks two-coloured over their faces (false if the face graph is not bipartite),
+  // the face entities keep FIRST / LAST flags in the order of the launch groups, the entities on brick
+  // edges and corners are private.  `bh` as returned by build_bricks (entity words without flags);
+  // positions below refer to the group-sorted order of THIS schedule.
+  struct FreeHost
+  {
+    int                   n_groups = 0, n_iface_groups = 0;
+    std::vector<uint32_t> group_start;            // [n_groups + 1]
+    std::vector<uint32_t> ent;                    // [n_bricks * n_entities]: first DoF | FIRST << 30 | LAST << 31, or invalid
+    std::vector<uint32_t> surf_off;               // [n_entities]: offset of a private entity inside a block, or invalid
+    uint32_t              n_surf = 0;             // private values per brick
+    std::vector<uint32_t> surf_dof, surf_start, surf_pos; // private DoFs (shared with other ranks first) and their blocks' positions
+    uint32_t              n_surf_shared = 0;
+  };
+  bool build_free_schedule(int p, const BrickHost &bh, uint32_t n_dofs, const uint32_t *shared, uint32_t n_shared,
+                           bool split_interface, int n_classes, const std::vector<uint32_t> &item_map, FreeHost &out);
+
   // Item table of the macro-element kernel (mgx_macro.hip), one per degree: the (NB p + 1)^3 points
   // of a brick in the order they are gathered and written out.  Entities are taken cell after cell
   // in Morton order ({hex, x-face, y-face, xy-line, z-face, xz-line, yz-line, vertex} on the high

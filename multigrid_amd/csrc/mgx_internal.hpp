@@ -42,6 +42,8 @@ namespace mgx
     uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour
     bool     exchange_unfused = false; // MGX_EXCHANGE_UNFUSED one pack / unpack launch per neighbour
     uint32_t cell_colour_min  = 4096;  // MGX_CELL_COLOUR_MIN  general-coefficient levels from this many cells run colour by colour
+    uint32_t free_max_bricks  = 16384; // MGX_FREE_MAX_BRICKS  levels with at most this many bricks run the plain / residual / Chebyshev forms of the brick loop on a reduced-colour schedule (mgx_macro.hip, FREE) instead of eight colour launches
+    uint32_t free_one_max     = 1024;  // MGX_FREE_ONE_MAX     ... with one class (one launch) up to this many bricks, two classes beyond
     bool     no_graph         = false; // MGX_NO_GRAPH         no HIP-graph replay of the coarse levels
     uint32_t graph_max_dofs   = 600000; // MGX_GRAPH_MAX_DOFS  largest level inside the replayed graph
     bool     rccl_selftest    = false; // MGX_RCCL_SELFTEST    one-rank communicator may name itself as neighbour
@@ -75,6 +77,27 @@ namespace mgx
     EOMat<T> mass, lapl;
   };
 
+  // Reduced-colour schedule of the macro-element kernel (mgx_macro.hip, FREE; built by
+  // build_free_schedule, mgx_bricks.cpp): one or two classes of bricks instead of eight colours.  The
+  // entities bricks of one class share are PRIVATE: every brick stores their partial sums in a block
+  // of its own, priv[brick][n_surf], and launch_surf_finish adds the blocks up per DoF (entries
+  // surf_pos[surf_start[i] .. surf_start[i+1]) for DoF surf_dof[i], ascending) and applies the
+  // post-operation.  The first n_surf_shared DoFs of that list are shared with other ranks: their
+  // sum goes to the carrier vector and is completed after the exchange.
+  struct FreeSchedule
+  {
+    int       n_classes = 0;                    // 1 or 2
+    int       n_groups = 0, n_iface_groups = 0; // launch groups (classes, interface bricks first if split)
+    uint32_t  group_start[9] = {0};
+    uint32_t *ent         = nullptr; // device [n_bricks * entities]: entity table in group order, flags of this schedule
+    uint32_t *surf_off    = nullptr; // device [entities per brick]: offset of a private entity in a block, kInvalid: not private
+    uint32_t  n_surf      = 0;       // values per block
+    void     *priv        = nullptr; // device, number type
+    uint32_t *surf_dof    = nullptr, *surf_start = nullptr, *surf_pos = nullptr;
+    uint32_t  n_surf_dofs = 0, n_surf_shared = 0;
+    bool      available() const { return ent != nullptr; }
+  };
+
   // Brick schedule of a level (mgx_brick.hip): 64-cell bricks sorted by colour, one launch per
   // colour; per brick the first DoF of each of its 9^3 mesh entities and the FIRST/LAST flags.
   struct BrickData
@@ -88,6 +111,7 @@ namespace mgx
     uint32_t *item_map  = nullptr; // device [(NB p + 1)^3]: write-out order of the macro-element kernel
     std::vector<uint32_t> order; // host: colour-sorted position -> brick index in cell order
     bool      available() const { return n_bricks > 0; }
+    FreeSchedule fr; // reduced-colour schedule of the plain / residual / Chebyshev forms (may be absent)
   };
   constexpr int kBrickEntities = 729;
   constexpr int kMaxColours    = 32;
@@ -195,15 +219,23 @@ namespace mgx
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr,
                          double f0 = 0., void *coarse = nullptr, const uint32_t *coarse_blocks = nullptr,
-                         int group_begin = 0, int group_end = -1);
+                         int group_begin = 0, int group_end = -1, bool free_schedule = false);
+  // free_schedule (modes 0..6, op.bricks.fr.available()): the launch groups are those of the reduced-colour
+  // schedule; the caller completes the private DoFs with launch_surf_finish: DoFs [first, first + count)
+  // of op.bricks.fr.surf_dof; those below n_surf_shared: carrier[d] = sum only
+  void launch_surf_finish(hipStream_t s, const OperatorData &op, int mode, uint32_t first, uint32_t count, void *carrier,
+                          const void *x, void *out, const void *a, const void *dinv, const void *old, double f1, double f2,
+                          double f0);
   // macro-element form of the separable brick loop (mgx_macro.hip), one translation unit per number
   // type; false: mode / degree not covered (the caller falls back to the cell-by-cell form)
   bool launch_macro_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                              const void *b, void *out, void *partial, double f1, double f2, const void *old,
-                             double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
+                             double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end,
+                             bool free_schedule);
   bool launch_macro_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                              const void *b, void *out, void *partial, double f1, double f2, const void *old,
-                             double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
+                             double f0, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end,
+                             bool free_schedule);
   // fused PCG step on a brick-scheduled level (mgx_macro.hip, kCgUpdate)
   bool launch_macro_cg_update_f64(hipStream_t s, const OperatorData &op, double alpha, double beta, const void *r, void *q,
                                   void *p, void *x, void *carrier, double *partials, uint32_t capacity,

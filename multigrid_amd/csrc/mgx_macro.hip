@@ -115,7 +115,7 @@ namespace mgx
     static constexpr int JP      = (NPAIR + THREADS - 1) / THREADS;   // pairs per thread
     static constexpr int JS      = (NSINGLE + THREADS - 1) / THREADS; // singles per thread
     static constexpr int IT      = 2 * JP + JS;                       // value slots per thread
-    static constexpr int TSZ     = (2 * NE * 4 + (int)sizeof(T) - 1) / (int)sizeof(T); // two entity tables, in T's
+    static constexpr int TSZ     = (3 * NE * 4 + (int)sizeof(T) - 1) / (int)sizeof(T); // two entity tables + the surface table, in T's
     static constexpr int ASZ     = NPTS > TSZ ? NPTS : TSZ;                            // LDS array size
     static constexpr int LDS     = 2 * ASZ * (int)sizeof(T);
     static constexpr int WG_LDS  = 163840 / LDS;
@@ -292,7 +292,7 @@ namespace mgx
   template <typename T>
   struct PostRsrc
   {
-    rsrc_t a, b, old, out, partial, src, srcw, xw;
+    rsrc_t a, b, old, out, partial, src, srcw, xw, priv;
   };
 
   // The fused post-operation on one assembled value (what the reference passes as
@@ -371,7 +371,22 @@ namespace mgx
   // stored vector when the diagonal is computed, macro_diag_table below); every thread holds the
   // values of its items in registers for all bricks.  One vector stream less in the fused
   // Chebyshev iterations (4 instead of 5 accesses per DoF).
-  template <int P, typename T, int MODE, bool DTAB>
+  //
+  // FREE (reduced-colour schedules of the plain / residual / Chebyshev forms, BrickData::fr): the eight
+  // colour launches exist because a brick hands the partial sums of its surface points to its
+  // neighbours through the carrier vector (FIRST / LAST read-modify-writes), and two bricks that
+  // share a point must not run at the same time.  Here the entities named by post.surf_off are
+  // PRIVATE instead: the brick stores their partial sums in a block of its own (post.priv =
+  // [brick][n_surf], entity by entity in item order) and surf_finish (mgx_vector.hip) adds the blocks
+  // up per DoF in a fixed order and applies the post-operation there.  Two schedules use it:
+  //   one class : every surface entity is private -- ONE launch for the whole level (levels whose
+  //               colour launches hold a brick per workgroup or less: nothing to pipeline, every
+  //               launch as long as a brick's whole latency chain);
+  //   two classes (parity of the brick position): only the entities on brick edges and corners,
+  //               which bricks of the same class share, are private (1.1 % of the DoFs at p = 4); the
+  //               faces keep the FIRST / LAST hand-over through the carrier between the two launches.
+  // The entity table of these schedules (its own brick order and flags) comes with the launch.
+  template <int P, typename T, int MODE, bool DTAB, bool FREE = false>
   __global__ void __launch_bounds__((MCfg<P, T>::THREADS), (MCfg<P, T>::MINW))
     brick_macro_kernel(const T *__restrict__ src, uint32_t brick_first, uint32_t brick_count,
                        const uint32_t *__restrict__ ent_base, const uint32_t *__restrict__ item_map,
@@ -445,11 +460,22 @@ namespace mgx
     const PostRsrc<T> R{make_rsrc(post.a, vec_bytes),   make_rsrc(post.b, vec_bytes),       make_rsrc(post.old, vec_bytes),
                         make_rsrc(post.out, vec_bytes), make_rsrc(post.partial, vec_bytes), rsrc,
                         make_rsrc((MODE == kCgUpdate || MODE == kChebFirstProlong) ? post.src_w : post.out, vec_bytes),
-                        make_rsrc(MODE == kCgUpdate ? post.x_w : post.out, vec_bytes)};
+                        make_rsrc(MODE == kCgUpdate ? post.x_w : post.out, vec_bytes),
+                        make_rsrc(FREE ? (const void *)post.priv : (const void *)post.out, FREE ? post.priv_bytes : vec_bytes)};
     double cg[4] = {0., 0., 0., 0.}; // kCgUpdate: q.p, r.r, q.r, q.q over the DoFs this workgroup completes
     const EOMat<T>   &M = B->mass, &K = B->lapl;
 
     uint32_t ec[NEW], en[NEW]; // entity table words of the current / the next brick
+    uint32_t sc[FREE ? NEW : 1]; // FREE: the surface table, parked next to the entity tables for the write-out
+    if (FREE)
+      {
+#pragma unroll
+        for (int j = 0; j < NEW; ++j)
+          {
+            const int i      = tid + j * NT;
+            sc[FREE ? j : 0] = post.surf_off[i < C::NE ? i : 0];
+          }
+      }
     auto table_load = [&](uint32_t brick, uint32_t(&e)[NEW]) {
 #pragma unroll
       for (int j = 0; j < NEW; ++j)
@@ -746,6 +772,14 @@ namespace mgx
         table_store(ebase, ec);
         if (has_next)
           table_store(E2, en);
+        const uint32_t *sbase = ebase + 2 * C::NE;
+        if (FREE)
+          {
+#pragma unroll
+            for (int j = 0; j < NEW; ++j)
+              if (tid + j * NT < C::NE)
+                ebase[2 * C::NE + tid + j * NT] = sc[FREE ? j : 0];
+          }
         __syncthreads();
         // (kChebInit gathers two operands per value: too many registers in flight next to the
         // write-out, its gather is issued afterwards)
@@ -766,10 +800,12 @@ namespace mgx
                         NCH    = (NU + kChunk - 1) / kChunk;
           PostOps<T>    ops[2][kChunk];
           uint32_t      iw[2][kChunk]; // entity table word of the unit (kInvalid: nothing to do)
+          uint32_t      pw[2][FREE ? kChunk : 1]; // FREE: byte offset of the unit's private value (interior: out of range)
+          const uint32_t priv0 = FREE ? (brick_first + b) * post.n_surf : 0u;
           // unit u: pair u (u < JP) or single u - JP; v0 = its first value slot
           auto slot0 = [&](int u) { return u < JP ? 2 * u : JP + u; };
           auto ulive = [&](int u) { return u < JP ? live_p(u) : live_s(u - JP); };
-          auto issue = [&](int c, PostOps<T>(&o)[kChunk], uint32_t(&w)[kChunk]) {
+          auto issue = [&](int c, PostOps<T>(&o)[kChunk], uint32_t(&w)[kChunk], uint32_t(&pv)[FREE ? kChunk : 1]) {
             // table lookups of the whole chunk first (one batch of LDS reads), then the loads
 #pragma unroll
             for (int j = 0; j < kChunk; ++j)
@@ -778,6 +814,18 @@ namespace mgx
                 w[j]        = kInvalid;
                 if (u < NU && ulive(u))
                   w[j] = ebase[item_slot(mw[slot0(u)])];
+                if (FREE)
+                  {
+                    // a private entity: FIRST (nothing to add to), never LAST, its value goes to the
+                    // brick's private block; every other entity follows the flags of its table word
+                    const uint32_t so = (u < NU && ulive(u)) ? sbase[item_slot(mw[slot0(u < NU ? u : 0)])] : kInvalid;
+                    const bool     vd = w[j] != kInvalid;
+                    if (vd && so != kInvalid)
+                      w[j] = ent_index(w[j]) | 0x40000000u;
+                    pv[FREE ? j : 0] = (vd && so != kInvalid)
+                                         ? (priv0 + so + item_offset(mw[slot0(u < NU ? u : 0)])) * (uint32_t)sizeof(T)
+                                         : kOob;
+                  }
               }
 #pragma unroll
             for (int j = 0; j < kChunk; ++j)
@@ -789,12 +837,12 @@ namespace mgx
                   post_issue<T, MODE, DTAB, false>(R, w[j], unit_offset(w[j], mw[slot0(u < NU ? u : 0)]), o[j]);
               }
           };
-          issue(0, ops[0], iw[0]);
+          issue(0, ops[0], iw[0], pw[0]);
 #pragma unroll
           for (int c = 0; c < NCH; ++c)
             {
               if (c + 1 < NCH)
-                issue(c + 1, ops[(c + 1) & 1], iw[(c + 1) & 1]);
+                issue(c + 1, ops[(c + 1) & 1], iw[(c + 1) & 1], pw[(c + 1) & 1]);
               __builtin_amdgcn_sched_barrier(0);
               T val[kChunk][2];
 #pragma unroll
@@ -873,7 +921,15 @@ namespace mgx
                           // out-of-range offsets drop the store; whole waves of interior items skip
                           // the carrier store
                           st(R.out, last ? off : kOob);
-                          if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
+                          if (FREE)
+                            {
+                              const uint32_t po = pw[c & 1][FREE ? j : 0];
+                              if (__builtin_amdgcn_ballot_w64(po != kOob) != 0)
+                                st(R.priv, po);
+                              if (__builtin_amdgcn_ballot_w64(vld && !last && po == kOob) != 0)
+                                st(R.partial, (last || po != kOob) ? kOob : off);
+                            }
+                          else if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
                             st(R.partial, last ? kOob : off);
                           if (MODE == kChebFirstProlong) // the corrected x is x_old of the next iteration
                             buf_st(R.srcw, last ? off : kOob, xs[kKeepX ? v0 : 0]);
@@ -953,10 +1009,46 @@ namespace mgx
   }
 
   template <int P, typename T, int MODE>
-  static void macro_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post, int g0, int g1)
+  static void macro_launch_free(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post_in, int g0, int g1)
+  {
+    using C             = MCfg<P, T>;
+    const FreeSchedule &fr = op.bricks.fr;
+    BrickPost<T>        post = post_in;
+    post.priv       = (T *)fr.priv;
+    post.surf_off   = fr.surf_off;
+    post.n_surf     = fr.n_surf;
+    post.priv_bytes = (uint32_t)((size_t)op.bricks.n_bricks * fr.n_surf * sizeof(T));
+    constexpr bool kUsesDiag = is_cheb_mode(MODE);
+    if (kUsesDiag && op.diag_items)
+      post.b = (const T *)op.diag_items;
+    for (int g = g0; g < g1; ++g)
+      {
+        const uint32_t first = fr.group_start[g], count = fr.group_start[g + 1] - first;
+        if (count == 0)
+          continue;
+        const uint32_t grid = std::min<uint32_t>(count, (uint32_t)(op.macro_wg_x16 ? 1 : C::WGS) * macro_cus(op));
+        if (kUsesDiag && op.diag_items)
+          hipLaunchKernelGGL((brick_macro_kernel<P, T, MODE, kUsesDiag, true>), dim3(grid), dim3(C::THREADS), 0, s, src, first,
+                             count, fr.ent, op.bricks.item_map, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
+                             (T)op.coef[2], post, (uint32_t)(op.n_dofs * sizeof(T)));
+        else
+          hipLaunchKernelGGL((brick_macro_kernel<P, T, MODE, false, true>), dim3(grid), dim3(C::THREADS), 0, s, src, first,
+                             count, fr.ent, op.bricks.item_map, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
+                             (T)op.coef[2], post, (uint32_t)(op.n_dofs * sizeof(T)));
+      }
+  }
+
+  template <int P, typename T, int MODE>
+  static void macro_launch(hipStream_t s, const OperatorData &op, const T *src, const BrickPost<T> &post, int g0, int g1,
+                           bool free_schedule = false)
   {
     using C             = MCfg<P, T>;
     const BrickData &bd = op.bricks;
+    if (free_schedule)
+      {
+        if constexpr (MODE <= kChebOldInit)
+          return macro_launch_free<P, T, MODE>(s, op, src, post, g0, g1);
+      }
     for (int c = g0; c < g1; ++c)
       {
         const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
@@ -983,17 +1075,17 @@ namespace mgx
 
   template <int P, typename T>
   static void macro_modes(hipStream_t s, const OperatorData &op, int mode, const T *src, const BrickPost<T> &post, int g0,
-                          int g1)
+                          int g1, bool fr)
   {
     switch (mode)
       {
-        case kPlain: macro_launch<P, T, kPlain>(s, op, src, post, g0, g1); break;
-        case kResidual: macro_launch<P, T, kResidual>(s, op, src, post, g0, g1); break;
-        case kCheb: macro_launch<P, T, kCheb>(s, op, src, post, g0, g1); break;
-        case kChebFirst: macro_launch<P, T, kChebFirst>(s, op, src, post, g0, g1); break;
-        case kChebZeroOld: macro_launch<P, T, kChebZeroOld>(s, op, src, post, g0, g1); break;
-        case kChebInit: macro_launch<P, T, kChebInit>(s, op, src, post, g0, g1); break;
-        case kChebOldInit: macro_launch<P, T, kChebOldInit>(s, op, src, post, g0, g1); break;
+        case kPlain: macro_launch<P, T, kPlain>(s, op, src, post, g0, g1, fr); break;
+        case kResidual: macro_launch<P, T, kResidual>(s, op, src, post, g0, g1, fr); break;
+        case kCheb: macro_launch<P, T, kCheb>(s, op, src, post, g0, g1, fr); break;
+        case kChebFirst: macro_launch<P, T, kChebFirst>(s, op, src, post, g0, g1, fr); break;
+        case kChebZeroOld: macro_launch<P, T, kChebZeroOld>(s, op, src, post, g0, g1, fr); break;
+        case kChebInit: macro_launch<P, T, kChebInit>(s, op, src, post, g0, g1, fr); break;
+        case kChebOldInit: macro_launch<P, T, kChebOldInit>(s, op, src, post, g0, g1, fr); break;
         case kResidualRestrict: macro_launch<P, T, kResidualRestrict>(s, op, src, post, g0, g1); break;
         case kChebFirstProlong: macro_launch<P, T, kChebFirstProlong>(s, op, src, post, g0, g1); break;
         default: break;
@@ -1147,13 +1239,16 @@ namespace mgx
   bool MGX_CAT(launch_macro_loop_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, int mode, const void *src,
                                                      const void *a, const void *b, void *out, void *partial,
                                                      double f1, double f2, const void *old, double f0, void *coarse,
-                                                     const uint32_t *coarse_blocks, int g0, int g1)
+                                                     const uint32_t *coarse_blocks, int g0, int g1, bool free_schedule)
   {
     using T = MGX_MACRO_T;
+    const bool fr = free_schedule && op.bricks.fr.available() && mode <= kChebOldInit && !MGX_MACRO_PAIRS;
+    if (free_schedule && !fr)
+      return false;
     if (mode < kPlain || (mode > kResidualRestrict && mode != kChebFirstProlong) || MGX_MACRO_PAIRS * (mode == kChebFirstProlong) ||
         (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
       return false;
-    BrickPost<T> post;
+    BrickPost<T> post{};
     post.a             = (const T *)a;
     post.b             = (const T *)b;
     post.old           = (const T *)old;
@@ -1168,17 +1263,17 @@ namespace mgx
     switch (op.p)
       {
 #ifdef MGX_MACRO_ONLY_P
-        case MGX_MACRO_ONLY_P: macro_modes<MGX_MACRO_ONLY_P, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case MGX_MACRO_ONLY_P: macro_modes<MGX_MACRO_ONLY_P, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
 #else
-        case 1: macro_modes<1, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 2: macro_modes<2, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 3: macro_modes<3, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 4: macro_modes<4, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 5: macro_modes<5, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 6: macro_modes<6, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 7: macro_modes<7, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 8: macro_modes<8, T>(s, op, mode, (const T *)src, post, g0, g1); break;
-        case 9: macro_modes<9, T>(s, op, mode, (const T *)src, post, g0, g1); break;
+        case 1: macro_modes<1, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 2: macro_modes<2, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 3: macro_modes<3, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 4: macro_modes<4, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 5: macro_modes<5, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 6: macro_modes<6, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 7: macro_modes<7, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 8: macro_modes<8, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
+        case 9: macro_modes<9, T>(s, op, mode, (const T *)src, post, g0, g1, fr); break;
 #endif
         default: return false;
       }

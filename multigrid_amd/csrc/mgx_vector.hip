@@ -146,6 +146,49 @@ namespace mgx
     }
   }
 
+  // Colour-free brick schedule (mgx_macro.hip, FREE): the DoFs on brick surfaces.  Entry i of the list:
+  // DoF sdof[i], whose value of A x is the sum of the bricks' private values priv[spos[k]],
+  // k in [sstart[i], sstart[i+1]), added in that (fixed) order.  Entries below n_carrier_only are shared
+  // with other ranks: carrier[d] = sum and nothing else (completed after the exchange).  Otherwise the
+  // post-operation of the brick loop (BrickMode, post_finish in mgx_macro.hip) on the completed value.
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_surf_finish(int mode, const T *__restrict__ priv, const uint32_t *__restrict__ sdof,
+                  const uint32_t *__restrict__ sstart, const uint32_t *__restrict__ spos, uint32_t first, uint32_t count,
+                  uint32_t n_carrier_only, T *carrier, const T *x, T *out, const T *__restrict__ a,
+                  const T *__restrict__ dinv, const T *old, T f1, T f2, T f0)
+  {
+    GRID_STRIDE(i0, count)
+    {
+      const uint32_t i = first + (uint32_t)i0, d = sdof[i];
+      T              sum = T(0);
+      for (uint32_t k = sstart[i]; k < sstart[i + 1]; ++k)
+        sum += priv[spos[k]];
+      if (i < n_carrier_only)
+        {
+          carrier[d] = sum;
+          continue;
+        }
+      if (mode == 0)
+        out[d] = sum;
+      else if (mode == 1)
+        out[d] = a[d] - sum;
+      else
+        {
+          const T bv = dinv[d], av = a[d];
+          const T xi = mode == 5 ? f0 * bv * av : x[d];
+          T       xn = xi + f2 * bv * (av - sum);
+          if (mode == 2)
+            xn += f1 * (xi - old[d]);
+          else if (mode == 6)
+            xn += f1 * (xi - f0 * bv * av);
+          else if (mode == 4 || mode == 5)
+            xn += f1 * xi;
+          out[d] = xn;
+        }
+    }
+  }
+
   // ---- interface exchange (domain decomposition) ----
   template <typename T>
   __global__ void __launch_bounds__(256)
@@ -467,6 +510,23 @@ namespace mgx
     BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_constrained<T>), stream_grid(count), dim3(256), 0, s, mode,
                                          (const T *)x, (T *)out, (const T *)b, (const T *)dinv, (T)f1, (T)f2, list,
                                          count, (const T *)ax, (const T *)old, (T)f0));
+  }
+
+  void launch_surf_finish(hipStream_t s, const OperatorData &op, int mode, uint32_t first, uint32_t count, void *carrier,
+                          const void *x, void *out, const void *a, const void *dinv, const void *old, double f1, double f2,
+                          double f0)
+  {
+    if (count == 0)
+      return;
+    const FreeSchedule &bd = op.bricks.fr;
+    if (!old)
+      old = out;
+    if (!x)
+      x = a; // mode 5 never reads it
+    BY_NUMBER(op.number, hipLaunchKernelGGL((k_surf_finish<T>), stream_grid(count), dim3(256), 0, s, mode, (const T *)bd.priv,
+                                            bd.surf_dof, bd.surf_start, bd.surf_pos, first, count, bd.n_surf_shared,
+                                            (T *)carrier, (const T *)x, (T *)out, (const T *)a, (const T *)dinv,
+                                            (const T *)old, (T)f1, (T)f2, (T)f0));
   }
 
   // dst[i] = 0 for i < n_head, dst[i] = src[i] behind: the zeroing before a cell loop that scatters
