@@ -48,10 +48,14 @@ def parse():
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--smoother-degree", type=int, default=3)
     ap.add_argument("--vcycle-number", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--smoother-polynomial", choices=["reference", "first_kind", "fourth_kind"], default="reference",
-                    help="reference: what the reference instantiates for the V-cycle number type -- fourth_kind for an "
-                         "fp64 V-cycle (MultigridSolver<dim,p,double,double>, multigrid_solver.h:951-952), first_kind "
-                         "for fp32 (:277-278); the work per V-cycle is the same")
+    ap.add_argument("--smoother-polynomial", choices=["first_kind", "fourth_kind", "reference"], default="first_kind",
+                    help="first_kind: the smoother SURVEY.md 8d defines the metric with (multigrid_solver.h:277-278, the "
+                         "README run); reference: what the reference instantiates for the V-cycle number type -- "
+                         "fourth_kind for MultigridSolver<dim,p,double,double> (:951-952), first_kind for fp32; the work "
+                         "per V-cycle is the same")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the end-to-end check after the timed region (PCG iteration count and L2 error of the "
+                         "manufactured problem, README.md:135-159)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -59,7 +63,9 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check without a GPU: ranks rendezvous (gloo), build their part of the mesh on the host "
                          "and exchange one interface vector; prints the JSON line with value null")
-    ap.add_argument("--cpu-cells", type=int, default=64, help="finest level of the CPU baseline sample")
+    ap.add_argument("--cpu-cells", type=int, default=0,
+                    help="finest level of the CPU baseline sample (0: the bench mesh itself if the host has the memory "
+                         "and the cores for it, else 64)")
     return ap.parse_args()
 
 
@@ -78,30 +84,68 @@ def cpu_baseline(args):
     the same workload: same element/algorithm on a smaller finest level (DoFs/s of a matrix-free
     operator is size independent once out of cache)."""
     from oracle import Oracle
-    ns, nr = split_size(args.cpu_cells)
+    cpu_cells = args.cpu_cells
+    if cpu_cells == 0:
+        # the bench mesh itself (about 25 fp64 vectors of 1.08 GB at 128^3 cells, p = 4) where the host can hold it
+        # and has the cores to finish the sample within a minute; otherwise one level coarser
+        avail = 0
+        try:
+            avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] * 1024
+        except (OSError, IndexError, ValueError):
+            pass
+        big = args.cells <= 128 and avail > 160e9 and (os.cpu_count() or 1) >= 16
+        cpu_cells = args.cells if big else min(args.cells, 64)
+    ns, nr = split_size(cpu_cells)
     t0 = time.time()
     orc = Oracle(args.degree, ns, nr, degree=args.smoother_degree, n_cycles=1, vfloat=False)
     n = orc.n_dofs(orc.max_level)
     orc.time_vmult(orc.max_level, 1)  # warm-up
-    n_mv = 40
+    n_mv = 40 if cpu_cells <= 64 else 10
     t_mv = orc.time_vmult(orc.max_level, n_mv) / n_mv
     orc.time_vcycle(1)
-    n_vc = 16
+    n_vc = 16 if cpu_cells <= 64 else 3
     t_vc = orc.time_vcycle(n_vc) / n_vc
     threads = orc.num_threads()
     orc.close()
     return {
         "value": n / (t_mv + t_vc), "unit": "DoFs/s", "cores": threads, "kind": "port",
         "sample": "FE_Q(%d) %d^3 cells (%d DoFs): %d fp64 matvecs + %d fp64 V-cycles of the oracle "
-                  "(oracle/mg_oracle.c, OpenMP), %.1f s incl. setup" % (args.degree, args.cpu_cells, n, n_mv, n_vc,
-                                                                        time.time() - t0),
+                  "(oracle/mg_oracle.c: OpenMP over cells, SIMD over batches of 8 cells), %.1f s incl. setup"
+                  % (args.degree, cpu_cells, n, n_mv, n_vc, time.time() - t0),
         "matvec_dofs_per_s": n / t_mv, "vcycle_dofs_per_s": n / t_vc,
         # per core, next to the only genuine deal.II figures there are (README.md:127, 12 Broadwell cores,
-        # AVX2-vectorised over cells; the oracle is a scalar restatement, not a tuned CPU code)
+        # AVX2-vectorised over cells with even-odd sweeps; the oracle batches 8 cells per SIMD lane group with dense sweeps)
         "matvec_dofs_per_s_per_core": n / t_mv / max(1, threads),
         "reference_readme_12c_broadwell": {"matvec_dofs_per_s": 8.74e8, "matvec_dofs_per_s_per_core": 8.74e8 / 12,
                                            "vcycle_mixed_precision_dofs_per_s": 9.7e7},
     }
+
+
+# README.md:135-159 (mixed precision, 2 V-cycles per level, deal.II 9.1): cells per direction -> (PCG iterations,
+# L2 error after PCG) of poisson_cube at p = 4; the iteration count also holds for the fp64 V-cycle
+README_P4 = {8: (8, 3.822e-4), 16: (8, 1.319e-5), 32: (8, 4.220e-7), 64: (8, 1.327e-8), 128: (8, 4.207e-10)}
+
+
+def verify(args, solver, cube, world, decomposed, transport, native):
+    """End-to-end check of the run that was just timed (in particular of a multi-GPU run, whose first bytes over
+    xGMI move inside this script): the V-cycle-preconditioned CG of the program (multigrid_solver.h:483-493) on
+    the manufactured problem must converge in the README's number of iterations to the README's L2 error.  Every
+    rank runs it (the solve is collective); a wrong answer makes the run fail."""
+    t0 = time.time()
+    its, red = solver.solve_cg()
+    hist = solver.cg_history()
+    l2 = solver.compute_l2_error()
+    strong = not decomposed or args.scaling == "strong"
+    expect = README_P4.get(args.cells) if (args.degree == 4 and strong) else None
+    ok = bool(its <= 12 and hist[-1] <= 1e-9 * hist[0] and all(hist[i + 1] < hist[i] for i in range(len(hist) - 1)))
+    if expect:
+        ok = ok and its == expect[0] and abs(l2 - expect[1]) <= 0.03 * expect[1]
+    res = {"cg_its": its, "cg_reduction_rate": red, "l2_error": l2, "ok": ok,
+           "expected": {"cg_its": expect[0], "l2_error": expect[1], "source": "README.md:135-159"} if expect else None,
+           "rccl_ranks": world if decomposed else 1, "transport": transport, "seconds": time.time() - t0}
+    if not ok:
+        sys.stderr.write("bench.py: verification FAILED: %s\n" % json.dumps(res))
+    return res
 
 
 def spawn(args):
@@ -129,10 +173,13 @@ def spawn(args):
     import time
     failed_at, out = None, None
     while True:
-        try:
-            out, _ = procs[0].communicate(timeout=1.0)  # drains the pipe while waiting; a timed-out call loses nothing
-        except subprocess.TimeoutExpired:
-            pass
+        if procs[0].poll() is None or out is None:
+            try:
+                out, _ = procs[0].communicate(timeout=1.0)  # drains the pipe while waiting; a timed-out call loses nothing
+            except subprocess.TimeoutExpired:
+                pass
+        else:
+            time.sleep(0.25)  # rank 0 is done: wait for the others without spinning
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
             break
@@ -195,6 +242,11 @@ def dry_run(args, rank, world, dist):
         print(json.dumps({"metric": "DoFs/s for Laplace matvec + V-cycle, poisson_cube p=%d fp64" % args.degree,
                           "value": None, "unit": "DoFs/s", "n_gpus": world, "dry_run": True, "exchange_ok": ok,
                           "scaling": args.scaling if world > 1 else "weak",
+                          # what the real run checks after its timed region (verify()), unless --no-verify
+                          "verify": None if args.no_verify else
+                          {"expected": ({"cg_its": README_P4[args.cells][0], "l2_error": README_P4[args.cells][1]}
+                                        if args.degree == 4 and args.cells in README_P4 and
+                                        (world == 1 or args.scaling == "strong") else None), "ok": None},
                           "config": {"global_dofs": int(g.prod()), "n_dofs_per_gpu": cube.n_dofs(l),
                                      "process_grid": list(procs)}}))
     cube.close()
@@ -301,8 +353,7 @@ def main():
         step()
     # ---- the timed region: exactly K steps, bracketed by barrier + synchronize ----
     A.set_profiled(True)
-    if vnum == mg.F64:
-        solver.matrix(lmax).set_profiled(True)
+    solver.matrix(lmax).set_profiled(True)
     ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
@@ -310,7 +361,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {form: ctx.profile_read(form) for form in range(8)}
+    prof = {form: ctx.profile_read(form) for form in range(10)}
     ctx.profile_enable(False)
     if dist is not None:
         import torch
@@ -341,9 +392,13 @@ def main():
     # matvec_dg_cheby/program.cc:178); pre-smoothing from a zero guess: forms 5 and 6, which
     # recompute x_1 = D^-1 b / theta instead of storing it.  Form 2 has the most launches and the
     # most traffic.  One application = n_colours launches, each over n_dofs / n_colours DoFs.
-    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0, 5: 24.0, 6: 32.0, 7: 18.0}
+    # form 9 (first post-smoothing step with the prolongation fused in): x, b and 1/8 coarse value read, the
+    # corrected x and x_new written = 33 B/DoF
+    ALG = {0: 16.0, 1: 24.0, 2: 40.0, 3: 32.0, 4: 32.0, 5: 24.0, 6: 32.0, 7: 18.0, 9: 33.0}
     NAMES = {0: "kPlain", 1: "kResidual", 2: "kCheb", 3: "kChebFirst", 4: "kChebZeroOld", 5: "kChebInit",
-             6: "kChebOldInit", 7: "kResidualRestrict"}
+             6: "kChebOldInit", 7: "kResidualRestrict", 9: "kChebFirstProlong"}
+    if vnum != mg.F64:
+        ALG = {k: (v / 2 if k != 0 else v) for k, v in ALG.items()}  # the V-cycle forms run in fp32, the matvec in fp64
 
     def roof(form):
         launches, ms = prof[form]
@@ -368,8 +423,8 @@ def main():
                 traffic = k["traffic_bytes_per_launch"]
         per_launch_bytes = ALG[form] * n_dofs / n_col
         ach = per_launch_bytes / (avg * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "mgx::brick_macro_kernel<%d,double,%s> (finest level, per colour launch)"
-                % (args.degree, NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"bound": "hbm", "kernel": "mgx::brick_macro_kernel<%d,%s,%s> (finest level, per colour launch)"
+                % (args.degree, "double" if (vnum == mg.F64 or form == 0) else "float", NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 "
                                    "per the gfx950 correction; same kernel sources as this build)" % TRAFFIC_FILE)
@@ -408,18 +463,33 @@ def main():
                    "transport": transport if decomposed else None},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
-        "roofline": roof(2) if vnum == mg.F64 else roof(0),
+        "roofline": roof(2) or roof(0),
         "roofline_matvec": roof(0),
+        # the other finest-level forms of the step (HIP events around every application, as above)
+        "roofline_forms": {NAMES[f]: {k: r[k] for k in ("achieved", "frac", "avg_launch_ms", "launches",
+                                                         "algorithmic_bytes_per_dof", "traffic")}
+                           for f in (1, 3, 5, 6, 7, 9) for r in [roof(f)] if r},
+        # the V-cycle as a whole against the fully fused model of SURVEY.md 8d: (10 n + 4.25) accesses per level DoF
+        # x 8/7 (level sum) = 313 B per fine DoF at n = 3 in fp64
+        "roofline_vcycle": (lambda b: {"bound": "hbm", "algorithmic_bytes_per_fine_dof": b,
+                                       "achieved": b * n_dofs / t_vc / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": b * n_dofs / t_vc / 1e9 / HBM_PEAK_GBS})(
+            (10.0 * args.smoother_degree + 4.25) * (8.0 if vnum == mg.F64 else 4.0) * 8.0 / 7.0),
     }
+    if not args.no_verify:
+        out["verify"] = verify(args, solver, cube, world, decomposed, transport, native)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out))
+    failed = "verify" in out and not out["verify"]["ok"]
     solver.close()
     cube.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: the verification solve gave a wrong answer (see the verify object)")
 
 
 if __name__ == "__main__":

@@ -30,6 +30,16 @@ def test_gpus_flag_launches_ranks(n, scaling, grid):
     assert line["config"]["global_dofs"] == (cells[0] * 4 + 1) * (cells[1] * 4 + 1) * (cells[2] * 4 + 1)
     if scaling == "strong":  # the ranks split one mesh: less than the whole on each
         assert line["config"]["n_dofs_per_gpu"] < line["config"]["global_dofs"]
+    # the real run verifies itself after the timed region (README.md:135-159): on the split mesh the PCG must
+    # take the single-domain iteration count and reach its L2 error; the weak family has no README row
+    want = {"cg_its": 8, "l2_error": 1.319e-5} if scaling == "strong" else None
+    assert line["verify"] == {"expected": want, "ok": None}
+
+
+def test_no_verify_flag():
+    out = run_bench("--gpus", "2", "--dry-run", "--cells", "8", "--no-verify")
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert json.loads(out.stdout.decode().strip().splitlines()[-1])["verify"] is None
 
 
 def test_gpus_flag_must_match_world_size():
