@@ -55,10 +55,26 @@ typedef struct mgx_solver_s   *mgx_solver_t;    /* MultigridSolver<3,p,Number,do
 
 const char *mgx_last_error(void);
 const char *mgx_version(void);
+/* 1 if the library was built with the round-1 cell-by-cell brick kernels (make crosscheck: the
+ * cross-check of the macro-element kernel, context options "cells_form" / "brick_wide_max") */
+int mgx_has_cells_form(void);
 
 /* ---- context: device + stream (replaces MPI_InitFinalize / the implicit host execution
  * context, poisson_cube/program.cc:664) ---- */
 int mgx_context_create(mgx_context_t *ctx, int device);
+/* Options of the context, to be set before the first object is created on it.  The scheduling
+ * thresholds (also read from the environment when the context is created: MGX_BRICK_MIN,
+ * MGX_OVERLAP_MIN_BRICKS, MGX_RESTRICT_COLOUR_MIN, MGX_CELL_COLOUR_MIN, MGX_FREE_MAX_BRICKS,
+ * MGX_FREE_ONE_MAX, MGX_GRAPH_MAX_DOFS; MGX_TRACE) under the names "brick_min", "overlap_min_bricks",
+ * "restrict_colour_min", "cell_colour_min", "free_max_bricks", "free_one_max", "graph_max_dofs",
+ * "trace"; and selectors of numerically equivalent code paths that exist for tests and A/B timings
+ * and are never taken from the environment: "general_kernel", "no_bricks", ("cells_form",
+ * "brick_wide_max": cross-check builds only,) "macro_wg_per_cu_x16", "no_diag_table", "no_fused_init", "no_fused_restrict",
+ * "no_fused_prolong", "force_fused_transfers", "transfer_v1", "restrict_atomic", "exchange_unfused",
+ * "no_graph", "dg_no_overlap".  "rccl_selftest" lets a one-rank communicator name itself as its own
+ * neighbour (emulation of a rank on one GPU; the sums it produces are wrong by construction).
+ * Unknown name: MGX_ERR_INVALID_ARGUMENT. */
+int mgx_context_set_option(mgx_context_t ctx, const char *name, double value);
 int mgx_context_destroy(mgx_context_t ctx);
 int mgx_sync(mgx_context_t ctx);
 /* free and total bytes of the context's device (hipMemGetInfo) */
@@ -158,6 +174,11 @@ int mgx_sadd(mgx_context_t ctx, int number, void *x, double s, double a, const v
 /* x . y and ||x||_2 (Vector::l2_norm multigrid_solver.h:263,444,466; operator* in SolverCG) */
 int mgx_dot(mgx_context_t ctx, int number, const void *x, const void *y, size_t n, double *result);
 int mgx_l2_norm(mgx_context_t ctx, int number, const void *x, size_t n, double *result);
+/* The same reductions with the ownership of the entries stated by the operator the vectors belong to
+ * (on a decomposed mesh mgx_dot / mgx_l2_norm find the operator through the vector length; two levels
+ * with vectors of one length but different interfaces make that ambiguous and are refused there) */
+int mgx_operator_dot(mgx_operator_t op, const void *x, const void *y, double *result);
+int mgx_operator_l2_norm(mgx_operator_t op, const void *x, double *result);
 /* v[idx[i]] = val[i] (host index/value lists): multigrid_solver.h:257-259,408-409,427-428 */
 int mgx_set_entries(mgx_context_t ctx, int number, void *v, const uint32_t *idx_host,
                     const double *val_host, uint32_t count);

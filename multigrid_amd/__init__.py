@@ -179,22 +179,42 @@ class Communicator:
             print("mgx Communicator.alloc failed:", repr(e), file=sys.stderr, flush=True)
             return None
 
+    def _device_tensor(self, ptr, nbytes):
+        """torch view of `nbytes` of device memory at `ptr`: the tensor the alloc callback handed out, or -- for
+        buffers the library owns (the DG ghost exchange sends from hipMalloc'd pack buffers and receives straight
+        into the ghost part of the vector it was given, mgx_dg.hip) -- a zero-copy wrapper of the raw pointer"""
+        import torch
+        t = self._tensors.get(ptr)
+        if t is not None:
+            return t[:nbytes]
+
+        class _Raw:  # __cuda_array_interface__ v2: torch wraps the memory, it does not own it
+            pass
+        raw = _Raw()
+        raw.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(raw, device="cuda")
+
     def _exchange(self, user, plan_id, number, n_neighbors, ranks, counts, send, recv):
         try:
             import torch
             dt = torch.float64 if number == F64 else torch.float32
             es = 8 if number == F64 else 4
             if self.device_transport:
-                ops = self._p2p.get(plan_id)
+                # the operations are cached per plan AND buffer set: one plan serves many vectors when the
+                # library receives in place (DG ghosts), each with its own receive pointers
+                key = (plan_id, tuple(send[k] for k in range(n_neighbors)), tuple(recv[k] for k in range(n_neighbors)))
+                ops = self._p2p.get(key)
                 if ops is None:
                     ops = []
                     for k in range(n_neighbors):
                         cnt = counts[k]
-                        st = self._tensors[send[k]][:cnt * es].view(dt)
-                        rt = self._tensors[recv[k]][:cnt * es].view(dt)
+                        st = self._device_tensor(send[k], cnt * es).view(dt)
+                        rt = self._device_tensor(recv[k], cnt * es).view(dt)
                         ops.append(self.dist.P2POp(self.dist.isend, st, ranks[k]))
                         ops.append(self.dist.P2POp(self.dist.irecv, rt, ranks[k]))
-                    self._p2p[plan_id] = ops
+                    if len(self._p2p) > 256:
+                        self._p2p.clear()
+                    self._p2p[key] = ops
                 if ops:
                     for req in self.dist.batch_isend_irecv(ops):
                         req.wait()
@@ -248,12 +268,18 @@ _DT = {F32: np.float32, F64: np.float64}
 class Context:
     """HIP device + stream (mgx_context_t)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, options=None):
+        """options: {name: value} for mgx_context_set_option (code-path selectors and thresholds; include/mgx.h)"""
         self.lib = _lib.load()
         h = C.c_void_p()
         check(self.lib.mgx_context_create(C.byref(h), device))
         self.h = h
         self.device = device
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        check(self.lib.mgx_context_set_option(self.h, name.encode(), float(value)))
 
     def sync(self):
         check(self.lib.mgx_sync(self.h))

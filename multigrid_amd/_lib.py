@@ -94,6 +94,8 @@ SIGNATURES = {
     "mgx_last_error": (C.c_char_p, []),
     "mgx_version": (C.c_char_p, []),
     "mgx_context_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "mgx_context_set_option": (C.c_int, [vp, C.c_char_p, C.c_double]),
+    "mgx_has_cells_form": (C.c_int, []),
     "mgx_context_destroy": (C.c_int, [vp]),
     "mgx_sync": (C.c_int, [vp]),
     "mgx_device_memory_info": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -118,6 +120,8 @@ SIGNATURES = {
     "mgx_sadd": (C.c_int, [vp, C.c_int, vp, C.c_double, C.c_double, vp, C.c_size_t]),
     "mgx_dot": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, f64p]),
     "mgx_l2_norm": (C.c_int, [vp, C.c_int, vp, C.c_size_t, f64p]),
+    "mgx_operator_dot": (C.c_int, [vp, vp, vp, f64p]),
+    "mgx_operator_l2_norm": (C.c_int, [vp, vp, f64p]),
     "mgx_set_entries": (C.c_int, [vp, C.c_int, vp, u32p, f64p, C.c_uint32]),
     "mgx_operator_create": (C.c_int, [vp, C.POINTER(OperatorDesc), C.POINTER(vp)]),
     "mgx_operator_destroy": (C.c_int, [vp]),

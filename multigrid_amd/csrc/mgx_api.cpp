@@ -83,40 +83,85 @@ namespace
 
 int mgx::report_error(int code, const char *message) { return fail(code, message ? message : ""); }
 
+// The environment carries the thresholds a deployment may want to tune, nothing else: no variable
+// changes what is computed or selects a diagnostic / cross-check code path.  Those are options of
+// a context, set explicitly with mgx_context_set_option (tests, A/B timings, tools).
+#ifndef MGX_CELLS_FORM
+#define MGX_CELLS_FORM 0
+#endif
+extern "C" int mgx_has_cells_form(void) { return MGX_CELLS_FORM; }
+
 mgx::Tunables mgx::Tunables::from_environment()
 {
   Tunables t;
-  auto     flag = [](const char *name) { return std::getenv(name) != nullptr; };
-  auto     num  = [](const char *name, uint32_t dflt) {
+  auto     num = [](const char *name, uint32_t dflt) {
     const char *e = std::getenv(name);
     return e ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
   };
-  t.trace               = flag("MGX_TRACE");
-  t.general_kernel      = flag("MGX_GENERAL_KERNEL");
-  t.no_bricks           = flag("MGX_NO_BRICKS");
+  t.trace               = std::getenv("MGX_TRACE") != nullptr;
   t.brick_min           = num("MGX_BRICK_MIN", t.brick_min);
-  t.brick_min_from_env  = flag("MGX_BRICK_MIN");
+  t.brick_min_from_env  = std::getenv("MGX_BRICK_MIN") != nullptr;
   t.overlap_min         = num("MGX_OVERLAP_MIN_BRICKS", t.overlap_min);
-  t.cells_form          = std::getenv("MGX_BRICK_FORM") && std::string(std::getenv("MGX_BRICK_FORM")) == "cells";
-  t.wide_max            = num("MGX_BRICK_WIDE_MAX", t.wide_max);
-  t.macro_wg_x16        = num("MGX_MACRO_WG_PER_CU_X16", 0);
-  t.no_diag_table       = flag("MGX_NO_DIAG_TABLE");
-  t.no_fused_init       = flag("MGX_NO_FUSED_INIT");
-  t.no_fused_restrict   = flag("MGX_NO_FUSED_RESTRICT");
-  t.no_fused_prolong    = flag("MGX_NO_FUSED_PROLONG");
-  t.force_fused_transfers = flag("MGX_FORCE_FUSED_TRANSFERS");
-  t.transfer_v1         = flag("MGX_TRANSFER_V1");
-  t.restrict_atomic     = flag("MGX_RESTRICT_ATOMIC");
   t.restrict_colour_min = num("MGX_RESTRICT_COLOUR_MIN", t.restrict_colour_min);
-  t.exchange_unfused    = flag("MGX_EXCHANGE_UNFUSED");
   t.cell_colour_min     = num("MGX_CELL_COLOUR_MIN", t.cell_colour_min);
   t.free_max_bricks     = num("MGX_FREE_MAX_BRICKS", t.free_max_bricks);
   t.free_one_max        = num("MGX_FREE_ONE_MAX", t.free_one_max);
-  t.no_graph            = flag("MGX_NO_GRAPH");
   t.graph_max_dofs      = num("MGX_GRAPH_MAX_DOFS", t.graph_max_dofs);
-  t.rccl_selftest       = flag("MGX_RCCL_SELFTEST");
-  t.dg_no_overlap       = flag("MGX_DG_NO_OVERLAP");
   return t;
+}
+
+bool mgx::Tunables::set(const std::string &name, double value)
+{
+  const bool     on = value != 0.;
+  const uint32_t u  = value <= 0. ? 0u : (value >= 4294967295. ? 0xFFFFFFFFu : (uint32_t)value);
+  struct Entry
+  {
+    const char *name;
+    bool       *flag;
+    uint32_t   *number;
+  };
+  const Entry table[] = {
+    {"trace", &trace, nullptr},
+    {"brick_min", nullptr, &brick_min},
+    {"overlap_min_bricks", nullptr, &overlap_min},
+    {"restrict_colour_min", nullptr, &restrict_colour_min},
+    {"cell_colour_min", nullptr, &cell_colour_min},
+    {"free_max_bricks", nullptr, &free_max_bricks},
+    {"free_one_max", nullptr, &free_one_max},
+    {"graph_max_dofs", nullptr, &graph_max_dofs},
+    // code-path selectors (numerically equivalent paths; tests compare them)
+    {"general_kernel", &general_kernel, nullptr},
+    {"no_bricks", &no_bricks, nullptr},
+#if MGX_CELLS_FORM // cross-check builds only (make crosscheck)
+    {"cells_form", &cells_form, nullptr},
+    {"brick_wide_max", nullptr, &wide_max},
+#endif
+    {"macro_wg_per_cu_x16", nullptr, &macro_wg_x16},
+    {"no_diag_table", &no_diag_table, nullptr},
+    {"no_fused_init", &no_fused_init, nullptr},
+    {"no_fused_restrict", &no_fused_restrict, nullptr},
+    {"no_fused_prolong", &no_fused_prolong, nullptr},
+    {"force_fused_transfers", &force_fused_transfers, nullptr},
+    {"transfer_v1", &transfer_v1, nullptr},
+    {"restrict_atomic", &restrict_atomic, nullptr},
+    {"exchange_unfused", &exchange_unfused, nullptr},
+    {"no_graph", &no_graph, nullptr},
+    {"dg_no_overlap", &dg_no_overlap, nullptr},
+    // emulation of a rank of a decomposed mesh on one GPU (tools/rank_emulation.py): the results are WRONG
+    {"rccl_selftest", &rccl_selftest, nullptr},
+  };
+  for (const Entry &e : table)
+    if (name == e.name)
+      {
+        if (e.flag)
+          *e.flag = on;
+        else
+          *e.number = u;
+        if (name == "brick_min")
+          brick_min_from_env = true; // taken as given (no p <= 2 doubling)
+        return true;
+      }
+  return false;
 }
 
 struct ExchangePlan
@@ -755,6 +800,15 @@ int mgx_context_create(mgx_context_t *out, int device)
   return MGX_OK;
 }
 
+int mgx_context_set_option(mgx_context_t ctx, const char *name, double value)
+{
+  MGX_REQUIRE(ctx && name, "mgx_context_set_option: null argument");
+  if (!ctx->tun.set(name, value))
+    return fail(MGX_ERR_INVALID_ARGUMENT, std::string("mgx_context_set_option: unknown option '") + name + "'");
+  g_trace = g_trace || ctx->tun.trace;
+  return MGX_OK;
+}
+
 int mgx_context_destroy(mgx_context_t ctx)
 {
   if (!ctx)
@@ -988,6 +1042,23 @@ int mgx_l2_norm(mgx_context_t ctx, int number, const void *x, size_t n, double *
   MGX_REQUIRE(ctx && result && (n == 0 || x), "mgx_l2_norm: null argument");
   double s = 0;
   MGX_TRY(dot(ctx, number, x, x, n, &s));
+  *result = std::sqrt(s);
+  return MGX_OK;
+}
+
+/* reductions over the DoFs a rank owns, with the ownership taken from the operator itself (mgx_dot finds
+ * it through the vector length) */
+int mgx_operator_dot(mgx_operator_t op, const void *x, const void *y, double *result)
+{
+  MGX_REQUIRE(op && x && y && result, "mgx_operator_dot: null argument");
+  return dot(op->ctx, op->d.number, x, y, op->d.n_dofs, result, op->plan.get());
+}
+
+int mgx_operator_l2_norm(mgx_operator_t op, const void *x, double *result)
+{
+  MGX_REQUIRE(op && x && result, "mgx_operator_l2_norm: null argument");
+  double s = 0;
+  MGX_TRY(dot(op->ctx, op->d.number, x, x, op->d.n_dofs, &s, op->plan.get()));
   *result = std::sqrt(s);
   return MGX_OK;
 }
@@ -1275,7 +1346,10 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
     }
   // brick schedule for the atomic-free cell loop (mgx_brick.hip); MGX_NO_BRICKS=1 keeps the
   // per-cell kernel (A/B measurements)
-  if (!tun.no_bricks && !general && (p <= 4 || d.separable))
+  // (builds without the cell-by-cell cross-check kernels schedule bricks only where the macro-element
+  // kernel runs: separable operator, vector below the 4 GB of a buffer descriptor)
+  const bool macro_covers = d.separable && (uint64_t)desc->n_dofs * number_size(d.number) < 0xFFFFFFF0ull;
+  if (!tun.no_bricks && !general && (MGX_CELLS_FORM ? (p <= 4 || d.separable) : macro_covers))
     {
       BrickHost   bh;
       std::string why;
@@ -2724,7 +2798,11 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
       if (!ctx->comm.allreduce_sum || ctx->comm.allreduce_sum(ctx->comm.user, S->agg_host.data(), (int)ng) != 0)
         return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
       if (num == MGX_F64)
-        MGX_HIP(hipMemcpyAsync(G->defect[L], S->agg_host.data(), 8 * ng, hipMemcpyHostToDevice, s));
+        {
+          // pageable staging buffer, rewritten by the next cycle: the copy must have left it before we return
+          MGX_HIP(hipMemcpyAsync(G->defect[L], S->agg_host.data(), 8 * ng, hipMemcpyHostToDevice, s));
+          MGX_HIP(hipStreamSynchronize(s));
+        }
       else
         {
           std::vector<float> tmp(S->agg_host.begin(), S->agg_host.end());
@@ -2755,6 +2833,7 @@ int mgx_solver_set_agglomeration(mgx_solver_t S, int level, mgx_solver_t coarse,
               "mgx_solver_set_agglomeration: the coarse solver lives on a context of its own without a communicator");
   MGX_REQUIRE(n_local == S->matrix[level]->d.n_dofs, "mgx_solver_set_agglomeration: map length is not the level size");
   const uint32_t ng = coarse->matrix[level]->d.n_dofs;
+  MGX_REQUIRE(ng <= 0x7FFFFFFFu, "mgx_solver_set_agglomeration: the agglomerated level exceeds the count of one allreduce");
   for (uint32_t i = 0; i < n_local; ++i)
     if (local_to_global[i] >= ng)
       return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_solver_set_agglomeration: map entry out of range");
@@ -2928,7 +3007,7 @@ int mgx_solver_solve_hooked(mgx_solver_t S, int do_analyze, double *reduction_ra
       }
       if (do_analyze)
         {
-          MGX_TRY(mgx_l2_norm(S->ctx, MGX_F64, S->residual[level], n, &init_residual)); // :444
+          MGX_TRY(mgx_operator_l2_norm(S->matrix_dp[level], S->residual[level], &init_residual)); // :444
           if (trace)
             trace[2 * level] = init_residual;
         }
@@ -2943,7 +3022,7 @@ int mgx_solver_solve_hooked(mgx_solver_t S, int do_analyze, double *reduction_ra
           MGX_TRY(mgx_vmult(S->matrix_dp[level], S->residual[level], S->solution[level]));    // :464
           launch_sadd(s, MGX_F64, S->residual[level], -1., 1., S->rhs[level], n);             // :465
           double res_norm = 0;
-          MGX_TRY(mgx_l2_norm(S->ctx, MGX_F64, S->residual[level], n, &res_norm));            // :466
+          MGX_TRY(mgx_operator_l2_norm(S->matrix_dp[level], S->residual[level], &res_norm));        // :466
           rate = std::pow(res_norm / init_residual, 1. / S->n_cycles);                        // :467
           if (trace)
             trace[2 * level + 1] = res_norm;
@@ -2997,7 +3076,7 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
   MGX_HIP(hipMemsetAsync(x, 0, 8 * n, s)); // :488
   launch_copy_cast(s, r, MGX_F64, S->rhs[lmax], MGX_F64, n);
   double res0 = 0;
-  MGX_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
+  MGX_TRY(mgx_operator_l2_norm(A, r, &res0));
   double       res = res0, rz = 0, rz_old = 0;
   unsigned int it  = 0;
   S->cg_history.assign(1, res0);
@@ -3094,7 +3173,7 @@ int mgx_solver_solve_cg_fused(mgx_solver_t S, unsigned int *iterations, double *
   MGX_HIP(hipMemsetAsync(p, 0, 8 * n, s));
   launch_copy_cast(s, r, MGX_F64, S->rhs[lmax], MGX_F64, n);
   double res0 = 0;
-  MGX_TRY(mgx_l2_norm(ctx, MGX_F64, r, n, &res0));
+  MGX_TRY(mgx_operator_l2_norm(A, r, &res0));
   MGX_TRY(mgx_solver_vmult(S, q, r)); // q = z_0 = M r_0
   double rz = 0;
   MGX_TRY(dot(ctx, MGX_F64, r, q, n, &rz));

@@ -1,5 +1,8 @@
-// mgx_brick.hip -- the production cell loop: atomic-free, deterministic, with the vector updates
-// of the caller fused in (the GPU counterpart of MatrixFree::cell_loop(..., operation_before_loop,
+// mgx_brick.hip -- the round-1 cell-by-cell brick loop, kept as a CROSS-CHECK of the macro-element
+// kernel (mgx_macro.hip, the production cell loop): compiled only into builds with MGX_CELLS_FORM=1
+// (make CELLS_FORM=1; option "cells_form" of a context), never into the default library.  What is
+// always compiled from this file is launch_brick_loop, the dispatcher.
+// Atomic-free, deterministic, with the vector updates of the caller fused in (the GPU counterpart of MatrixFree::cell_loop(..., operation_before_loop,
 // operation_after_loop), laplace_operator.h:605-634, 723-741).
 //
 // Work decomposition
@@ -31,11 +34,17 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
+#ifndef MGX_CELLS_FORM
+#define MGX_CELLS_FORM 0
+#endif
+
 namespace mgx
 {
+#if MGX_CELLS_FORM
 
   template <int N, typename T>
   __device__ __forceinline__ void bmv(const T *__restrict__ M, const T (&in)[N], T (&out)[N])
@@ -892,6 +901,7 @@ namespace mgx
       }
 #undef MGX_BRICK_CASE
   }
+#endif // MGX_CELLS_FORM
 
   void launch_brick_loop(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                          const void *b, void *out, void *partial, double f1, double f2, const void *old, double f0,
@@ -913,10 +923,17 @@ namespace mgx
         if (done)
           return;
       }
-    // (the caller asks for the colour-free schedule only where the macro-element kernel runs)
+    // (the caller asks for the reduced-colour schedules only where the macro-element kernel runs)
+#if MGX_CELLS_FORM
     if (op.number == 1)
       brick_dispatch<double>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
     else
       brick_dispatch<float>(s, op, mode, src, a, b, out, partial, f1, f2, old, f0, coarse, coarse_blocks, g0, g1);
+#else
+    // unreachable: mgx_operator_create builds a brick schedule only for operators the macro-element
+    // kernel covers; fail loudly rather than return without having computed anything
+    fprintf(stderr, "mgx: brick loop requested for an operator the macro-element kernel does not cover (mode %d)\n", mode);
+    abort();
+#endif
   }
 } // namespace mgx

@@ -1493,11 +1493,16 @@ namespace
     // (interior cells first in the caller's order: two contiguous ranges, no index lists)
     const uint32_t *li = op->interior_is_prefix ? nullptr : op->interior_cells;
     const uint32_t *lb = op->interior_is_prefix ? nullptr : op->boundary_cells;
-    MGX_DG_TRY(launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, li, op->n_interior));
-    MGX_DG_TRY(ghosts_exchange(op, ghosted, side));
-    MGX_DG_TRY(launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, lb, op->n_boundary, side,
-                            op->interior_is_prefix ? op->n_interior : 0));
-    return mgx::side_stream_end(op->ctx);
+    // whatever fails below, the main stream is ordered behind the side stream again before returning:
+    // nothing of this application may still be in flight when the caller reuses src / dst
+    int status = launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, li, op->n_interior);
+    if (status == MGX_OK)
+      status = ghosts_exchange(op, ghosted, side);
+    if (status == MGX_OK)
+      status = launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, lb, op->n_boundary, side,
+                            op->interior_is_prefix ? op->n_interior : 0);
+    const int joined = mgx::side_stream_end(op->ctx);
+    return status != MGX_OK ? status : joined;
   }
 } // namespace
 

@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 struct mgx_context_s;
@@ -15,11 +16,11 @@ namespace mgx
   constexpr int      kMaxN    = 10; // p <= 9
   constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
-  // Every switch the library takes from the environment, read ONCE when a context is created
-  // (mgx_context_create) and carried by the objects built on that context -- no getenv on any hot
-  // path, and two contexts of one process can differ (the tests compare code paths that way).
-  // All of them select between numerically equivalent code paths or set thresholds; none changes
-  // what is computed.  Defaults in brackets.
+  // Options of a context, carried by the objects built on it (two contexts of one process can differ:
+  // the tests compare code paths that way).  The thresholds marked ENV are also read from the
+  // environment, ONCE, when a context is created; everything else is set only through
+  // mgx_context_set_option(ctx, "<name>", value) before the first object is created on the context.
+  // All but rccl_selftest select between numerically equivalent code paths or set thresholds.
   struct Tunables
   {
     bool     trace            = false; // MGX_TRACE            host control flow on stderr
@@ -48,6 +49,7 @@ namespace mgx
     uint32_t graph_max_dofs   = 600000; // MGX_GRAPH_MAX_DOFS  largest level inside the replayed graph
     bool     rccl_selftest    = false; // MGX_RCCL_SELFTEST    one-rank communicator may name itself as neighbour
     static Tunables from_environment();
+    bool            set(const std::string &name, double value); // false: unknown option
   };
 
   // 1D data of the element in the operator's number type, resident in device memory and read

@@ -1190,14 +1190,20 @@ namespace mgx
     uint32_t         used = 0;
     auto             run  = [&](auto cfg) {
       using C = decltype(cfg);
+      // room for the partial sums of ALL launch groups is checked before the first launch: a launch
+      // already updates p, q and x, after which the caller's unfused path would start from half-updated vectors
+      uint64_t total = 0;
+      for (int c = 0; c < bd.n_colours; ++c)
+        total += std::min<uint32_t>(bd.colour_start[c + 1] - bd.colour_start[c],
+                                    (uint32_t)(op.macro_wg_x16 ? 1 : C::WGS) * macro_cus(op));
+      if (total > capacity)
+        return false;
       for (int c = 0; c < bd.n_colours; ++c)
         {
           const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
           if (count == 0)
             continue;
           const uint32_t grid = std::min<uint32_t>(count, (uint32_t)(op.macro_wg_x16 ? 1 : C::WGS) * macro_cus(op));
-          if (used + grid > capacity)
-            return false;
           post.sums = partials + 4 * (size_t)used;
           used += grid;
           hipLaunchKernelGGL((brick_macro_kernel<C::N - 1, T, kCgUpdate, false>), dim3(grid), dim3(C::THREADS), 0, s,

@@ -95,3 +95,17 @@ def test_native_rccl_send_recv_to_self():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selftest.py")], cwd=root,
                          capture_output=True, timeout=300)
     assert out.returncode == 0 and b"rccl selftest ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_callback_device_transport_takes_library_owned_buffers():
+    """with the torch-NCCL callback transport (native RCCL off or unavailable) the DG ghost exchange hands
+    the communicator device pointers that did not come from its alloc callback, and different receive pointers
+    for every vector under one plan id: they are wrapped in place and cached per buffer set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "callback_transport_worker.py")], cwd=root, env=env,
+                         capture_output=True, timeout=600)
+    assert out.returncode == 0 and b"callback transport ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

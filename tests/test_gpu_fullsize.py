@@ -106,27 +106,24 @@ def test_c2_full_solve_reaches_the_readme_accuracy(big):
         assert solver.compute_l2_error() < 4.2068e-10
 
 
-FALLBACKS = {"MGX_NO_FUSED_RESTRICT": "1", "MGX_NO_FUSED_INIT": "1", "MGX_TRANSFER_V1": "1",
-             "MGX_RESTRICT_ATOMIC": "1", "MGX_BRICK_WIDE_MAX": "0", "MGX_NO_GRAPH": "1", "MGX_BRICK_FORM": "cells",
-             "MGX_NO_DIAG_TABLE": "1", "MGX_NO_FUSED_PROLONG": "1"}
+FALLBACKS = {"no_fused_restrict": 1, "no_fused_init": 1, "transfer_v1": 1, "restrict_atomic": 1, "no_graph": 1,
+             "no_diag_table": 1, "no_fused_prolong": 1, "free_max_bricks": 0}
 
 
 @pytest.mark.parametrize("p,ns,nr", [(4, 3, 5), (2, 1, 7), (3, 1, 6), (5, 1, 5), (8, 1, 5), (1, 1, 7), (7, 1, 4), (9, 1, 4)])
 def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     """Meshes the oracle cannot run in seconds (4 - 17 M DoFs; production thresholds, i.e. without
-    the test overrides of conftest.py): the default V-cycle -- macro-element brick loop with the
-    inverse diagonal in registers, fused residual + restriction, first Chebyshev iterate formed on
-    the fly, pipelined colour-by-colour transfers, graph replay -- against the same solver on a
-    context created with every one of those switched off (cell-by-cell brick kernel, streamed
-    diagonal, first-version transfer kernels, separate residual and restriction, stored first
-    iterate).  The two differ in summation order only."""
+    the test overrides of conftest.py): the default V-cycle -- macro-element brick loop on the
+    reduced-colour schedules with the inverse diagonal in registers, fused residual + restriction, first
+    Chebyshev iterate formed on the fly, pipelined colour-by-colour transfers, graph replay -- against the
+    same solver on a context with every one of those switched off (eight colour launches, streamed
+    diagonal, first-version transfer kernels, separate residual and restriction, stored first iterate;
+    in a cross-check build also the cell-by-cell brick kernel).  The two differ in summation order only."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
     # degrees 7 and 8 run the separate transfer kernels by default (faster there): their fused forms
     # stay under test
-    monkeypatch.setenv("MGX_FORCE_FUSED_TRANSFERS", "1")
-    ctx = mg.Context(0)
-    monkeypatch.delenv("MGX_FORCE_FUSED_TRANSFERS")
+    ctx = mg.Context(0, options={"force_fused_transfers": 1})
     cube = mg.Cube(p, ns, nr)
     l = cube.max_level
     n = cube.n_dofs(l)
@@ -135,9 +132,10 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     a = ctx.vector(n)
     solver.vmult(a, x)
     solver.vmult(a, x)  # second call: coarse levels replayed from the graph
-    for k, v in FALLBACKS.items():
-        monkeypatch.setenv(k, v)
-    ctx2 = mg.Context(0)  # the switches are read when a context is created
+    options = dict(FALLBACKS)
+    if mg._lib.load().mgx_has_cells_form():
+        options.update(cells_form=1, brick_wide_max=0)
+    ctx2 = mg.Context(0, options=options)
     plain = mg.MultigridSolver(ctx2, cube, 3, 3, 1, mg.F64)
     # a vector belongs to the stream of the context that made it (its zeroing is enqueued there):
     # the second solver works on vectors of its own context, and both streams are drained before
@@ -150,8 +148,6 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     mg.check(ctx.lib.mgx_sadd(ctx.h, mg.F64, b.ptr, 1.0, -1.0, a.ptr, n))
     assert ctx.l2_norm(b) < 1e-11 * nb
     # and the full solve converges as it should (rate of the README table: 0.11 - 0.16)
-    for k in FALLBACKS:
-        monkeypatch.delenv(k)
     rate, trace = solver.solve(True)
     assert rate < 0.3 and (trace[1:, 1] < trace[1:, 0]).all()
     for v in (x, a, b):

@@ -55,12 +55,13 @@ def test_vmult_and_residual(ctx, p, ns, nr):
 @pytest.mark.parametrize("p,ns,nr", [(4, 1, 3), (2, 1, 3), (3, 3, 2)])
 @pytest.mark.parametrize("wide_max", ["0", "100000"])
 def test_cell_by_cell_brick_kernel(monkeypatch, p, ns, nr, wide_max):
-    """The cell-by-cell form of the brick loop (MGX_BRICK_FORM=cells; production: the macro-element
-    form, which every other test runs), in its 256-thread (MGX_BRICK_WIDE_MAX=0) and its
-    512-thread form.  The switches are read when the context is created."""
-    monkeypatch.setenv("MGX_BRICK_FORM", "cells")
-    monkeypatch.setenv("MGX_BRICK_WIDE_MAX", wide_max)
-    ctx = mg.Context(0)
+    """The cell-by-cell form of the brick loop (round-1 kernels, built only into the cross-check library:
+    make -C multigrid_amd/csrc crosscheck, MGX_LIB_PATH=multigrid_amd/libmgx_crosscheck.so; production: the
+    macro-element form, which every other test runs), in its 256-thread (brick_wide_max = 0) and its
+    512-thread form."""
+    if not mg._lib.load().mgx_has_cells_form():
+        pytest.skip("library built without the cell-by-cell cross-check kernels")
+    ctx = mg.Context(0, options={"cells_form": 1, "brick_wide_max": float(wide_max)})
     cube = mg.Cube(p, ns, nr)
     orc = oracle_for(cube, p, ns, nr, degree=3)
     solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)

@@ -1,6 +1,6 @@
 """Cost / benefit of launching the interface bricks first and overlapping the exchange with the
 interior bricks, on ONE GPU: a single-rank RCCL communicator whose only neighbour is the rank itself
-(MGX_RCCL_SELFTEST), the "interface" being the unconstrained DoFs of the mid plane x = G/2 of the
+(context option "rccl_selftest"), the "interface" being the unconstrained DoFs of the mid plane x = G/2 of the
 cube (2 brick layers touch it, as for a rank with two interface faces).  The sums are wrong (the
 rank adds its own copy), the launch sequence, the RCCL send/recv on the side stream and the timing
 are those of a real decomposed run.  usage: overlap_probe.py on|off [cells] [reps]
@@ -9,7 +9,6 @@ import ctypes as C, os, sys, time
 mode = sys.argv[1] if len(sys.argv) > 1 else "on"
 cells = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-os.environ["MGX_RCCL_SELFTEST"] = "1"
 os.environ["MGX_OVERLAP_MIN_BRICKS"] = "1" if mode == "on" else "4000000000"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,7 +16,7 @@ import multigrid_amd as mg
 from multigrid_amd import _lib
 
 nr = int(np.log2(cells))
-ctx = mg.Context(0)
+ctx = mg.Context(0, options={"rccl_selftest": 1})
 lib = ctx.lib
 buf = (C.c_uint8 * 128)()
 mg.check(lib.mgx_rccl_unique_id(buf))

@@ -1,6 +1,6 @@
 """What one rank of `bench.py --gpus N` (strong scaling of the 128^3-cell problem) does, run on ONE GPU:
 the rank-0 part of the block-split mesh with a one-rank RCCL communicator in which every neighbour
-is the rank itself (MGX_RCCL_SELFTEST).  The sums are wrong (the rank adds copies of its own
+is the rank itself (context option "rccl_selftest").  The sums are wrong (the rank adds copies of its own
 interface values), but the launch sequence, the kernels, the RCCL send/recv groups and the
 reductions are those of a real run; only the link is missing.  Compared with the same number of
 cells as an undecomposed cube this shows what the decomposition costs on the device.
@@ -9,7 +9,6 @@ import ctypes as C, os, sys, time
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 cells = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-os.environ["MGX_RCCL_SELFTEST"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import multigrid_amd as mg
@@ -26,7 +25,7 @@ def timed(ctx, fn, k):
 
 nr = int(np.log2(cells))
 procs = mg.process_grid(N)
-ctx = mg.Context(0)
+ctx = mg.Context(0, options={"rccl_selftest": 1})
 buf = (C.c_uint8 * 128)()
 mg.check(ctx.lib.mgx_rccl_unique_id(buf))
 mg.check(ctx.lib.mgx_context_set_rccl(ctx.h, 0, 1, buf))

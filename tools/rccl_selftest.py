@@ -3,13 +3,12 @@ whose only "neighbour" is the rank itself -- ncclSend/ncclRecv to self inside a 
 the library on its stream -- checked against the expected sum, plus ncclAllReduce through a dot
 product.  (Real peers need several GPUs; this covers id plumbing, dlopen, group calls, stream order.)"""
 import ctypes as C, os, sys
-os.environ["MGX_RCCL_SELFTEST"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import multigrid_amd as mg
 from multigrid_amd import _lib
 
-ctx = mg.Context(0)
+ctx = mg.Context(0, options={"rccl_selftest": 1})
 lib = ctx.lib
 buf = (C.c_uint8 * 128)()
 mg.check(lib.mgx_rccl_unique_id(buf))
