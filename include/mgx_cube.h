@@ -71,13 +71,31 @@ typedef struct
  *                 (poisson_shell/program.cc:425) as an equiangular cube-sphere sector: curved cells
  *   PROBLEM_SHELL u = sin(2 pi (x+y)), a = 1 + 1e6 prod_e cos^2(2 pi x_e + 0.1 e), f = -div(a grad u)
  *                 (poisson_shell/program.cc:97-137, 157-200, 219-225)
- * The six-block shell itself (unstructured block connectivity) is not provided. */
+ *   HYPER_SHELL   the whole shell, mgx_cube_create_shell below */
 #define MGX_CUBE_GEOMETRY_CARTESIAN 0
 #define MGX_CUBE_GEOMETRY_SHEARED 1
 #define MGX_CUBE_GEOMETRY_SHELL_SECTOR 2
+#define MGX_CUBE_GEOMETRY_HYPER_SHELL 3
 #define MGX_CUBE_PROBLEM_CUBE 0
 #define MGX_CUBE_PROBLEM_SHELL 1
 int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
+/* The mesh of poisson_shell: GridGenerator::hyper_shell(tria, origin, 0.5, 1.0, n_coarse) with n_coarse = 6
+ * (one cell per face of a cube) or 12 (per face of a rhombic dodecahedron), refined n_refine times
+ * (poisson_shell/program.cc:425-431); Dirichlet values on both spheres.  The coarse cells ("blocks") are
+ * refined uniformly, cells in Morton order block after block (children of cell c: 8c .. 8c+7).  The local
+ * coordinates of the blocks are chosen such that every mesh entity is seen in the same lexicographic order
+ * by all cells that contain it, so that the compressed index tables of LaplaceOperator hold on the whole
+ * shell (laplace_operator.h:272-340); the cell geometry is the degree-p interpolant of the block map
+ * (0.5 + 0.5 w) n(u, v), n the normalised bilinear interpolant of the polyhedron face.  problem:
+ * MGX_CUBE_PROBLEM_SHELL (poisson_shell) or MGX_CUBE_PROBLEM_CUBE (constant coefficient).  One rank.
+ * The multiplicities of the transfer are not powers of two where three blocks meet: levels carry no
+ * weight_shift, mgx_transfer_create derives owner weights. */
+int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *cube);
+/* multi-block meshes: the physical Gauss-Lobatto points of every cell of a level,
+ * out[cell][3][(p+1)^3], and the number of cells around each of the 27 entities of every cell
+ * (what deal.II's mesh would tell a caller; the oracle of the tests is built on them) */
+int            mgx_cube_cell_nodes(mgx_cube_t cube, int level, double *out);
+const uint8_t *mgx_cube_entity_multiplicity(mgx_cube_t cube, int level);
 /* [n_cells][6][(p+1)^3] merged coefficient of a mapped level (NULL on the Cartesian cube) */
 const double *mgx_cube_coef_q(mgx_cube_t cube, int level);
 int mgx_cube_rank(mgx_cube_t cube);

@@ -371,7 +371,7 @@ class Cube:
     PROBLEM = {"cube": 0, "shell": 1}
 
     def __init__(self, degree, n_subdiv=1, n_refine=3, box=None, procs=(1, 1, 1), rank=0, numbering="brick",
-                 origin=-1.0, h0=1.9, geometry="cartesian", problem="cube"):
+                 origin=-1.0, h0=1.9, geometry="cartesian", problem="cube", shell=None):
         """box=None: the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction.
         box=(sx,sy,sz): a box of sx x sy x sz cubic coarse cells of size h0 from (origin,)*3,
         optionally distributed over the process grid `procs`; this rank owns box[d]/procs[d] coarse
@@ -382,10 +382,22 @@ class Cube:
         geometry / problem (box form only): mapped meshes and the variable coefficient of
         poisson_shell, MGX_CUBE_GEOMETRY_* / MGX_CUBE_PROBLEM_* in mgx_cube.h.
         numbering: "brick" (default, grouped for the device cell loop) or "cell" (the
-        plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h."""
+        plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h.
+        shell=6 | 12: the mesh of poisson_shell instead, GridGenerator::hyper_shell(0, 0.5, 1.0, shell) refined
+        n_refine times (mgx_cube_create_shell); problem "shell" (default there) or "cube"."""
         self.lib = _lib.load()
         h = C.c_void_p()
         num = self.NUMBERING[numbering]
+        self.shell = shell
+        if shell is not None:
+            self.box_desc = None
+            check(self.lib.mgx_cube_create_shell(degree, int(shell), n_refine, self.PROBLEM[problem], C.byref(h)))
+            self.h = h
+            self.rank, self.size = 0, 1
+            self.degree = degree
+            self.n_levels = self.lib.mgx_cube_n_levels(h)
+            self.max_level = self.n_levels - 1
+            return
         self.box_desc = None if box is None else dict(box=tuple(box), origin=origin, h0=h0, geometry=geometry,
                                                         problem=problem, numbering=numbering)
         if box is None:
@@ -446,6 +458,19 @@ class Cube:
 
     def children(self, l):
         return self._arr("mgx_cube_children", (self.n_cells(l - 1), 8), l)
+
+    def cell_nodes(self, l):
+        """multi-block meshes: physical Gauss-Lobatto points of every cell, [n_cells, 3, (p+1)^3]"""
+        out = np.empty((self.n_cells(l), 3, (self.degree + 1) ** 3))
+        check(self.lib.mgx_cube_cell_nodes(self.h, l, out.ctypes.data_as(_lib.f64p)))
+        return out
+
+    def entity_multiplicity(self, l):
+        """multi-block meshes: cells around each of the 27 entities of every cell, [n_cells, 27]"""
+        ptr = self.lib.mgx_cube_entity_multiplicity(self.h, l)
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(ptr, shape=(self.n_cells(l) * 27,)).reshape(-1, 27).copy()
 
     def cell_coords(self, l):
         return self._arr("mgx_cube_cell_coords", (self.n_cells(l), 3), l)

@@ -2307,14 +2307,28 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
       for (int e = 0; e < 27; ++e)
         cnt[rep(pc, e)]++;
     std::vector<uint8_t> shift(27 * (size_t)npar, 0);
+    // Multiplicities other than 1/2/4/8 (three blocks of a multi-block mesh around an edge): the
+    // restriction then uses OWNER weights -- a shared fine DoF is restricted by the one parent that
+    // owns its entity, with weight 1.  Any weights that add up to one over the parents of a fine
+    // DoF give the same R = P^T (P is interpolatory: a fine DoF on a shared entity only couples to
+    // coarse DoFs on that entity, which all its parents hold); only the summation order differs.
+    bool owner_weights = false;
     for (uint32_t pc = 0; pc < npar; ++pc)
       for (int e = 0; e < 27; ++e)
         {
           const uint8_t c = cnt[rep(pc, e)];
           if (c != 1 && c != 2 && c != 4 && c != 8)
-            return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: fine DoF multiplicity is not 1/2/4/8");
+            owner_weights = true;
           shift[27 * (size_t)pc + e] = c == 1 ? 0 : (c == 2 ? 1 : (c == 4 ? 2 : 3));
         }
+    if (owner_weights)
+      {
+        if (coarse->plan || desc->weight_shift)
+          return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: fine DoF multiplicities other than 1/2/4/8 on a decomposed "
+                                           "mesh or together with weight_shift");
+        std::fill(shift.begin(), shift.end(), (uint8_t)0);
+        tr->d.owner_weights = true;
+      }
     if (desc->weight_shift) // multiplicities that count the parents of other ranks as well
       {
         for (size_t i = 0; i < shift.size(); ++i)
@@ -2510,6 +2524,11 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
               MGX_HIP(hipMemcpy(tr->d.coarse_blocks, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
             }
         }
+    }
+  if (tr->d.owner_weights && !tr->d.patch)
+    {
+      std::unique_ptr<mgx_transfer_s, int (*)(mgx_transfer_t)> guard(tr.release(), mgx_transfer_destroy);
+      return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: owner weights need the pipelined transfer kernels (fine level below 2^29 DoFs)");
     }
   *out = tr.release();
   return MGX_OK;

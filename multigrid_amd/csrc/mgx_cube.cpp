@@ -13,7 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <array>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace
@@ -164,6 +166,16 @@ namespace
     // folded in, det(J) w_q and the physical quadrature point; empty on the Cartesian
     // constant-coefficient mesh
     std::vector<double>   coef_q, jxw, xq;
+    // multi-block meshes (hyper_shell): number of cells around each of the 27 entities of every cell
+    // (the multiplicities of the transfer where they are not products of 1 and 2 per direction)
+    std::vector<uint8_t>  ent_mult;
+  };
+
+  // one coarse cell of the hyper_shell meshes (mgx_shell.inc): the corner vectors c00, c10, c01, c11
+  // (u, then v) of its face of the generating polyhedron
+  struct ShellBlock
+  {
+    int c[4][3];
   };
 
   inline uint32_t compact3(uint32_t m)
@@ -261,6 +273,7 @@ struct mgx_cube_s
   }
   Basis              basis;
   std::vector<Level> levels;
+  std::vector<ShellBlock> shell; // MGX_CUBE_GEOMETRY_HYPER_SHELL: the coarse cells
 };
 
 namespace
@@ -598,6 +611,10 @@ namespace
         }
   }
 
+} // namespace
+#include "mgx_shell.inc"
+namespace
+{
   // evaluate_coefficient, general branch (laplace_operator.h:388-430) for a mapped mesh: the cell
   // geometry is the degree-p interpolant of the map at the GLL support points (MappingQ of
   // multigrid_solver.h:139); per quadrature point JxW = det J w_q and coef = a(x_q) JxW J^-1 J^-T
@@ -618,6 +635,9 @@ namespace
           const double X0[3] = {C.origin + L.h * (L.off[0] + L.coords[3 * (size_t)c]),
                                 C.origin + L.h * (L.off[1] + L.coords[3 * (size_t)c + 1]),
                                 C.origin + L.h * (L.off[2] + L.coords[3 * (size_t)c + 2])};
+          if (C.geometry == MGX_CUBE_GEOMETRY_HYPER_SHELL)
+            shell_cell_nodes(C, L, c, nodes);
+          else
           for (int k = 0, i3 = 0; k < n; ++k)
             for (int j = 0; j < n; ++j)
               for (int i = 0; i < n; ++i, ++i3)
@@ -682,6 +702,9 @@ namespace
     const Basis &B = C.basis;
     // inhomogeneous_bc: analytic solution at the support points of boundary DoFs, nonzero only
     std::vector<double> bc_full(L.n_dofs, 0.);
+    if (C.geometry == MGX_CUBE_GEOMETRY_HYPER_SHELL)
+      shell_boundary_values(C, L, bc_full);
+    else
     {
       // support point coordinate of LOCAL grid index g along direction d
       std::vector<double> xd[3];
@@ -920,6 +943,58 @@ int mgx_cube_create_box(const mgx_cube_box_desc *bd, mgx_cube_t *out)
   return create_impl(*bd, out);
 }
 
+int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *out)
+{
+  if (!out || degree < 1 || degree > MGX_MAX_DEGREE || n_refine < 0 || n_refine > 8)
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: degree must be in 1..9 and n_refine in 0..8");
+  if (n_coarse != 6 && n_coarse != 12)
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: 6 or 12 coarse cells (GridGenerator::hyper_shell)");
+  if (problem < 0 || problem > MGX_CUBE_PROBLEM_SHELL)
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: unknown problem");
+  if ((uint64_t)n_coarse << (3 * n_refine) >= 0x10000000ull)
+    return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_create_shell: too many cells");
+  omp_set_num_threads(effective_threads());
+  auto C        = std::make_unique<mgx_cube_s>();
+  C->p          = degree;
+  C->origin     = 0.;
+  C->h0         = 0.5;
+  C->geometry   = MGX_CUBE_GEOMETRY_HYPER_SHELL;
+  C->problem.id = problem;
+  C->groots[0] = C->lroots[0] = n_coarse;
+  C->shell      = shell_blocks(n_coarse);
+  make_basis(C->basis, degree);
+  C->levels.resize(n_refine + 1);
+  for (int l = 0; l <= n_refine; ++l)
+    {
+      std::string why;
+      if (!build_shell_level(*C, C->levels[l], l, why))
+        return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
+      build_geometry(*C, C->levels[l]);
+      build_rhs(*C, C->levels[l]);
+    }
+  *out = C.release();
+  return MGX_OK;
+}
+
+int mgx_cube_cell_nodes(mgx_cube_t c, int l, double *out)
+{
+  if (!c || !out || l < 0 || l >= (int)c->levels.size())
+    return MGX_ERR_INVALID_ARGUMENT;
+  if (c->geometry != MGX_CUBE_GEOMETRY_HYPER_SHELL)
+    return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_cell_nodes: multi-block meshes only");
+  const Level &L  = c->levels[l];
+  const size_t n3 = (size_t)(c->p + 1) * (c->p + 1) * (c->p + 1);
+#pragma omp parallel for schedule(static)
+  for (uint32_t cell = 0; cell < L.n_cells; ++cell)
+    shell_cell_nodes(*c, L, cell, out + 3 * n3 * cell);
+  return MGX_OK;
+}
+
+const uint8_t *mgx_cube_entity_multiplicity(mgx_cube_t c, int l)
+{
+  return (c && l >= 0 && l < (int)c->levels.size() && !c->levels[l].ent_mult.empty()) ? c->levels[l].ent_mult.data() : nullptr;
+}
+
 int mgx_cube_destroy(mgx_cube_t cube)
 {
   delete cube;
@@ -950,7 +1025,7 @@ uint32_t        mgx_cube_n_shared(mgx_cube_t c, int l) { return (uint32_t)c->lev
 const uint32_t *mgx_cube_shared(mgx_cube_t c, int l) { return c->levels[l].shared.data(); }
 uint32_t        mgx_cube_n_not_owned(mgx_cube_t c, int l) { return (uint32_t)c->levels[l].not_owned.size(); }
 const uint32_t *mgx_cube_not_owned(mgx_cube_t c, int l) { return c->levels[l].not_owned.data(); }
-const uint8_t  *mgx_cube_weight_shift(mgx_cube_t c, int l) { return l > 0 ? c->levels[l].weight_shift.data() : nullptr; }
+const uint8_t  *mgx_cube_weight_shift(mgx_cube_t c, int l) { return (l > 0 && !c->levels[l].weight_shift.empty()) ? c->levels[l].weight_shift.data() : nullptr; }
 void            mgx_cube_cells_per_dim3(mgx_cube_t c, int l, uint32_t local[3], uint32_t global[3])
 {
   for (int d = 0; d < 3; ++d)
@@ -1168,7 +1243,7 @@ int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int 
       mgx_transfer_desc t;
       t.children     = cube->levels[l].children.data();
       t.prolong_1d   = cube->basis.P1;
-      t.weight_shift = cube->levels[l].weight_shift.data();
+      t.weight_shift = cube->levels[l].weight_shift.empty() ? nullptr : cube->levels[l].weight_shift.data();
       status       = mgx_transfer_create(out->matrix_dp[l - 1], out->matrix_dp[l], &t, &out->transfer_dp[l]);
       if (status != MGX_OK)
         break;

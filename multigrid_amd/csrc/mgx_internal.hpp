@@ -174,6 +174,7 @@ namespace mgx
     // entities of the PB^3 parents the brick's cells belong to (PB = 2 for p <= 4, 1 for p >= 5)
     uint32_t           *coarse_blocks = nullptr;
     mutable uint32_t    pipe_grid[4] = {0, 0, 0, 0}; // persistent grid of prolongate(add), prolongate, restrict x2
+    bool                owner_weights = false;   // restriction: weight 1 for the parent that owns a fine entity, 0 for the others (multi-block meshes)
     bool                coarse_coloured = false; // coarse cells c and c' with c % 8 == c' % 8 share no DoF
     uint32_t            n_cus = 256;
     uint32_t            colour_min = 16384; // Tunables::restrict_colour_min

@@ -117,7 +117,7 @@ namespace mgx
   __global__ void __launch_bounds__(TPCfg<P>::THREADS)
     restrict_pipe_kernel(T *__restrict__ coarse, const T *__restrict__ fine, const uint32_t *__restrict__ patch_,
                          const uint32_t *__restrict__ idx_c_, uint32_t n_parents_, const Basis1D<T> *__restrict__ B,
-                         uint32_t colour, T *__restrict__ scratch)
+                         uint32_t colour, T *__restrict__ scratch, int owner_weights)
   {
     // scratch (uncoloured launch only): the parent's (p+1)^3 sums go to scratch[parent (p+1)^3 + .] for the
     // ordered assembly of the coarse level (mgx_kernels.hip, assemble_kernel) instead of atomic adds
@@ -186,7 +186,9 @@ namespace mgx
           for (int e = 0; e < 5; ++e)
             {
               w[e]      = tbl[b][has[it] ? 25 * e + line[it].sxy : 0];
-              sh[it][e] = pw_shift(w[e]);
+              // weight 2^-shift of the fine DoFs of this patch entity; owner weights (multi-block meshes):
+              // 1 for the parent that owns the entity, 0 (shift 31 is never a real one) for the others
+              sh[it][e] = owner_weights ? (pw_owned(w[e]) ? 0u : 31u) : pw_shift(w[e]);
             }
 #pragma unroll
           for (int c = 0; c < M; ++c)
@@ -221,7 +223,7 @@ namespace mgx
 #pragma unroll
             for (int c = 0; c < M; ++c)
               {
-                const T x = v[it][c] * (T(1) / T(1u << sh[it][zslot(c)]));
+                const T x = sh[it][zslot(c)] == 31u ? T(0) : v[it][c] * (T(1) / T(1u << sh[it][zslot(c)]));
 #pragma unroll
                 for (int k = 0; k < N; ++k)
                   r[k] = fma(p1[c * N + k], x, r[k]);
@@ -531,7 +533,7 @@ namespace mgx
         for (uint32_t colour = 0; colour < 8; ++colour)
           hipLaunchKernelGGL((restrict_pipe_kernel<P, T, true>), dim3(g), dim3(C::THREADS), 0, s, (T *)coarse_out,
                              (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis, colour,
-                             (T *)nullptr);
+                             (T *)nullptr, t.owner_weights ? 1 : 0);
       }
     else
       {
@@ -541,7 +543,7 @@ namespace mgx
         hipLaunchKernelGGL((restrict_pipe_kernel<P, T, false>),
                            dim3(grid_of(2, (const void *)restrict_pipe_kernel<P, T, false>)), dim3(C::THREADS), 0, s,
                            (T *)coarse_out, (const T *)fine, t.patch, idx_c, c.n_cells, (const Basis1D<T> *)c.basis,
-                           0u, scratch);
+                           0u, scratch, t.owner_weights ? 1 : 0);
         if (scratch)
           launch_assemble(s, c, 1, coarse_out, nullptr, 0u);
       }

@@ -100,8 +100,19 @@ def lib():
     L.orc_time_vcycle.restype = C.c_double
     L.orc_time_vcycle.argtypes = [vp, C.c_int]
     L.orc_num_threads.restype = C.c_int
+    L.orc_create_from_mesh.restype = vp
+    L.orc_create_from_mesh.argtypes = [C.c_int, C.c_int, C.POINTER(MeshLevel), C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L
+
+
+class MeshLevel(C.Structure):
+    """orc_mesh_level (mg_oracle.h)"""
+    _fields_ = [("n_cells", C.c_uint32), ("n_dofs", C.c_uint32), ("n_constrained", C.c_uint32),
+                ("idx27", C.POINTER(C.c_uint32)), ("idx27_plain", C.POINTER(C.c_uint32)),
+                ("constrained", C.POINTER(C.c_uint32)), ("children", C.POINTER(C.c_uint32)),
+                ("dof_gid", C.POINTER(C.c_uint32)), ("ent_mult", C.POINTER(C.c_uint8)),
+                ("cell_nodes", C.POINTER(C.c_double))]
 
 
 def _p(a):
@@ -116,11 +127,28 @@ class Oracle:
     PROBLEM = {"cube": 0, "shell": 1}
 
     def __init__(self, p, n_subdiv=1, n_refine=3, degree=3, n_cycles=1, vfloat=False, box=None, geometry=None,
-                 problem="cube", origin=-0.9, h0=None, polynomial="first_kind"):
+                 problem="cube", origin=-0.9, h0=None, polynomial="first_kind", mesh=None):
         """box=(sx,sy,sz): the doubling-mesh family (coarse cubes of size 1.9 from (-1,-1,-1));
         otherwise the square mesh [-0.9,1]^3 with n_subdiv coarse cells per direction"""
         self.L = lib()
-        if geometry is not None:
+        if mesh is not None:
+            # a mesh described by tables (multi-block shell): `mesh` provides the per-level arrays of orc_mesh_level
+            u32, u8, f64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+            keep, levels = [], (MeshLevel * mesh.n_levels)()
+            for l in range(mesh.n_levels):
+                arrs = dict(idx27=np.ascontiguousarray(mesh.idx27(l), np.uint32), idx27_plain=np.ascontiguousarray(mesh.idx27_plain(l), np.uint32),
+                            constrained=np.ascontiguousarray(mesh.constrained(l), np.uint32),
+                            children=np.ascontiguousarray(mesh.children(l), np.uint32) if l > 0 else np.zeros(1, np.uint32),
+                            dof_gid=np.ascontiguousarray(mesh.dof_grid(l), np.uint32),
+                            ent_mult=np.ascontiguousarray(mesh.entity_multiplicity(l), np.uint8),
+                            cell_nodes=np.ascontiguousarray(mesh.cell_nodes(l), np.float64))
+                keep.append(arrs)
+                levels[l].n_cells, levels[l].n_dofs, levels[l].n_constrained = mesh.n_cells(l), mesh.n_dofs(l), mesh.n_constrained(l)
+                for k, t in (("idx27", u32), ("idx27_plain", u32), ("constrained", u32), ("children", u32), ("dof_gid", u32),
+                             ("ent_mult", u8), ("cell_nodes", f64)):
+                    setattr(levels[l], k, arrs[k].ctypes.data_as(t))
+            self.h = self.L.orc_create_from_mesh(p, mesh.n_levels, levels, degree, n_cycles, int(vfloat), self.PROBLEM[problem])
+        elif geometry is not None:
             # mapped mesh / variable coefficient (poisson_shell): box of `box` (default n_subdiv^3) coarse cells
             b = box if box is not None else (n_subdiv,) * 3
             self.h = self.L.orc_create_mapped(p, b[0], b[1], b[2], origin, 1.9 / b[0] if h0 is None else h0, n_refine,

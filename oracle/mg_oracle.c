@@ -224,8 +224,13 @@ typedef struct
   int       Nd[3];         /* cells per direction */
   uint32_t  n_cells, n_dofs, n_constrained;
   uint32_t *idx27, *idx27_plain, *constrained, *cell_coords, *dof_grid;
-  uint32_t  colour_start[9];
+  int       n_colours;        /* 8 parity classes on the structured box; greedy colouring of a mesh given by tables */
+  uint32_t  colour_start[65];
   uint32_t *colour_cells;
+  /* mesh given by tables (orc_create_from_mesh): cells around each of the 27 entities of every cell,
+   * physical Gauss-Lobatto points of every cell [cell][3][n^3]; NULL on the structured box */
+  uint8_t  *ent_mult;
+  double   *cell_nodes;
   uint32_t *children_of_parent; /* [n_cells(level-1)*8] -> cell index on this level */
   double    h, coef[6];
   /* general branch (laplace_operator.h:388-430): per (cell, q) merged coefficient with the weight
@@ -292,6 +297,7 @@ static void level_init(orc_level *L, int p, const int roots[3], double h0, int l
       L->cell_coords[3 * (size_t)c + 2] = (rz << level) + morton_compact(m >> 2);
     }
   /* colour lists */
+  L->n_colours    = 8;
   uint32_t cnt[8] = {0};
   for (uint32_t c = 0; c < nc; ++c)
     cnt[(L->cell_coords[3 * (size_t)c] & 1) | ((L->cell_coords[3 * (size_t)c + 1] & 1) << 1) |
@@ -404,6 +410,8 @@ static void level_free(orc_level *L)
   free(L->coef_q);
   free(L->jxw);
   free(L->xq);
+  free(L->ent_mult);
+  free(L->cell_nodes);
 }
 
 /* number-type instantiations */
@@ -534,7 +542,7 @@ static void compute_rhs(const orc_problem *P, const orc_level *L, double *dst, c
   const int      p = P->p, n = p + 1, n3 = n * n * n;
   const basis_d *B = BD(P);
   memset(dst, 0, sizeof(double) * L->n_dofs);
-  for (int col = 0; col < 8; ++col)
+  for (int col = 0; col < L->n_colours; ++col)
     {
       const uint32_t  nc   = L->colour_start[col + 1] - L->colour_start[col];
       const uint32_t *list = L->colour_cells + L->colour_start[col];
@@ -555,9 +563,9 @@ static void compute_rhs(const orc_problem *P, const orc_level *L, double *dst, c
             sweep_d(n, 0, B->D, t0, gx, 0);
             sweep_d(n, 1, B->D, t0, gy, 0);
             sweep_d(n, 2, B->D, t0, gz, 0);
-            const double x0 = P->origin + L->h * L->cell_coords[3 * (size_t)c],
-                         y0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 1],
-                         z0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 2];
+            const double x0 = L->cell_coords ? P->origin + L->h * L->cell_coords[3 * (size_t)c] : 0.,
+                         y0 = L->cell_coords ? P->origin + L->h * L->cell_coords[3 * (size_t)c + 1] : 0.,
+                         z0 = L->cell_coords ? P->origin + L->h * L->cell_coords[3 * (size_t)c + 2] : 0.;
             if (L->coef_q) /* general branch: full coefficient per q, JxW and x_q from the mapping */
               for (int q = 0; q < n3; ++q)
                 {
@@ -694,6 +702,9 @@ static void level_geometry(const orc_problem *P, orc_level *L)
 #pragma omp for schedule(static)
     for (uint32_t c = 0; c < L->n_cells; ++c)
       {
+        if (L->cell_nodes) /* mesh given by tables: the cell's Gauss-Lobatto points as the caller's mesh places them */
+          memcpy(xn, L->cell_nodes + 3 * (size_t)n3 * c, sizeof(double) * 3 * n3);
+        else
         for (int k = 0, i3 = 0; k < n; ++k)
           for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i, ++i3)
@@ -751,6 +762,10 @@ static void level_geometry(const orc_problem *P, orc_level *L)
   }
 }
 
+/* everything MultigridSolver's constructor does once the levels exist: vectors, boundary values, right-hand
+ * side, diagonal, smoothers (multigrid_solver.h:168-289) */
+static orc_problem *finish_problem(orc_problem *P);
+
 static orc_problem *create_impl(int p, const int roots[3], double origin, double h0, int n_refine, int degree,
                                 int n_cycles, int vfloat, int geometry, int problem)
 {
@@ -786,6 +801,12 @@ static orc_problem *create_impl(int p, const int roots[3], double origin, double
       if (geometry != ORC_GEOM_CARTESIAN || problem != ORC_PROBLEM_CUBE)
         level_geometry(P, &P->levels[l]);
     }
+  return finish_problem(P);
+}
+
+static orc_problem *finish_problem(orc_problem *P)
+{
+  const int degree = P->degree, vfloat = P->vfloat;
   P->solution = (double **)calloc(P->n_levels, sizeof(double *));
   P->rhs      = (double **)calloc(P->n_levels, sizeof(double *));
   P->residual = (double **)calloc(P->n_levels, sizeof(double *));
@@ -805,11 +826,37 @@ static orc_problem *create_impl(int p, const int roots[3], double origin, double
       P->bc_idx[l] = (uint32_t *)malloc(sizeof(uint32_t) * (L->n_constrained + 1));
       P->bc_val[l] = (double *)malloc(sizeof(double) * (L->n_constrained + 1));
       uint32_t cnt = 0;
+      double  *bc_xyz = NULL; /* mesh given by tables: support points of the DoFs from the cells' nodes */
+      if (L->cell_nodes)
+        {
+          const int p = P->p, n = p + 1, n3 = n * n * n;
+          bc_xyz      = (double *)calloc(3 * (size_t)L->n_dofs, sizeof(double));
+          for (uint32_t c = 0; c < L->n_cells; ++c)
+            for (int e = 0; e < 27; ++e)
+              {
+                const int      cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+                const int      nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
+                const uint32_t base = L->idx27_plain[27 * (size_t)c + e];
+                for (int oz = 0; oz < nz; ++oz)
+                  for (int oy = 0; oy < ny; ++oy)
+                    for (int ox = 0; ox < nx; ++ox)
+                      {
+                        const int i = cx == 0 ? 0 : (cx == 2 ? p : 1 + ox), j = cy == 0 ? 0 : (cy == 2 ? p : 1 + oy),
+                                  k = cz == 0 ? 0 : (cz == 2 ? p : 1 + oz), i3 = (k * n + j) * n + i;
+                        const uint32_t dof = base + (uint32_t)((oz * ny + oy) * nx + ox);
+                        for (int d = 0; d < 3; ++d)
+                          bc_xyz[3 * (size_t)dof + d] = L->cell_nodes[(3 * (size_t)c + d) * n3 + i3];
+                      }
+              }
+        }
       for (uint32_t i = 0; i < L->n_constrained; ++i)
         {
           const uint32_t dof = L->constrained[i];
           double         x[3];
-          grid_to_xyz(P, L, L->dof_grid[dof], x);
+          if (bc_xyz)
+            memcpy(x, bc_xyz + 3 * (size_t)dof, sizeof(x));
+          else
+            grid_to_xyz(P, L, L->dof_grid[dof], x);
           const double v = u_exact(x[0], x[1], x[2]);
           if (v != 0.0)
             {
@@ -819,6 +866,7 @@ static orc_problem *create_impl(int p, const int roots[3], double origin, double
             }
         }
       P->bc_count[l] = cnt;
+      free(bc_xyz);
       set_bc(P, l, P->solution[l], 0);                      /* multigrid_solver.h:257-259 */
       compute_rhs(P, L, P->rhs[l], P->solution[l]);         /* :261 */
       /* V-cycle vectors and smoother (multigrid_solver.h:168-170, 269-289) */
@@ -863,6 +911,115 @@ static orc_problem *create_impl(int p, const int roots[3], double origin, double
     }
   return P;
 }
+
+/* The same solver on a mesh the caller describes by tables -- what deal.II's DoFHandler / MatrixFree would
+ * hand over: per level the compressed index tables, the constrained DoFs, the children of every cell of the
+ * next coarser level, a run-independent id per DoF (start vector of the eigenvalue estimate), the number of
+ * cells around each of the 27 entities of every cell (transfer weights) and the physical Gauss-Lobatto points
+ * of every cell, from which the mapping data and the merged coefficient are computed HERE
+ * (evaluate_coefficient, laplace_operator.h:388-430).  Used for the multi-block shell of poisson_shell, whose
+ * mesh generator lives in the product's provider (mgx_cube_create_shell); all arithmetic stays the oracle's. */
+orc_problem *orc_create_from_mesh(int p, int n_levels, const orc_mesh_level *mesh, int degree, int n_cycles, int vfloat,
+                                  int problem)
+{
+  g_problem = problem;
+#ifdef _OPENMP
+  omp_set_num_threads(effective_threads());
+#endif
+  if (p < 1 || p > 9 || n_levels < 1 || !mesh)
+    return NULL;
+  orc_problem *P = (orc_problem *)calloc(1, sizeof(orc_problem));
+  P->p           = p;
+  P->n_subdiv    = 1;
+  P->roots[0] = P->roots[1] = P->roots[2] = 1;
+  P->geometry = ORC_GEOM_TABLES;
+  P->problem  = problem;
+  P->n_levels = n_levels;
+  P->degree   = degree;
+  P->n_cycles = n_cycles;
+  P->vfloat   = vfloat;
+  basis_init(&P->basis, p);
+  P->Bd = malloc(sizeof(basis_d));
+  P->Bf = malloc(sizeof(basis_f));
+  basis_init_d((basis_d *)P->Bd, &P->basis);
+  basis_init_f((basis_f *)P->Bf, &P->basis);
+  P->levels = (orc_level *)calloc(P->n_levels, sizeof(orc_level));
+  const int n3 = (p + 1) * (p + 1) * (p + 1);
+  for (int l = 0; l < n_levels; ++l)
+    {
+      orc_level            *L = &P->levels[l];
+      const orc_mesh_level *m = &mesh[l];
+      L->level         = l;
+      L->N             = 0;
+      L->n_cells       = m->n_cells;
+      L->n_dofs        = m->n_dofs;
+      L->n_constrained = m->n_constrained;
+      L->h             = 1.;
+#define ORC_DUP(dst, src, type, count)                                \
+  do                                                                  \
+    {                                                                 \
+      (dst) = (type *)malloc(sizeof(type) * ((size_t)(count) + 1));   \
+      memcpy((dst), (src), sizeof(type) * (size_t)(count));           \
+    }                                                                 \
+  while (0)
+      ORC_DUP(L->idx27, m->idx27, uint32_t, 27 * (size_t)m->n_cells);
+      ORC_DUP(L->idx27_plain, m->idx27_plain, uint32_t, 27 * (size_t)m->n_cells);
+      ORC_DUP(L->constrained, m->constrained, uint32_t, m->n_constrained);
+      ORC_DUP(L->dof_grid, m->dof_gid, uint32_t, m->n_dofs);
+      ORC_DUP(L->ent_mult, m->ent_mult, uint8_t, 27 * (size_t)m->n_cells);
+      ORC_DUP(L->cell_nodes, m->cell_nodes, double, 3 * (size_t)n3 * m->n_cells);
+      if (l > 0)
+        ORC_DUP(L->children_of_parent, m->children, uint32_t, 8 * (size_t)mesh[l - 1].n_cells);
+#undef ORC_DUP
+      /* cell colours for the OpenMP loops: greedy, two cells conflict if they share an entity */
+      {
+        uint64_t *used   = (uint64_t *)calloc(L->n_dofs, sizeof(uint64_t));
+        uint8_t  *colour = (uint8_t *)malloc(L->n_cells);
+        uint32_t  cnt[64] = {0};
+        int       nco     = 0;
+        for (uint32_t c = 0; c < L->n_cells; ++c)
+          {
+            uint64_t mask = 0;
+            for (int e = 0; e < 27; ++e)
+              {
+                const int inner = (e % 3 == 1) + ((e / 3) % 3 == 1) + (e / 9 == 1);
+                if (inner == 3 || (inner > 0 && p == 1))
+                  continue;
+                mask |= used[L->idx27_plain[27 * (size_t)c + e]];
+              }
+            int col = 0;
+            while (col < 63 && ((mask >> col) & 1u))
+              ++col;
+            colour[c] = (uint8_t)col;
+            cnt[col]++;
+            if (col + 1 > nco)
+              nco = col + 1;
+            for (int e = 0; e < 27; ++e)
+              {
+                const int inner = (e % 3 == 1) + ((e / 3) % 3 == 1) + (e / 9 == 1);
+                if (inner == 3 || (inner > 0 && p == 1))
+                  continue;
+                used[L->idx27_plain[27 * (size_t)c + e]] |= 1ull << col;
+              }
+          }
+        L->n_colours       = nco;
+        L->colour_start[0] = 0;
+        for (int i = 0; i < nco; ++i)
+          L->colour_start[i + 1] = L->colour_start[i] + cnt[i];
+        L->colour_cells = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)L->n_cells);
+        uint32_t pos[64];
+        for (int i = 0; i < nco; ++i)
+          pos[i] = L->colour_start[i];
+        for (uint32_t c = 0; c < L->n_cells; ++c)
+          L->colour_cells[pos[colour[c]]++] = c;
+        free(used);
+        free(colour);
+      }
+      level_geometry(P, L);
+    }
+  return finish_problem(P);
+}
+
 
 void orc_destroy(orc_problem *P)
 {
@@ -1212,9 +1369,9 @@ double orc_l2_error(orc_problem *P, int level)
         sweep_d(n, 0, B->S, u, t0, 0);
         sweep_d(n, 1, B->S, t0, u, 0);
         sweep_d(n, 2, B->S, u, t0, 0);
-        const double x0 = P->origin + L->h * L->cell_coords[3 * (size_t)c],
-                     y0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 1],
-                     z0 = P->origin + L->h * L->cell_coords[3 * (size_t)c + 2];
+        const double x0 = L->cell_coords ? P->origin + L->h * L->cell_coords[3 * (size_t)c] : 0.,
+                     y0 = L->cell_coords ? P->origin + L->h * L->cell_coords[3 * (size_t)c + 1] : 0.,
+                     z0 = L->cell_coords ? P->origin + L->h * L->cell_coords[3 * (size_t)c + 2] : 0.;
         for (int k = 0, q = 0; k < n; ++k)
           for (int j = 0; j < n; ++j)
             for (int i = 0; i < n; ++i, ++q)

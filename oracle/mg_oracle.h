@@ -48,6 +48,7 @@ orc_problem *orc_create_box(int p, int sx, int sy, int sz, int n_refine, int deg
 #define ORC_GEOM_CARTESIAN 0
 #define ORC_GEOM_SHEARED 1
 #define ORC_GEOM_SHELL_SECTOR 2
+#define ORC_GEOM_TABLES 3 /* cell geometry given by the caller's node tables (orc_create_from_mesh) */
 #define ORC_PROBLEM_CUBE 0
 #define ORC_PROBLEM_SHELL 1
 orc_problem *orc_create_mapped(int p, int sx, int sy, int sz, double origin, double h0, int n_refine, int degree,
@@ -119,6 +120,21 @@ void orc_vcycle_apply(orc_problem *P, double *dst, const double *src);
  * level >= 1, 4 doubles {error start, residual start, residual end, error end}
  * (only meaningful with do_analyze).  Returns the V-cycle reduction rate. */
 double orc_solve(orc_problem *P, int do_analyze, double *trace);
+/* A mesh described by tables instead of the built-in structured box (multi-block meshes such as the
+ * hyper_shell of poisson_shell): one entry per level, all arrays copied.  children: [n_cells(level-1)*8]
+ * cells of this level (NULL on level 0); dof_gid: run-independent id per DoF; ent_mult: cells around
+ * each of the 27 entities of every cell; cell_nodes: [n_cells][3][(p+1)^3] physical Gauss-Lobatto points.
+ * The index tables must satisfy the entity-contiguity contract of laplace_operator.h:272-340. */
+typedef struct
+{
+  uint32_t        n_cells, n_dofs, n_constrained;
+  const uint32_t *idx27, *idx27_plain, *constrained, *children, *dof_gid;
+  const uint8_t  *ent_mult;
+  const double   *cell_nodes;
+} orc_mesh_level;
+orc_problem *orc_create_from_mesh(int p, int n_levels, const orc_mesh_level *mesh, int degree, int n_cycles, int vfloat,
+                                  int problem);
+
 /* MultigridSolver::solve_cg (multigrid_solver.h:483-493) */
 int orc_solve_cg(orc_problem *P, double *reduction);
 /* residual norms of that solve: [0] start, [k] after iteration k; returns their number */

@@ -59,7 +59,7 @@ def test_mapped_multigrid_solver(ctx, geometry, problem):
     l = cube.max_level
     for lev in range(cube.n_levels):
         gi, oi = solver.smoother(lev).info(), orc.cheb_info(lev)
-        assert gi["degree"] == oi["degree"] and gi["cg_its"] == oi["cg_its"]
+        assert gi["degree"] == oi["degree"] and abs(gi["cg_its"] - oi["cg_its"]) <= (2 if lev == 0 else 0)
         assert gi["lambda_max"] == pytest.approx(oi["lambda_max"], rel=1e-8)
     x = cube.seeded_vector(l, 5)
     src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
@@ -147,3 +147,58 @@ def test_colour_by_colour_launches_of_the_general_branch(monkeypatch, geometry, 
     orc.close()
     c.close()
     c_atomic.close()
+
+
+@pytest.mark.parametrize("n_coarse,p,nr,problem", [(6, 4, 2, "shell"), (12, 4, 1, "shell"), (6, 2, 3, "shell"), (12, 3, 2, "cube"),
+                                                   (6, 5, 1, "shell"), (6, 1, 3, "cube")])
+def test_hyper_shell_solver_against_oracle(ctx, n_coarse, p, nr, problem):
+    """The mesh of poisson_shell itself -- GridGenerator::hyper_shell(0, 0.5, 1.0, 6 | 12) + refine_global
+    (poisson_shell/program.cc:425-431): operator, diagonal, smoother parameters, transfers, V-cycle, FMG and
+    PCG on the device against the oracle assembled on the same mesh tables (tests/test_hyper_shell.py pins
+    the tables).  Three blocks meet at the radial edges through the polyhedron's vertices: the transfer
+    runs with owner weights there, the oracle with 1/multiplicity -- the same operator."""
+    cube = mg.Cube(p, n_refine=nr, shell=n_coarse, problem=problem)
+    orc = Oracle(p, degree=3, n_cycles=1, mesh=cube, problem=problem)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    for l in range(cube.n_levels):
+        A = solver.matrix_dp(l)
+        x, b = cube.seeded_vector(l, 1), cube.seeded_vector(l, 2)
+        src, rhs, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=b), ctx.vector(x.size)
+        A.vmult(dst, src)
+        assert rel(dst.download(), orc.vmult(l, x)) < 1e-12
+        A.vmult_residual(rhs, src, dst)
+        assert rel(dst.download(), orc.vmult_residual(l, b, x)) < 1e-12
+        assert rel(A.get_matrix_diagonal_inverse().download(), orc.inv_diag(l)) < 1e-12
+        gi, oi = solver.smoother(l).info(), orc.cheb_info(l)
+        # (level 0: the eigenvalue CG runs to a 1e-10 residual -- 75 iterations on the 12-cell mesh with the 1e6
+        # contrast -- and stops an iteration earlier or later with the last bits of either implementation; the
+        # levels above run a fixed 15 iterations)
+        assert gi["degree"] == oi["degree"] and abs(gi["cg_its"] - oi["cg_its"]) <= (2 if l == 0 else 0)
+        assert gi["lambda_max"] == pytest.approx(oi["lambda_max"], rel=1e-8)
+        if l > 0:
+            T = mg.Transfer(solver.matrix_dp(l - 1), A, cube.children(l), cube.prolong_1d())
+            xc = cube.seeded_vector(l - 1, 3)
+            cv, fv = ctx.vector(xc.size, data=xc), ctx.vector(x.size, data=x)
+            T.prolongate_and_add(fv, cv)
+            assert rel(fv.download(), orc.prolongate(l, xc, fine=x, with_bc=True)) < 1e-13
+            cv2 = ctx.vector(xc.size, data=xc)
+            T.restrict_and_add(cv2, src)
+            assert rel(cv2.download(), orc.restrict_and_add(l, xc, x, with_bc=True)) < 1e-12
+            T.clear()
+    lmax = cube.max_level
+    x = cube.seeded_vector(lmax, 5)
+    src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
+    for _ in range(2):
+        solver.vmult(dst, src)
+        assert rel(dst.download(), orc.vcycle(x)) < 1e-9
+    rate, trace = solver.solve(True)
+    orate, otrace = orc.solve(True)
+    assert rate == pytest.approx(orate, rel=1e-6)
+    # (one V-cycle per level reduces the residual of the 1e6-contrast problem by 0.15 only: the FMG iterate
+    # carries the 1e-9 differences of the cycles amplified by the conditioning of the operator)
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=2e-6)
+    assert_same_cg(solver, orc)
+    assert solver.compute_l2_error() == pytest.approx(orc.l2_error(), rel=2e-6)
+    solver.close()
+    cube.close()
+    orc.close()
