@@ -202,3 +202,23 @@ def test_hyper_shell_solver_against_oracle(ctx, n_coarse, p, nr, problem):
     solver.close()
     cube.close()
     orc.close()
+
+
+def test_poisson_shell_harness_runs():
+    """tools/poisson_shell.py (poisson_shell/program.cc): command line, cycle protocol (6- and 12-cell shells in
+    turn), the program's output lines and table"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "poisson_shell.py"), "2", "4000", "--cycles", "0:6"],
+                         cwd=root, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    text = out.stdout.decode()
+    assert "Testing FE_Q<3>(2)" in text and "Max size reached, terminating." in text
+    for n_dofs in (78, 150, 490, 970, 3474):  # cycles 0 .. 4: (6 | 12) N^2 + 2 points per sphere, N + 1 spheres
+        assert "Best timings for ndof = %d " % n_dofs in text and "L2 error with ndof = %d " % n_dofs in text
+    assert "Number of degrees of freedom: 6930" in text  # cycle 5 exceeds the maximum size
+    rows = [l.split() for l in text.splitlines() if l[:1].isdigit() and len(l.split()) == 11]
+    assert [int(r[0]) for r in rows] == [6, 12, 48, 96, 384]
+    assert all(int(r[9]) < 60 for r in rows)  # PCG iterations
