@@ -37,6 +37,17 @@ namespace
 
   // ------------------------------------------------------------------------------------------
   // device data
+  // Even-odd form of an n x n matrix M with M[q][i] = s M[n-1-q][n-1-i] (s = +1: values of a
+  // symmetric basis in symmetric points; s = -1: derivatives), H = n / 2:
+  //   eo[q H + i] = { (M[q][i] + M[n-1-q][i]) / 2, (M[q][i] - M[n-1-q][i]) / 2 }   (q, i < H)
+  //   mrow[i] = M[H][i], mcol[q] = M[q][H], mm = M[H][H]                           (n odd)
+  template <typename T>
+  struct EOLine
+  {
+    T eo[2 * (kMaxN / 2) * (kMaxN / 2)];
+    T mrow[kMaxN / 2], mcol[kMaxN / 2], mm;
+  };
+
   template <typename T>
   struct DGConst
   {
@@ -44,6 +55,15 @@ namespace
     T D[kMaxN * kMaxN];  // D[q*n+r]   derivative of the Gauss-point Lagrange basis in the Gauss points
     T E[kMaxN * kMaxN];  // E[i*n+e]   eigenvector e of (Laplace + penalty, mass) in the element basis
     T St[kMaxN * kMaxN], Dt[kMaxN * kMaxN], Et[kMaxN * kMaxN]; // their transposes (mul() reads these)
+    // even-odd form of S, St (symmetric under reversal of both indices) and D, Dt (antisymmetric),
+    // matrix_vector_kernel.h:47-113; see mul_eo below
+    EOLine<T> eoS, eoSt, eoD, eoDt;
+    // eigenvectors sorted by parity (even ones first): E[n-1-i][e] = +-E[i][e].  With H = n / 2, Ne = n - H
+    // even and No = H odd ones: epair[i No + k] = {E[i][k], E[i][Ne + k]} (i < H, k < No),
+    // elast[i] = E[i][Ne - 1] and emid[e] = E[H][e] (n odd).  (eo_e: the host found the parities pure; it refuses
+    // the operator otherwise -- a run-time choice between the two forms in the kernel costs 10-15 %)
+    T   epair[2 * (kMaxN / 2) * (kMaxN / 2)], elast[kMaxN / 2], emid[kMaxN / 2 + 1];
+    int eo_e;
     T w[kMaxN];          // Gauss weights on [0,1]
     T b[2][kMaxN], g[2][kMaxN];   // Gauss-point Lagrange basis at x = 0 / 1: value, derivative
     T fb[2][kMaxN], fg[2][kMaxN]; // element basis at x = 0 / 1: value, derivative
@@ -172,6 +192,89 @@ namespace
     mul_t<N, T>(Mt, in, out);
   }
 
+  // The same product, out[i] = sum_q M[q][i] in[q], for a matrix with the reversal symmetry of sign SIGN
+  // in even-odd form (the reference's apply_1d_matvec_kernel, matrix_vector_kernel.h:47-113): the input
+  // is split into xe = in[q] + in[n-1-q] and xo = in[q] - in[n-1-q]; u = ce^T xe and v = co^T xo are two
+  // independent half-size products (one 2-vector FMA per entry: v_pk_fma_f32 in fp32), out[i] = u + v,
+  // out[n-1-i] = SIGN (u - v).  n^2 multiply-adds become n^2 / 2 + n additions.
+  template <int N, typename T, int SIGN>
+  __device__ __forceinline__ void mul_eo(const EOLine<T> &A, const T (&in)[N], T (&out)[N])
+  {
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int H = N / 2;
+    T2            x[H > 0 ? H : 1];
+#pragma unroll
+    for (int q = 0; q < H; ++q)
+      x[q] = T2{in[q] + in[N - 1 - q], in[q] - in[N - 1 - q]};
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+      {
+        T2 acc = T2{A.eo[2 * i], A.eo[2 * i + 1]} * x[0];
+#pragma unroll
+        for (int q = 1; q < H; ++q)
+          acc = __builtin_elementwise_fma(T2{A.eo[2 * (q * H + i)], A.eo[2 * (q * H + i) + 1]}, x[q], acc);
+        if (N % 2)
+          acc[0] = fma(A.mrow[i], in[H], acc[0]);
+        out[i]         = acc[0] + acc[1];
+        out[N - 1 - i] = SIGN > 0 ? acc[0] - acc[1] : acc[1] - acc[0];
+      }
+    if (N % 2)
+      {
+        T m = SIGN > 0 ? A.mm * in[H] : T(0);
+#pragma unroll
+        for (int q = 0; q < H; ++q)
+          m = fma(A.mcol[q], SIGN > 0 ? x[q][0] : x[q][1], m);
+        out[H] = m;
+      }
+  }
+
+  // which form a (degree, number type) instantiation uses.  In fp32 the dense product already runs on
+  // 2-vectors (13 packed FMAs per line at p = 4 against 12 instructions plus the additions of the
+  // even-odd one): the gain starts small and grows with the degree; fp64 has no packed FMA.
+  template <int N, typename T>
+  struct LineForm
+  {
+#ifdef MGX_DG_EVEN_ODD
+    static constexpr bool eo = MGX_DG_EVEN_ODD != 0;
+#else
+    static constexpr bool eo = N >= 5; // measured (merged Chebyshev step, MI355X): fp32 p = 3 -2 %, p = 4 +4 %, p = 6 +32 %, p = 8 +60 %; fp64 p = 4 +13 %, p = 8 +118 %
+#endif
+  };
+  // the four sweeps of the kernel: values S / S^T (symmetric), derivative D / D^T (antisymmetric);
+  // in (mul_t convention) out[i] = sum_q M[q][i] in[q]
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_S(const DGConst<T> *__restrict__ c, const T (&in)[N], T (&out)[N]) // mul_t(c->S)
+  {
+    if constexpr (LineForm<N, T>::eo)
+      mul_eo<N, T, 1>(c->eoS, in, out);
+    else
+      mul_t<N, T>(c->S, in, out);
+  }
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_St(const DGConst<T> *__restrict__ c, const T (&in)[N], T (&out)[N]) // mul(c->St)
+  {
+    if constexpr (LineForm<N, T>::eo)
+      mul_eo<N, T, 1>(c->eoSt, in, out);
+    else
+      mul_t<N, T>(c->St, in, out);
+  }
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_D(const DGConst<T> *__restrict__ c, const T (&in)[N], T (&out)[N]) // mul_t(c->D)
+  {
+    if constexpr (LineForm<N, T>::eo)
+      mul_eo<N, T, -1>(c->eoD, in, out);
+    else
+      mul_t<N, T>(c->D, in, out);
+  }
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_Dt(const DGConst<T> *__restrict__ c, const T (&in)[N], T (&out)[N]) // mul(c->Dt)
+  {
+    if constexpr (LineForm<N, T>::eo)
+      mul_eo<N, T, -1>(c->eoDt, in, out);
+    else
+      mul_t<N, T>(c->Dt, in, out);
+  }
+
   template <int N, typename T>
   __device__ __forceinline__ T dot_line(const T *__restrict__ v, const T (&in)[N])
   {
@@ -190,6 +293,69 @@ namespace
       out[i] = in[i];
   }
 
+  // q[e] = sum_i E[i][e] r[i] (to the eigenvector basis) and r[i] = sum_e E[i][e] q[e] (back): every
+  // eigenvector is even or odd, so the even ones see r[i] + r[n-1-i] only, the odd ones r[i] - r[n-1-i]
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_E(const DGConst<T> *__restrict__ c, const T (&r)[N], T (&q)[N])
+  {
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int H = N / 2, Ne = N - H, No = H;
+    if constexpr (!LineForm<N, T>::eo)
+      return mul_t<N, T>(c->E, r, q);
+    T2 x[H > 0 ? H : 1];
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+      x[i] = T2{r[i] + r[N - 1 - i], r[i] - r[N - 1 - i]};
+#pragma unroll
+    for (int k = 0; k < No; ++k)
+      {
+        T2 acc = T2{c->epair[2 * k], c->epair[2 * k + 1]} * x[0];
+#pragma unroll
+        for (int i = 1; i < H; ++i)
+          acc = __builtin_elementwise_fma(T2{c->epair[2 * (i * No + k)], c->epair[2 * (i * No + k) + 1]}, x[i], acc);
+        if (N % 2)
+          acc[0] = fma(c->emid[k], r[H], acc[0]);
+        q[k]      = acc[0];
+        q[Ne + k] = acc[1];
+      }
+    if (N % 2)
+      {
+        T m = c->emid[Ne - 1] * r[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+          m = fma(c->elast[i], x[i][0], m);
+        q[Ne - 1] = m;
+      }
+  }
+  template <int N, typename T>
+  __device__ __forceinline__ void mul_Et(const DGConst<T> *__restrict__ c, const T (&q)[N], T (&r)[N])
+  {
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int H = N / 2, Ne = N - H, No = H;
+    if constexpr (!LineForm<N, T>::eo)
+      return mul_t<N, T>(c->Et, q, r);
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+      {
+        T2 acc = T2{c->epair[2 * (i * No)], c->epair[2 * (i * No) + 1]} * T2{q[0], q[Ne]};
+#pragma unroll
+        for (int k = 1; k < No; ++k)
+          acc = __builtin_elementwise_fma(T2{c->epair[2 * (i * No + k)], c->epair[2 * (i * No + k) + 1]}, T2{q[k], q[Ne + k]}, acc);
+        if (N % 2)
+          acc[0] = fma(c->elast[i], q[Ne - 1], acc[0]);
+        r[i]         = acc[0] + acc[1];
+        r[N - 1 - i] = acc[0] - acc[1];
+      }
+    if (N % 2)
+      {
+        T m = c->emid[0] * q[0];
+#pragma unroll
+        for (int e = 1; e < Ne; ++e)
+          m = fma(c->emid[e], q[e], m);
+        r[H] = m;
+      }
+  }
+
   // block-Jacobi in the eigenvector basis on the x-lines held in registers:  r <- T D^-1 T^T r
   // (JacobiTransformed::do_local_operation, laplace_operator_dg.h:2086-2097).  U is scratch.
   template <int P, typename T>
@@ -201,39 +367,39 @@ namespace
     T             q[N];
     if (active)
       {
-        mul_t<N>(c->E, r, q); // out[e] = sum_i E[i][e] r[i]
+        mul_E<N>(c, r, q); // out[e] = sum_i E[i][e] r[i]
         st_line<N>(U, (b * N + a) * PX, 1, q);
       }
     __syncthreads();
     if (active)
       {
         ld_line<N>(U, b * N * PX + a, PX, r);
-        mul_t<N>(c->E, r, q);
+        mul_E<N>(c, r, q);
         st_line<N>(U, b * N * PX + a, PX, q);
       }
     __syncthreads();
     if (active)
       {
         ld_line<N>(U, b * PX + a, N * PX, r);
-        mul_t<N>(c->E, r, q);
+        mul_E<N>(c, r, q);
 #pragma unroll
         for (int k = 0; k < N; ++k)
           q[k] *= inv_diag[(k * N + b) * N + a];
-        mul<N>(c->Et, q, r); // out[i] = sum_e E[i][e] q[e]
+        mul_Et<N>(c, q, r); // out[i] = sum_e E[i][e] q[e]
         st_line<N>(U, b * PX + a, N * PX, r);
       }
     __syncthreads();
     if (active)
       {
         ld_line<N>(U, b * N * PX + a, PX, q);
-        mul<N>(c->Et, q, r);
+        mul_Et<N>(c, q, r);
         st_line<N>(U, b * N * PX + a, PX, r);
       }
     __syncthreads();
     if (active)
       {
         ld_line<N>(U, (b * N + a) * PX, 1, q);
-        mul<N>(c->Et, q, r);
+        mul_Et<N>(c, q, r);
       }
   }
 
@@ -321,7 +487,7 @@ namespace
         for (int i = 0; i < N; ++i)
           xs[i] = src[cbase + (b * N + a) * N + i];
         if constexpr (TYPE != MGX_DG_GAUSS)
-          mul<N>(c->St, xs, u);
+          mul_St<N>(c, xs, u);
         else
           copy_line<N>(xs, u);
         st_line<N>(U, (b * N + a) * PX, 1, u);
@@ -335,7 +501,7 @@ namespace
           {
             T u[N], v[N];
             ld_line<N>(U, b * N * PX + a, PX, u);
-            mul<N>(c->St, u, v);
+            mul_St<N>(c, u, v);
             st_line<N>(U, b * N * PX + a, PX, v);
           }
         __syncthreads();
@@ -348,12 +514,12 @@ namespace
         ld_line<N>(U, b * PX + a, N * PX, u);
         if constexpr (TYPE != MGX_DG_GAUSS)
           {
-            mul<N>(c->St, u, v);
+            mul_St<N>(c, u, v);
             st_line<N>(U, b * PX + a, N * PX, v);
           }
         else
           copy_line<N>(u, v);
-        mul<N>(c->Dt, v, u);
+        mul_Dt<N>(c, v, u);
         st_line<N>(GZ, b * PX + a, N * PX, u);
         To[4] = dot_line<N>(c->b[0], v);
         To[5] = dot_line<N>(c->b[1], v);
@@ -367,7 +533,7 @@ namespace
       {
         T u[N], v[N];
         ld_line<N>(U, b * N * PX + a, PX, u);
-        mul<N>(c->Dt, u, v);
+        mul_Dt<N>(c, u, v);
         st_line<N>(GY, b * N * PX + a, PX, v);
         To[2] = dot_line<N>(c->b[0], u);
         To[3] = dot_line<N>(c->b[1], u);
@@ -452,7 +618,7 @@ namespace
                   T  u[N], v[N];
                   T *arr = F + ((L / N) / 2 * 3 + (L / N) % 2) * FS + (L % N) * PX;
                   ld_line<N>(arr, 0, 1, u);
-                  mul<N>(c->St, u, v);
+                  mul_St<N>(c, u, v);
                   st_line<N>(arr, 0, 1, v);
                 }
             __syncthreads();
@@ -462,7 +628,7 @@ namespace
                   T  u[N], v[N];
                   T *arr = F + ((L / N) / 2 * 3 + (L / N) % 2) * FS + (L % N);
                   ld_line<N>(arr, 0, PX, u);
-                  mul<N>(c->St, u, v);
+                  mul_St<N>(c, u, v);
                   st_line<N>(arr, 0, PX, v);
                 }
             __syncthreads();
@@ -498,8 +664,8 @@ namespace
               T         st[N], wj[N], ds[N], dj[N];
               ld_line<N>(E0(s), l * PX, 1, st);
               ld_line<N>(E1(s), l * PX, 1, wj);
-              mul<N>(c->Dt, st, ds);
-              mul_t<N>(c->D, wj, dj);
+              mul_Dt<N>(c, st, ds);
+              mul_D<N>(c, wj, dj);
               const T wl = c->w[l] * c->fw[d];
 #pragma unroll
               for (int i = 0; i < N; ++i)
@@ -517,8 +683,8 @@ namespace
               ld_line<N>(E0(s), l, PX, st);
               ld_line<N>(E1(s), l, PX, wj);
               ld_line<N>(AT(s), l, PX, v);
-              mul<N>(c->Dt, st, ds);
-              mul_t<N>(c->D, wj, dj);
+              mul_Dt<N>(c, st, ds);
+              mul_D<N>(c, wj, dj);
               const T wl = c->w[l] * c->fw[d];
 #pragma unroll
               for (int i = 0; i < N; ++i)
@@ -555,7 +721,7 @@ namespace
       {
         T u[N], gx[N], gy[N], gz[N], o[N];
         ld_line<N>(U, (b * N + a) * PX, 1, u);
-        mul<N>(c->Dt, u, gx);
+        mul_Dt<N>(c, u, gx);
         ld_line<N>(GY, (b * N + a) * PX, 1, gy);
         ld_line<N>(GZ, (b * N + a) * PX, 1, gz);
         const T wab = c->w[a] * c->w[b];
@@ -572,7 +738,7 @@ namespace
           }
         st_line<N>(GY, (b * N + a) * PX, 1, gy);
         st_line<N>(GZ, (b * N + a) * PX, 1, gz);
-        mul_t<N>(c->D, gx, o);
+        mul_D<N>(c, gx, o);
         add_faces(0, o);
         st_line<N>(U, (b * N + a) * PX, 1, o);
       }
@@ -583,7 +749,7 @@ namespace
         T fy[N], o[N], u[N];
         ld_line<N>(GY, b * N * PX + a, PX, fy);
         ld_line<N>(U, b * N * PX + a, PX, u);
-        mul_t<N>(c->D, fy, o);
+        mul_D<N>(c, fy, o);
         add_faces(1, o);
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -597,14 +763,14 @@ namespace
         T fz[N], o[N], u[N];
         ld_line<N>(GZ, b * PX + a, N * PX, fz);
         ld_line<N>(U, b * PX + a, N * PX, u);
-        mul_t<N>(c->D, fz, o);
+        mul_D<N>(c, fz, o);
         add_faces(2, o);
 #pragma unroll
         for (int i = 0; i < N; ++i)
           o[i] += u[i];
         if constexpr (TYPE != MGX_DG_GAUSS)
           {
-            mul_t<N>(c->S, o, u);
+            mul_S<N>(c, o, u);
             st_line<N>(U, b * PX + a, N * PX, u);
           }
         else
@@ -617,7 +783,7 @@ namespace
           {
             T u[N], v[N];
             ld_line<N>(U, b * N * PX + a, PX, u);
-            mul_t<N>(c->S, u, v);
+            mul_S<N>(c, u, v);
             st_line<N>(U, b * N * PX + a, PX, v);
           }
         __syncthreads();
@@ -629,7 +795,7 @@ namespace
         T u[N];
         ld_line<N>(U, (b * N + a) * PX, 1, u);
         if constexpr (TYPE != MGX_DG_GAUSS)
-          mul_t<N>(c->S, u, y);
+          mul_S<N>(c, u, y);
         else
           copy_line<N>(u, y);
       }
@@ -906,6 +1072,7 @@ namespace
   {
     int                 n = 0;
     std::vector<double> xq, wq, S, SD, D, E, lambda;
+    bool                e_parity = false; // eigenvectors sorted even first / odd behind (see build_1d)
     double              b[2][kMaxN], g[2][kMaxN], fb[2][kMaxN], fg[2][kMaxN];
     double              hderiv = 0;
     std::vector<double> P1; // [i*n+q]: values in the Gauss-Lobatto nodes -> coefficients of the element basis
@@ -1075,6 +1242,45 @@ namespace
             s -= L[k * n + i] * h.E[k * n + e];
           h.E[i * n + e] = s / L[i * n + i];
         }
+    // Eigenvectors even ones first, odd ones behind (each group by ascending eigenvalue): the cell kernel
+    // applies E in even-odd form (mul_E).  The operator is invariant under x -> 1 - x, so every
+    // eigenvector of a simple eigenvalue has a parity; a pair that does not (degenerate eigenvalues) keeps
+    // the ascending order and the dense product.
+    {
+      std::vector<int> parity(n, 0);
+      bool             pure = true;
+      for (int e = 0; e < n; ++e)
+        {
+          double even = 0, odd = 0, nrm = 0;
+          for (int i = 0; i < n; ++i)
+            {
+              even += std::fabs(h.E[i * n + e] - h.E[(n - 1 - i) * n + e]);
+              odd += std::fabs(h.E[i * n + e] + h.E[(n - 1 - i) * n + e]);
+              nrm += std::fabs(h.E[i * n + e]);
+            }
+          parity[e] = even <= 1e-9 * nrm ? 1 : (odd <= 1e-9 * nrm ? -1 : 0);
+          pure      = pure && parity[e] != 0;
+        }
+      const int n_even = (int)std::count(parity.begin(), parity.end(), 1);
+      h.e_parity = pure && n_even == n - n / 2;
+      if (h.e_parity)
+        {
+          std::vector<int> order;
+          for (int pass = 1; pass >= -1; pass -= 2)
+            for (int e = 0; e < n; ++e)
+              if (parity[e] == pass)
+                order.push_back(e);
+          std::vector<double> E2(n * n), l2(n);
+          for (int k = 0; k < n; ++k)
+            {
+              l2[k] = h.lambda[order[k]];
+              for (int i = 0; i < n; ++i)
+                E2[i * n + k] = h.E[i * n + order[k]];
+            }
+          h.E.swap(E2);
+          h.lambda.swap(l2);
+        }
+    }
     // 1D forms in the eigenvector basis
     h.lt.assign(n, 0);
     h.ct.assign(n, 0);
@@ -1197,6 +1403,44 @@ namespace
           c.Dt[r * n + q] = (T)h.D[q * n + r];
           c.Et[r * n + q] = (T)h.E[q * n + r];
         }
+    // even-odd tables (the symmetry itself is checked when the operator is created)
+    auto eo_fill = [&](EOLine<T> &e, auto M) { // M(q, i)
+      const int H = n / 2;
+      for (int q = 0; q < H; ++q)
+        for (int i = 0; i < H; ++i)
+          {
+            e.eo[2 * (q * H + i)]     = (T)(0.5 * (M(q, i) + M(n - 1 - q, i)));
+            e.eo[2 * (q * H + i) + 1] = (T)(0.5 * (M(q, i) - M(n - 1 - q, i)));
+          }
+      if (n % 2)
+        {
+          for (int i = 0; i < H; ++i)
+            {
+              e.mrow[i] = (T)M(H, i);
+              e.mcol[i] = (T)M(i, H);
+            }
+          e.mm = (T)M(H, H);
+        }
+    };
+    {
+      const int H = n / 2, Ne = n - H, No = H;
+      c.eo_e      = h.e_parity ? 1 : 0;
+      for (int i = 0; i < H; ++i)
+        {
+          for (int k = 0; k < No; ++k)
+            {
+              c.epair[2 * (i * No + k)]     = (T)h.E[i * n + k];
+              c.epair[2 * (i * No + k) + 1] = (T)h.E[i * n + Ne + k];
+            }
+          c.elast[i] = (T)h.E[i * n + Ne - 1];
+        }
+      for (int e = 0; e < Ne; ++e)
+        c.emid[e] = (n % 2) ? (T)h.E[H * n + e] : (T)0;
+    }
+    eo_fill(c.eoS, [&](int q, int i) { return h.S[q * n + i]; });
+    eo_fill(c.eoSt, [&](int q, int i) { return h.S[i * n + q]; });
+    eo_fill(c.eoD, [&](int q, int i) { return h.D[q * n + i]; });
+    eo_fill(c.eoDt, [&](int q, int i) { return h.D[i * n + q]; });
     for (int i = 0; i < n; ++i)
       {
         c.w[i] = (T)h.wq[i];
@@ -1570,6 +1814,24 @@ int mgx_dg_operator_create(mgx_context_t ctx, const mgx_dg_operator_desc *desc, 
     status = build_geometry(desc->jacobian, desc->degree, op->g, why);
   if (status != MGX_OK)
     return dg_fail(status, "mgx_dg_operator_create: " + why);
+  {
+    // the even-odd line products of the cell kernel (mul_eo) rest on the reversal symmetry of the 1D
+    // matrices: S[q][i] = S[n-1-q][n-1-i], D[q][r] = -D[n-1-q][n-1-r].  All three bases have it.
+    const int n = op->h.n;
+    double    dev = 0, scale = 0;
+    for (int q = 0; q < n; ++q)
+      for (int i = 0; i < n; ++i)
+        {
+          dev   = std::max(dev, std::fabs(op->h.S[q * n + i] - op->h.S[(n - 1 - q) * n + n - 1 - i]));
+          dev   = std::max(dev, std::fabs(op->h.D[q * n + i] + op->h.D[(n - 1 - q) * n + n - 1 - i]));
+          scale = std::max(scale, std::max(std::fabs(op->h.S[q * n + i]), std::fabs(op->h.D[q * n + i])));
+        }
+    if (dev > 1e-11 * scale)
+      return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: the 1D basis is not symmetric under x -> 1 - x");
+    if (!op->h.e_parity)
+      return dg_fail(MGX_ERR_UNSUPPORTED, "mgx_dg_operator_create: the eigenvectors of the 1D problem have no definite parity "
+                                          "(degenerate eigenvalues)");
+  }
 
   const size_t        nsz = desc->number == MGX_F64 ? 8 : 4;
   std::vector<double> table(64 * n3), diag;
@@ -1783,8 +2045,12 @@ int mgx_dg_operator_info(mgx_dg_operator_t op, double *hderiv, double penalty[3]
     for (int d = 0; d < 3; ++d)
       penalty[d] = op->g.sigma[d];
   if (eigenvalues_1d)
-    for (int i = 0; i <= MGX_MAX_DEGREE; ++i)
-      eigenvalues_1d[i] = i < op->h.n ? op->h.lambda[i] : 0.0;
+    {
+      std::vector<double> sorted(op->h.lambda.begin(), op->h.lambda.begin() + op->h.n);
+      std::sort(sorted.begin(), sorted.end()); // (held parity by parity internally)
+      for (int i = 0; i <= MGX_MAX_DEGREE; ++i)
+        eigenvalues_1d[i] = i < op->h.n ? sorted[i] : 0.0;
+    }
   return MGX_OK;
 }
 
