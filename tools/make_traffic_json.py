@@ -1,5 +1,6 @@
 """profiles/*_pmc_traffic_*.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
-tools/matvec_loop.py <cells> <n> cheb [degree].  usage: make_traffic_json.py fetch.csv write.csv cells out.json [degree=4]
+tools/matvec_loop.py <cells> <n> all [degree] (every finest-level form of the brick loop: operator, residual,
+Chebyshev forms, and the V-cycle's fused transfer forms).  usage: make_traffic_json.py fetch.csv write.csv cells out.json [degree=4]
 
 Streaming kernels of the same run with known byte counts calibrate the counters (gfx950:
 FETCH_SIZE reports 1/2 for 8-B-per-lane reads, WRITE_SIZE is exact)."""
@@ -32,7 +33,7 @@ def main():
     fe, wr, cells, out = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     p = int(sys.argv[5]) if len(sys.argv) > 5 else 4
     n = (cells * p + 1) ** 3
-    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 tools/matvec_loop.py %d 3 cheb %d"
+    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 tools/matvec_loop.py %d 3 all %d"
                       "   (and a second pass with --pmc WRITE_SIZE)" % (cells, p),
            "workload": "poisson_cube FE_Q(%d) %d^3 cells, %d DoFs, fp64, finest level, per colour launch" % (p, cells, n),
            "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
@@ -50,12 +51,13 @@ def main():
                 "known_read_bytes": rb, "FETCH_SIZE_KiB": f, "reported/known": f * 1024 / rb,
                 "known_write_bytes": wb, "WRITE_SIZE_KiB": w, "write reported/known": (w * 1024 / wb) if wb else None}
     names = {0: ("kPlain", 16), 1: ("kResidual", 24), 2: ("kCheb", 40), 3: ("kChebFirst", 32), 4: ("kChebZeroOld", 32),
-             5: ("kChebInit", 24), 6: ("kChebOldInit", 32), 7: ("kResidualRestrict", 18)}
+             5: ("kChebInit", 24), 6: ("kChebOldInit", 32), 7: ("kResidualRestrict", 18), 9: ("kChebFirstProlong", 33)}
     for mode, (nm, alg) in names.items():
         # macro-element form (production; fused Chebyshev forms with the inverse diagonal in registers
         # when the diagonal is uniform), else the cell-by-cell form
-        for k in ("void mgx::brick_macro_kernel<%d, double, %d, true>" % (p, mode),
-                  "void mgx::brick_macro_kernel<%d, double, %d, false>" % (p, mode),
+        # (last template argument: the eight-colour schedule of the finest level, not a reduced-colour one)
+        for k in ("void mgx::brick_macro_kernel<%d, double, %d, true, false>" % (p, mode),
+                  "void mgx::brick_macro_kernel<%d, double, %d, false, false>" % (p, mode),
                   "void mgx::brick_sep_kernel<%d, double, %d, false>" % (p, mode)):
             if k in fe and k in wr:
                 break

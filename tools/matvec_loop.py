@@ -18,6 +18,17 @@ y = ctx.vector(cube.n_dofs(l))
 if mode == "vmult":
     for _ in range(n):
         op.vmult(y, x)
+elif mode == "all":
+    # every finest-level form: operator (0), residual (1), and V-cycles -- pre-smoothing from a zero start (5, 6),
+    # residual + restriction (7), post-smoothing with the prolongation fused in (9, 2, 2)
+    solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
+    A = solver.matrix_dp(l)
+    r = ctx.vector(cube.n_dofs(l))
+    for _ in range(n):
+        A.vmult(y, x)
+        A.vmult_residual(x, y, r)
+        solver.vmult(y, x)
+        ctx.sync()
 else:
     sm = mg.Chebyshev(op, 20., 3, 15)
     for _ in range(n):
