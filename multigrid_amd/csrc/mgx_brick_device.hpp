@@ -166,112 +166,134 @@ namespace mgx
   // coarse vector through the coarse entity table of the brick.  Bricks of one colour launch are
   // not adjacent, so their parents share no coarse DoF: plain read-modify-write.
   // ------------------------------------------------------------------------------------------
+  // one parent's part of a line: o[j] = sum_a P1[a][j] r[a], a over the 2p+1 fine points of parent pb
   template <int P, typename T>
-  __device__ __forceinline__ void restrict_line(const T *__restrict__ p1, const T (&r)[BCfg<P>::G],
-                                                T (&out)[(BCfg<P>::NB / 2) * P + 1])
+  __device__ __forceinline__ void restrict_half(const T *__restrict__ p1, const T (&r)[2 * P + 1], T (&o)[P + 1])
   {
-    constexpr int N = P + 1, M = 2 * P + 1, PB = BCfg<P>::NB / 2;
+    constexpr int N = P + 1, M = 2 * P + 1;
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb)
+    for (int j = 0; j < N; ++j)
       {
-        T o[N];
+        T s = p1[j] * r[0];
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-          {
-            T s = p1[j] * r[pb * 2 * P];
-#pragma unroll
-            for (int a = 1; a < M; ++a)
-              s = fma(p1[a * N + j], r[pb * 2 * P + a], s);
-            o[j] = s;
-          }
-        if (pb == 0)
-          {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-              out[j] = o[j];
-          }
-        else
-          {
-            // the node shared by the two parents was counted by both (unit weight in each)
-            out[pb * P] += o[0] - r[pb * 2 * P];
-#pragma unroll
-            for (int j = 1; j < N; ++j)
-              out[pb * P + j] = o[j];
-          }
+        for (int a = 1; a < M; ++a)
+          s = fma(p1[a * N + j], r[a], s);
+        o[j] = s;
       }
   }
 
+  // Work items of a sweep are HALF lines (one parent's 2p+1 fine points -> p+1 coarse values) where a line
+  // spans two parents (p <= 4), two neighbouring lanes per line: 289 + 153 + 81 lines on 256 threads take
+  // 3 + 2 + 1 passes of half the work instead of 2 + 1 + 1 passes of the whole.  The coarse point the two
+  // parents share receives both contributions (minus the fine value counted by both) from the lower lane.
   template <int P, typename T, int NT>
   __device__ __forceinline__ void restrict_brick(int tid, T *acc, const T *__restrict__ p1, T *__restrict__ coarse,
                                                  const uint32_t *__restrict__ ctab)
   {
     using C           = BCfg<P>;
-    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1;
-    // x: lines (y, z)
-    for (int l = tid; l < G * G; l += NT)
-      {
-        T r[G], o[CN];
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-          r[i] = acc[l * G + i];
-        restrict_line<P, T>(p1, r, o);
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-          acc[l * G + j] = o[j];
-      }
-    __syncthreads();
-    // y: lines (x < CN, z)
-    for (int l = tid; l < CN * G; l += NT)
-      {
-        const int x = l % CN, z = l / CN;
-        T         r[G], o[CN];
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-          r[i] = acc[(z * G + i) * G + x];
-        restrict_line<P, T>(p1, r, o);
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-          acc[(z * G + j) * G + x] = o[j];
-      }
-    __syncthreads();
-    // z: lines (x, y) with x, y < CN; the results go to the coarse vector
+    constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1, N = P + 1, M = 2 * P + 1;
     auto layer = [](int a, int &e, int &o, int &n) {
       const int q = a / P, rr = a - q * P;
       e           = 2 * q + (rr != 0);
       o           = rr ? rr - 1 : 0;
       n           = rr ? P - 1 : 1;
     };
-    for (int l = tid; l < CN * CN; l += NT)
-      {
-        const int x = l % CN, y = l / CN;
-        T         r[G], o[CN];
+    // the coarse values this thread will add to (z sweep, one coarse point per parent-half item): requested
+    // now, two sweeps ahead of their use
+    constexpr int NZ = (CN * CN * PB + NT - 1) / NT;
+    T            *cp[NZ][N];
+    T             cv[NZ][N];
+    bool          ok[NZ][N];
 #pragma unroll
-        for (int i = 0; i < G; ++i)
-          r[i] = acc[(i * G + y) * G + x];
-        restrict_line<P, T>(p1, r, o);
-        int ex, ey, ox, oy, nx, ny;
+    for (int it = 0; it < NZ; ++it)
+      {
+        const int t = tid + it * NT, l = t / PB, pb = t % PB;
+        const bool live = t < CN * CN * PB;
+        const int  x = live ? l % CN : 0, y = live ? l / CN : 0;
+        int        ex, ey, ox, oy, nx, ny;
         layer(x, ex, ox, nx);
         layer(y, ey, oy, ny);
-        // read-modify-write of the CN coarse values of this line: all loads first, then all stores
-        // (a load behind a store to the same vector would wait for it: CN dependent round trips)
-        T  *cp[CN];
-        T   cv[CN];
-        bool ok[CN];
 #pragma unroll
-        for (int j = 0; j < CN; ++j)
+        for (int j = 0; j < N; ++j)
           {
             int ez, oz, nz;
-            layer(j, ez, oz, nz);
+            layer(pb * P + j, ez, oz, nz);
             const uint32_t w = ctab[(ez * CE1 + ey) * CE1 + ex];
-            ok[j]            = w != kInvalid;
-            cp[j]            = coarse + (ok[j] ? w + (uint32_t)((oz * ny + oy) * nx + ox) : 0u);
-            cv[j]            = *cp[j];
+            // the shared point of two parents is written by the lower one
+            ok[it][j] = live && w != kInvalid && !(PB == 2 && pb == 1 && j == 0);
+            cp[it][j] = coarse + (ok[it][j] ? w + (uint32_t)((oz * ny + oy) * nx + ox) : 0u);
+            cv[it][j] = *cp[it][j];
           }
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-          if (ok[j])
-            *cp[j] = cv[j] + o[j];
       }
+    // generic sweep over `lines` lines: base(l) = first point of line l, stride between its points
+    auto sweep = [&](int lines, auto base, int stride, auto sink) {
+#pragma unroll 1
+      for (int t0 = 0; t0 < lines * PB; t0 += NT)
+        {
+          const int  t = t0 + tid, l = t / PB, pb = t % PB;
+          const bool live = t < lines * PB;
+          T          r[M], o[N];
+          const int  b0 = base(live ? l : 0) + pb * 2 * P * stride;
+#pragma unroll
+          for (int a = 0; a < M; ++a)
+            r[a] = acc[b0 + a * stride];
+          restrict_half<P, T>(p1, r, o);
+          if (PB == 2)
+            {
+              // lower lane: its last coarse point also takes the upper lane's first (the fine value at
+              // that point was counted by both)
+              const T up = __shfl_down(o[0], 1);
+              if (pb == 0)
+                o[P] += up - r[2 * P];
+            }
+          sink(live, l, pb, o);
+        }
+    };
+    // x: lines (y, z), results over the head of the line
+    sweep(
+      G * G, [&](int l) { return l * G; }, 1,
+      [&](bool live, int l, int pb, const T(&o)[N]) {
+        // (a line's two items sit in neighbouring lanes of one wave: the reads above are done)
+        if (live)
+          {
+#pragma unroll
+            for (int j = (pb == 0 ? 0 : 1); j < N; ++j)
+              acc[l * G + pb * P + j] = o[j];
+          }
+      });
+    __syncthreads();
+    // y: lines (x < CN, z)
+    sweep(
+      CN * G, [&](int l) { return (l / CN) * G * G + l % CN; }, G,
+      [&](bool live, int l, int pb, const T(&o)[N]) {
+        if (live)
+          {
+            const int x = l % CN, z = l / CN;
+#pragma unroll
+            for (int j = (pb == 0 ? 0 : 1); j < N; ++j)
+              acc[(z * G + pb * P + j) * G + x] = o[j];
+          }
+      });
+    __syncthreads();
+    // z: lines (x, y) with x, y < CN; the results are added to the coarse vector (values requested above;
+    // all stores behind all loads: a load behind a store to the same vector would wait for it)
+    {
+      int it = 0;
+      sweep(
+        CN * CN, [&](int l) { return (l / CN) * G + l % CN; }, G * G,
+        [&](bool, int, int, const T(&o)[N]) {
+#pragma unroll
+          for (int k = 0; k < NZ; ++k)
+            if (k == it)
+              {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                  if (ok[k][j])
+                    *cp[k][j] = cv[k][j] + o[j];
+              }
+          ++it;
+        });
+    }
   }
 
   // ------------------------------------------------------------------------------------------
@@ -321,6 +343,8 @@ namespace mgx
     pnt  = (z * G + y) * G + x;
   }
 
+  // (half-line work items as in restrict_brick were measured here too: 197 -> 253 us per colour launch of the
+  // fused form, the kernel spills 176 instead of 56 B per lane with them)
   template <int P, typename T, int NT>
   __device__ __forceinline__ void prolong_brick(int tid, T *acc, const T *__restrict__ p1,
                                                 const T (&cv)[((BCfg<P>::NB / 2) * P + 1) * ((BCfg<P>::NB / 2) * P + 1) *

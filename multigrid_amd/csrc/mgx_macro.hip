@@ -783,7 +783,9 @@ namespace mgx
         __syncthreads();
         // (kChebInit gathers two operands per value: too many registers in flight next to the
         // write-out, its gather is issued afterwards)
-        constexpr bool kPipeGather = (MODE != kChebInit || DTAB) && MODE != kCgUpdate;
+        // (likewise kChebFirstProlong, which also holds the coarse values and the corrected x: with the next
+        // gather in flight it spills 56 B per lane; without, 177 instead of 193 us per colour launch)
+        constexpr bool kPipeGather = (MODE != kChebInit || DTAB) && MODE != kCgUpdate && MODE != kChebFirstProlong;
         if (has_next && kPipeGather)
           gather_issue(E2, bn);
         MGX_STAMP_IT(7);
