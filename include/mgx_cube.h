@@ -93,7 +93,7 @@ int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
 int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *cube);
 /* multi-block meshes: the physical Gauss-Lobatto points of every cell of a level,
  * out[cell][3][(p+1)^3], and the number of cells around each of the 27 entities of every cell
- * (what deal.II's mesh would tell a caller; the oracle of the tests is built on them) */
+ * (what deal.II's mesh would tell a caller) */
 int            mgx_cube_cell_nodes(mgx_cube_t cube, int level, double *out);
 const uint8_t *mgx_cube_entity_multiplicity(mgx_cube_t cube, int level);
 /* [n_cells][6][(p+1)^3] merged coefficient of a mapped level (NULL on the Cartesian cube) */

@@ -1286,7 +1286,8 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
             }
         }
     }
-  if (general && desc->n_cells >= tun.cell_colour_min)
+  constexpr size_t kAssemblyMaxEntries = (size_t)1 << 26; // ordered assembly up to this many local values per level
+  if (general && (desc->n_cells >= tun.cell_colour_min || (size_t)n * n * n * desc->n_cells > kAssemblyMaxEntries))
     {
       // Cell colouring for the general branch: greedy over the cells in their order, two cells
       // conflict if they share a mesh entity that carries DoFs (its first DoF is the key).  On the
@@ -1443,7 +1444,6 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   // vector_access_reduced.h:153-229; constrained entities contribute nothing).  Larger levels than
   // kAssemblyMaxEntries keep the one launch with atomic adds (last bits not reproducible).
   {
-    constexpr size_t kAssemblyMaxEntries = (size_t)1 << 26;
     const size_t     n3 = (size_t)n * n * n, n_local = n3 * desc->n_cells;
     if (!d.bricks.available() && !d.cell_order && n_local <= kAssemblyMaxEntries)
       {

@@ -42,7 +42,7 @@ namespace mgx
     bool     restrict_atomic  = false; // MGX_RESTRICT_ATOMIC  one-launch restriction with atomics on every level
     uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour
     bool     exchange_unfused = false; // MGX_EXCHANGE_UNFUSED one pack / unpack launch per neighbour
-    uint32_t cell_colour_min  = 4096;  // MGX_CELL_COLOUR_MIN  general-coefficient levels from this many cells run colour by colour
+    uint32_t cell_colour_min  = 0xFFFFFFFFu; // MGX_CELL_COLOUR_MIN  general-coefficient levels from this many cells run colour by colour; by default only levels whose ordered-assembly tables would not fit do (measured on the shell meshes: one launch + ordered assembly 20 / 56 / 119 / 463 us at 6 k / 25 k / 49 k / 197 k cells against 103 / 136 / 202 / 540 us for the 13 colour launches of the greedy colouring)
     uint32_t free_max_bricks  = 16384; // MGX_FREE_MAX_BRICKS  levels with at most this many bricks run the plain / residual / Chebyshev forms of the brick loop on a reduced-colour schedule (mgx_macro.hip, FREE) instead of eight colour launches
     uint32_t free_one_max     = 1024;  // MGX_FREE_ONE_MAX     ... with one class (one launch) up to this many bricks, two classes beyond
     bool     no_graph         = false; // MGX_NO_GRAPH         no HIP-graph replay of the coarse levels

@@ -9,7 +9,10 @@ deg = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 ns, nr = cells, 0
 while ns % 2 == 0 and ns > 1:
     ns //= 2; nr += 1
-ctx = mg.Context(0)
+# mode "all": the level below the finest one runs on the one-launch schedule with separate transfer kernels, so that
+# every launch of the fused transfer forms (and every 512-block launch of the eight-colour kernels) in the trace
+# belongs to the finest level
+ctx = mg.Context(0, options={"free_one_max": 8192} if mode == "all" else None)
 cube = mg.Cube(deg, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
