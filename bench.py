@@ -35,7 +35,7 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (datasheet); tools/microbenc
 # executed by the macro-element brick kernel at p = 4: 289 lines x 628 fp64 instructions (ISA count of
 # the three sweeps: 158 + 279 + 191, ~80 % of them FMA = 2 flop) per 4096-DoF brick (dense 12-sweep form: 270)
 FLOP_PER_DOF_P4 = 80.0
-TRAFFIC_FILES = {(4, 128): "r02_pmc_traffic_128cube_p4.json", (8, 64): "r02_pmc_traffic_64cube_p8.json"}
+TRAFFIC_FILES = {(4, 128): "r03_pmc_traffic_128cube_p4.json", (8, 64): "r03_pmc_traffic_64cube_p8.json"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
 
 
