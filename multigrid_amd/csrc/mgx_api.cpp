@@ -3099,20 +3099,44 @@ int mgx_solver_solve_cg(mgx_solver_t S, unsigned int *iterations, double *reduct
   double       res = res0, rz = 0, rz_old = 0;
   unsigned int it  = 0;
   S->cg_history.assign(1, res0);
+  // Mixed precision on one rank: the precision casts around the V-cycle (:503, :507) are folded into the CG
+  // kernels next to them (mgx_vector.hip): the residual update writes the fp32 defect, the r.z product and the
+  // direction update read the fp32 result of the cycle.  The values are those the two copies would produce.
+  const bool mixed = S->vnumber == MGX_F32 && !ctx->has_comm;
+  float     *r32 = (float *)S->defect[lmax];
+  if (mixed)
+    launch_copy_cast(s, r32, MGX_F32, r, MGX_F64, n);
   // SolverCG with ReductionControl(1000, 1e-16, 1e-9) (:486)
   while (res > 1e-16 && res > 1e-9 * res0 && it < 1000)
     {
       ++it;
-      MGX_TRY(mgx_solver_vmult(S, z, r));
       rz_old = rz;
-      MGX_TRY(dot(ctx, MGX_F64, r, z, n, &rz, A->plan.get()));
-      if (it > 1)
-        launch_xpby(s, MGX_F64, d, z, rz / rz_old, n);
+      if (mixed)
+        {
+          MGX_TRY(v_cycle(S, lmax, 1)); // :505
+          const float *z32 = (const float *)S->solution_update[lmax];
+          launch_dot_f64_f32(s, r, z32, n, ctx->partial_dev, ctx->result_dev);
+          MGX_TRY(read_result(ctx, &rz));
+          if (it > 1)
+            launch_xpby_f64_f32(s, d, z32, rz / rz_old, n);
+          else
+            launch_copy_cast(s, d, MGX_F64, z32, MGX_F32, n);
+        }
       else
-        launch_copy_cast(s, d, MGX_F64, z, MGX_F64, n);
+        {
+          MGX_TRY(mgx_solver_vmult(S, z, r));
+          MGX_TRY(dot(ctx, MGX_F64, r, z, n, &rz, A->plan.get()));
+          if (it > 1)
+            launch_xpby(s, MGX_F64, d, z, rz / rz_old, n);
+          else
+            launch_copy_cast(s, d, MGX_F64, z, MGX_F64, n);
+        }
       MGX_TRY(mgx_vmult(A, h, d));
       double dh = 0;
       MGX_TRY(dot(ctx, MGX_F64, d, h, n, &dh, A->plan.get()));
+      if (mixed)
+        launch_cg_update_f32copy(s, x, r, d, h, rz / dh, n, r32, ctx->partial_dev, ctx->result_dev);
+      else
       launch_cg_update(s, MGX_F64, x, r, d, h, rz / dh, n, ctx->partial_dev, ctx->result_dev);
       if (ctx->has_comm)
         MGX_TRY(dot(ctx, MGX_F64, r, r, n, &res, A->plan.get()));

@@ -113,6 +113,9 @@ namespace mgx
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
+#ifndef MGX_PACKED_F32
+#define MGX_PACKED_F32 1
+#endif
   template <int N, typename T>
   __device__ __forceinline__ void eo_split(const T (&x)[N], T (&xe)[N / 2 + 1], T (&xo)[N / 2 + 1])
   {
@@ -132,6 +135,33 @@ namespace mgx
                                            T (&y)[N])
   {
     constexpr int H = N / 2;
+    if constexpr (sizeof(T) == 4 && MGX_PACKED_F32)
+      {
+        // fp32: the even and the odd half-products are two independent sums of the same length -- one stream
+        // of 2-vector multiply-adds (v_pk_fma_f32), half the instructions of the sweeps that bound this form
+        typedef T T2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int a = 0; a < H; ++a)
+          {
+            T2 r = T2{A.ee[a * H], A.eo[a * H]} * T2{xe[0], xo[0]};
+#pragma unroll
+            for (int i = 1; i < H; ++i)
+              r = __builtin_elementwise_fma(T2{A.ee[a * H + i], A.eo[a * H + i]}, T2{xe[i], xo[i]}, r);
+            if (N % 2)
+              r[0] = fma(A.mc[a], xe[H], r[0]);
+            y[a]         = r[0] + r[1];
+            y[N - 1 - a] = r[0] - r[1];
+          }
+        if (N % 2)
+          {
+            T r = A.mhh * xe[H];
+#pragma unroll
+            for (int i = 0; i < H; ++i)
+              r = fma(A.mc[i], xe[i], r);
+            y[H] = r;
+          }
+        return;
+      }
 #pragma unroll
     for (int a = 0; a < H; ++a)
       {

@@ -323,6 +323,11 @@ namespace mgx
                         size_t n, double *partial_dev, double *result_dev);
   //   d = z + beta d
   void launch_xpby(hipStream_t s, int number, void *d, const void *z, double beta, size_t n);
+  // mixed-precision PCG: the same with the fp32 copy of the new residual written along / the fp32 vector read directly
+  void launch_cg_update_f32copy(hipStream_t s, double *x, double *r, const double *d, const double *h, double alpha, size_t n,
+                                float *r32, double *partial_dev, double *result_dev);
+  void launch_dot_f64_f32(hipStream_t s, const double *x, const float *y, size_t n, double *partial_dev, double *result_dev);
+  void launch_xpby_f64_f32(hipStream_t s, double *d, const float *z, double beta, size_t n);
   // z = dinv .* r ; result = r.z
   void launch_jacobi_dot(hipStream_t s, int number, void *z, const void *dinv, const void *r, size_t n,
                          double *partial_dev, double *result_dev);

@@ -330,6 +330,42 @@ namespace mgx
     GRID_STRIDE(i, n) d[i] = z[i] + beta * d[i];
   }
 
+  // Mixed-precision PCG (fp64 outer iteration, fp32 V-cycle: the reference's default, poisson_cube/program.cc:76-77):
+  // the two precision-converting copies around the preconditioner (multigrid_solver.h:503, 507) are folded into
+  // the CG kernels next to them -- the residual update writes the fp32 defect the V-cycle reads, the r.z product and
+  // the direction update read the V-cycle's fp32 result.  Same values as the copies would have produced.
+  __global__ void __launch_bounds__(256)
+    k_cg_update_f32copy(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ d,
+                        const double *__restrict__ h, double alpha, size_t n, float *__restrict__ r32,
+                        double *__restrict__ partial)
+  {
+    double s = 0;
+    GRID_STRIDE(i, n)
+    {
+      x[i] += alpha * d[i];
+      const double ri = r[i] - alpha * h[i];
+      r[i]            = ri;
+      r32[i]          = (float)ri;
+      s += ri * ri;
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = s;
+  }
+  __global__ void __launch_bounds__(256)
+    k_dot_partial_f64_f32(const double *__restrict__ x, const float *__restrict__ y, size_t n, double *__restrict__ partial)
+  {
+    double s = 0;
+    GRID_STRIDE(i, n) s += x[i] * (double)y[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0)
+      partial[blockIdx.x] = s;
+  }
+  __global__ void __launch_bounds__(256) k_xpby_f64_f32(double *__restrict__ d, const float *__restrict__ z, double beta, size_t n)
+  {
+    GRID_STRIDE(i, n) d[i] = (double)z[i] + beta * d[i];
+  }
+
   template <typename T>
   __global__ void __launch_bounds__(256)
     k_jacobi_dot(T *__restrict__ z, const T *__restrict__ dinv, const T *__restrict__ r, size_t n,
@@ -650,6 +686,28 @@ namespace mgx
     BY_NUMBER(number, hipLaunchKernelGGL((k_cg_update<T>), g, dim3(256), 0, s, (T *)x, (T *)r, (const T *)d,
                                          (const T *)h, (T)alpha, n, partial_dev));
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+
+  void launch_cg_update_f32copy(hipStream_t s, double *x, double *r, const double *d, const double *h, double alpha, size_t n,
+                                float *r32, double *partial_dev, double *result_dev)
+  {
+    const dim3 g = reduce_grid(n);
+    hipLaunchKernelGGL(k_cg_update_f32copy, g, dim3(256), 0, s, x, r, d, h, alpha, n, r32, partial_dev);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+
+  void launch_dot_f64_f32(hipStream_t s, const double *x, const float *y, size_t n, double *partial_dev, double *result_dev)
+  {
+    const dim3 g = reduce_grid(n);
+    hipLaunchKernelGGL(k_dot_partial_f64_f32, g, dim3(256), 0, s, x, y, n, partial_dev);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, s, partial_dev, (int)g.x, result_dev);
+  }
+
+  void launch_xpby_f64_f32(hipStream_t s, double *d, const float *z, double beta, size_t n)
+  {
+    if (n == 0)
+      return;
+    hipLaunchKernelGGL(k_xpby_f64_f32, stream_grid(n), dim3(256), 0, s, d, z, beta, n);
   }
 
   void launch_xpby(hipStream_t s, int number, void *d, const void *z, double beta, size_t n)
