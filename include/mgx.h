@@ -300,8 +300,11 @@ typedef struct
   /* prolong_1d[a*(p+1)+i], a in [0,2p]: coarse 1D basis i at the fine patch point a */
   const double *prolong_1d;
   /* optional, may be NULL: weight_shift[27*parent + e] = log2(multiplicity) of patch entity e
-   * (deal.II's weights_on_refined, 3^dim per cell); needed on a decomposed mesh where the
-   * multiplicity counts parents of other ranks.  NULL: computed from the local tables. */
+   * (deal.II's weights_on_refined, 3^dim per cell), counting the parents of other ranks as well.
+   * NULL: computed from the local tables; where that is not possible -- multiplicities that are not
+   * powers of two (three cells around an edge of a multi-block mesh), decomposed meshes -- the
+   * restriction uses owner weights instead: a shared fine DoF is restricted, with weight 1, by the
+   * one parent (of the lowest rank that holds it) owning its entity.  Same R = P^T. */
   const uint8_t *weight_shift;
 } mgx_transfer_desc;
 int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_transfer_desc *desc,

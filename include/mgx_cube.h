@@ -87,10 +87,15 @@ int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
  * by all cells that contain it, so that the compressed index tables of LaplaceOperator hold on the whole
  * shell (laplace_operator.h:272-340); the cell geometry is the degree-p interpolant of the block map
  * (0.5 + 0.5 w) n(u, v), n the normalised bilinear interpolant of the polyhedron face.  problem:
- * MGX_CUBE_PROBLEM_SHELL (poisson_shell) or MGX_CUBE_PROBLEM_CUBE (constant coefficient).  One rank.
+ * MGX_CUBE_PROBLEM_SHELL (poisson_shell) or MGX_CUBE_PROBLEM_CUBE (constant coefficient).
  * The multiplicities of the transfer are not powers of two where three blocks meet: levels carry no
  * weight_shift, mgx_transfer_create derives owner weights. */
 int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *cube);
+/* The same distributed over n_ranks ranks (n_ranks divides n_coarse): rank r owns the coarse cells
+ * [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks) with everything refined from them; DoFs on faces between
+ * coarse cells of different ranks are duplicated and exchanged like the interface DoFs of the block-split cube
+ * (mgx_cube_exchange_desc). */
+int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int problem, int n_ranks, int rank, mgx_cube_t *cube);
 /* multi-block meshes: the physical Gauss-Lobatto points of every cell of a level,
  * out[cell][3][(p+1)^3], and the number of cells around each of the 27 entities of every cell
  * (what deal.II's mesh would tell a caller) */

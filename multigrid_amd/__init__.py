@@ -384,16 +384,19 @@ class Cube:
         numbering: "brick" (default, grouped for the device cell loop) or "cell" (the
         plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h.
         shell=6 | 12: the mesh of poisson_shell instead, GridGenerator::hyper_shell(0, 0.5, 1.0, shell) refined
-        n_refine times (mgx_cube_create_shell); problem "shell" (default there) or "cube"."""
+        n_refine times (mgx_cube_create_shell); problem "shell" (default there) or "cube"; procs=(n,1,1), rank=r:
+        the coarse cells distributed over n ranks (n divides `shell`)."""
         self.lib = _lib.load()
         h = C.c_void_p()
         num = self.NUMBERING[numbering]
         self.shell = shell
         if shell is not None:
             self.box_desc = None
-            check(self.lib.mgx_cube_create_shell(degree, int(shell), n_refine, self.PROBLEM[problem], C.byref(h)))
+            n_ranks = int(procs[0]) * int(procs[1]) * int(procs[2])
+            check(self.lib.mgx_cube_create_shell_ranks(degree, int(shell), n_refine, self.PROBLEM[problem], n_ranks, rank,
+                                                       C.byref(h)))
             self.h = h
-            self.rank, self.size = 0, 1
+            self.rank, self.size = rank, n_ranks
             self.degree = degree
             self.n_levels = self.lib.mgx_cube_n_levels(h)
             self.max_level = self.n_levels - 1

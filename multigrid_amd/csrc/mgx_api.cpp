@@ -166,6 +166,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
 
 struct ExchangePlan
 {
+  std::vector<uint32_t> not_owned_host; // DoFs a lower rank holds as well (host copy of not_owned_dev)
   int                    plan_id = 0, number = MGX_F64, self_pos = 0;
   std::vector<int>       rank;
   std::vector<uint32_t>  count;
@@ -1574,6 +1575,7 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       }
       P->n_shared    = e.n_shared;
       P->n_not_owned = e.n_not_owned;
+      P->not_owned_host.assign(e.not_owned, e.not_owned + e.n_not_owned);
       MGX_HIP(hipMalloc((void **)&P->shared_dev, sizeof(uint32_t) * (e.n_shared + 1)));
       MGX_HIP(hipMalloc((void **)&P->not_owned_dev, sizeof(uint32_t) * (e.n_not_owned + 1)));
       MGX_HIP(hipMalloc(&P->own_buf, es * (e.n_shared + 1)));
@@ -2321,11 +2323,15 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
             owner_weights = true;
           shift[27 * (size_t)pc + e] = c == 1 ? 0 : (c == 2 ? 1 : (c == 4 ? 2 : 3));
         }
+    // (on a decomposed mesh the local counts miss the parents of other ranks: without the caller's global
+    // weight_shift every rank uses owner weights, which need no count at all)
+    if (coarse->plan && !desc->weight_shift)
+      owner_weights = true;
     if (owner_weights)
       {
-        if (coarse->plan || desc->weight_shift)
-          return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: fine DoF multiplicities other than 1/2/4/8 on a decomposed "
-                                           "mesh or together with weight_shift");
+        if (desc->weight_shift)
+          return fail(MGX_ERR_UNSUPPORTED, "mgx_transfer_create: fine DoF multiplicities other than 1/2/4/8 together with "
+                                           "weight_shift");
         std::fill(shift.begin(), shift.end(), (uint8_t)0);
         tr->d.owner_weights = true;
       }
@@ -2338,8 +2344,6 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
             shift[i] = desc->weight_shift[i];
           }
       }
-    else if (coarse->plan)
-      return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_transfer_create: a decomposed mesh needs the global weight_shift");
     MGX_HIP(hipMalloc((void **)&tr->d.weight_shift, shift.size()));
     MGX_HIP(hipMemcpy(tr->d.weight_shift, shift.data(), shift.size(), hipMemcpyHostToDevice));
     // ownership of the fine entities for the atomic-free prolongation: first cell in cell order
@@ -2369,6 +2373,15 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
       {
         std::vector<uint32_t> patch(125 * (size_t)npar);
         bool                  consistent = true;
+        // owner weights on a decomposed mesh: a fine entity that a lower rank holds as well is restricted
+        // there; here it enters with weight 0 (the coarse sums are added over the ranks afterwards)
+        std::vector<uint8_t> foreign;
+        if (tr->d.owner_weights && fine->plan)
+          {
+            foreign.assign(fine->d.n_dofs, 0);
+            for (uint32_t i : fine->plan->not_owned_host)
+              foreign[i] = 1;
+          }
 #pragma omp parallel for schedule(static)
         for (uint32_t pc = 0; pc < npar; ++pc)
           for (int e = 0; e < 125; ++e)
@@ -2402,7 +2415,9 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
                       first = false;
                       owned = owned || ((own[fc] >> ce) & 1u);
                     }
-              const uint32_t sh = shift[27 * (size_t)pc + (cls[2] * 3 + cls[1]) * 3 + cls[0]];
+              uint32_t sh = shift[27 * (size_t)pc + (cls[2] * 3 + cls[1]) * 3 + cls[0]];
+              if (tr->d.owner_weights) // the field then says who restricts the entity: 0 = this parent, 1 = another one
+                sh = (owned && size != 0 && (foreign.empty() || !foreign[base])) ? 0u : 1u;
               patch[125 * (size_t)pc + e] =
                 size == 0 ? 0u : (base | (sh << 29) | ((owned ? 1u : 0u) << 31));
             }

@@ -273,7 +273,8 @@ struct mgx_cube_s
   }
   Basis              basis;
   std::vector<Level> levels;
-  std::vector<ShellBlock> shell; // MGX_CUBE_GEOMETRY_HYPER_SHELL: the coarse cells
+  std::vector<ShellBlock> shell; // MGX_CUBE_GEOMETRY_HYPER_SHELL: the coarse cells of the whole mesh
+  int                shell_block0 = 0; // ... the first one this rank owns
 };
 
 namespace
@@ -945,6 +946,11 @@ int mgx_cube_create_box(const mgx_cube_box_desc *bd, mgx_cube_t *out)
 
 int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *out)
 {
+  return mgx_cube_create_shell_ranks(degree, n_coarse, n_refine, problem, 1, 0, out);
+}
+
+int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int problem, int n_ranks, int rank, mgx_cube_t *out)
+{
   if (!out || degree < 1 || degree > MGX_MAX_DEGREE || n_refine < 0 || n_refine > 8)
     return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: degree must be in 1..9 and n_refine in 0..8");
   if (n_coarse != 6 && n_coarse != 12)
@@ -953,6 +959,8 @@ int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, m
     return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: unknown problem");
   if ((uint64_t)n_coarse << (3 * n_refine) >= 0x10000000ull)
     return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_create_shell: too many cells");
+  if (n_ranks < 1 || n_ranks > 12 || n_coarse % n_ranks != 0 || rank < 0 || rank >= n_ranks)
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: the number of ranks must divide the coarse cells");
   omp_set_num_threads(effective_threads());
   auto C        = std::make_unique<mgx_cube_s>();
   C->p          = degree;
@@ -962,13 +970,32 @@ int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, m
   C->problem.id = problem;
   C->groots[0] = C->lroots[0] = n_coarse;
   C->shell      = shell_blocks(n_coarse);
+  C->rank       = rank;
+  C->size       = n_ranks;
+  C->shell_block0 = rank * (n_coarse / n_ranks);
   make_basis(C->basis, degree);
   C->levels.resize(n_refine + 1);
   for (int l = 0; l <= n_refine; ++l)
     {
       std::string why;
-      if (!build_shell_level(*C, C->levels[l], l, why))
-        return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
+      if (n_ranks == 1)
+        {
+          if (!build_shell_level(*C, C->levels[l], l, why))
+            return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
+        }
+      else
+        {
+          // the tables of the whole mesh (every rank builds them; they are small next to the per-point
+          // coefficients), then this rank's blocks of it
+          Level      whole;
+          const int  b0 = C->shell_block0;
+          C->shell_block0 = 0;
+          const bool ok = build_shell_level(*C, whole, l, why);
+          C->shell_block0 = b0;
+          if (!ok)
+            return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
+          localise_shell_level(*C, whole, C->levels[l], n_coarse / n_ranks);
+        }
       build_geometry(*C, C->levels[l]);
       build_rhs(*C, C->levels[l]);
     }

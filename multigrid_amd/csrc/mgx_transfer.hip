@@ -186,9 +186,10 @@ namespace mgx
           for (int e = 0; e < 5; ++e)
             {
               w[e]      = tbl[b][has[it] ? 25 * e + line[it].sxy : 0];
-              // weight 2^-shift of the fine DoFs of this patch entity; owner weights (multi-block meshes):
-              // 1 for the parent that owns the entity, 0 (shift 31 is never a real one) for the others
-              sh[it][e] = owner_weights ? (pw_owned(w[e]) ? 0u : 31u) : pw_shift(w[e]);
+              // weight 2^-shift of the fine DoFs of this patch entity; owner weights (multi-block meshes): the field
+              // is 0 for the one parent (of the one rank) that restricts the entity -- weight 1 -- and 1 for the
+              // others -- weight 0 (shift 31 is never a real one)
+              sh[it][e] = owner_weights ? (pw_shift(w[e]) == 0u ? 0u : 31u) : pw_shift(w[e]);
             }
 #pragma unroll
           for (int c = 0; c < M; ++c)

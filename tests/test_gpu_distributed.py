@@ -109,3 +109,12 @@ def test_callback_device_transport_takes_library_owned_buffers():
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "callback_transport_worker.py")], cwd=root, env=env,
                          capture_output=True, timeout=600)
     assert out.returncode == 0 and b"callback transport ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("world,n_coarse,p,nr,problem", [(2, 6, 4, 2, "shell"), (3, 6, 2, 2, "shell"), (4, 12, 3, 1, "cube")])
+def test_decomposed_hyper_shell_matches_oracle(world, n_coarse, p, nr, problem):
+    """BASELINE config 4 on its own mesh on several ranks: the coarse cells of hyper_shell(6 | 12) dealt out to the
+    ranks, interface DoFs on the block faces exchanged; operator, diagonal, smoother parameters, V-cycle, FMG and
+    PCG against the single-domain oracle on the whole shell (owner weights in the transfers across ranks)"""
+    outs = launch("", world, 0, 0, extra=("gpu", str(n_coarse), str(p), str(nr), problem), worker="shell_dist_worker.py")
+    assert all("gpu ok" in o for o in outs), outs
