@@ -107,6 +107,14 @@ int mgx_dg_jacobi_vmult(mgx_dg_operator_t op, void *dst, const void *src);
 int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, unsigned iteration_index,
                                        double factor1, double factor2, void *solution, void *solution_old);
 
+/* LaplaceOperatorCompactCombine::vmult_with_cg_update (:863-908; action 2, epilogue :1827-1838): one iteration of
+ * the merged conjugate-gradient loop around the operator,
+ *   alpha != 0:  x += alpha p ;  p = beta p + q      alpha == 0:  p = q
+ *   q = A p ;  sums = { q.p, r.r, q.r, q.q }  summed over all ranks (host array)
+ * The four sums come out of the cell kernel's epilogue (block sums added in a fixed order). */
+int mgx_dg_vmult_with_cg_update(mgx_dg_operator_t op, double alpha, double beta, const void *r, void *q, void *p, void *x,
+                                double sums[4]);
+
 /* 1D data of the operator for inspection: hermite_derivative_on_face (:408-409), the penalty
  * parameters get_penalty(face 2d) (:789-793) and the 1D generalised eigenvalues (:207-208).
  * Any pointer may be NULL. */
@@ -156,6 +164,11 @@ int mgx_dg_solver_solve_cg(mgx_dg_solver_t solver, double tolerance, const doubl
  * zeroed first; constrained rows stay zero) and dg += P cg */
 int mgx_dg_restrict_to_cg(mgx_dg_solver_t solver, void *cg_dst, const void *dg_src);
 int mgx_dg_prolongate_add_cg_to_dg(mgx_dg_solver_t solver, void *dg_dst, const void *cg_src);
+/* LaplaceOperatorCompactCombine::vmult_residual_and_restrict_to_cg (:852-861; action 1, epilogue :1798-1819) of the
+ * solver's V-cycle operator: cg = P^T (rhs - A lhs), the residual changed to the FE_Q basis and added into the FE_Q
+ * vector inside the cell kernel (cg zeroed first, summed over the rank interfaces of a decomposed mesh).  The V-cycle
+ * runs this form unless the context option "dg_unmerged_restrict" is set. */
+int mgx_dg_vmult_residual_and_restrict_to_cg(mgx_dg_solver_t solver, void *cg_dst, const void *rhs, const void *lhs);
 
 /* ---- mesh helpers (stand in for GridGenerator + DoFHandler of the harness) ---- */
 

@@ -1016,6 +1016,14 @@ class DGLaplaceOperator:
             solution.ptr, solution_old.ptr = solution_old.ptr, solution.ptr
             solution.owned, solution_old.owned = solution_old.owned, solution.owned
 
+    def vmult_with_cg_update(self, alpha, beta, r, q, p, x):
+        """one merged CG iteration (laplace_operator_dg.h:863-908): x += alpha p, p = beta p + q (alpha == 0: p = q),
+        q = A p; returns (q.p, r.r, q.r, q.q) summed over the ranks"""
+        sums = np.empty(4)
+        check(self.lib.mgx_dg_vmult_with_cg_update(self.h, alpha, beta, r.ptr, q.ptr, p.ptr, x.ptr,
+                                                   sums.ctypes.data_as(_lib.f64p)))
+        return sums
+
     def basis_1d(self):
         """(shape values [q, i] in the Gauss points, Gauss points, Gauss weights) on [0, 1]"""
         n = self.degree + 1
@@ -1096,6 +1104,10 @@ class DGMultigridSolver:
 
     def prolongate_add_cg_to_dg(self, dg_dst, cg_src):
         check(self.lib.mgx_dg_prolongate_add_cg_to_dg(self.h, dg_dst.ptr, cg_src.ptr))
+
+    def vmult_residual_and_restrict_to_cg(self, cg_dst, rhs, lhs):
+        """cg = P^T (rhs - A lhs) in one kernel (laplace_operator_dg.h:852-861), V-cycle number type"""
+        check(self.lib.mgx_dg_vmult_residual_and_restrict_to_cg(self.h, cg_dst.ptr, rhs.ptr, lhs.ptr))
 
     def close(self):
         if getattr(self, "h", None):

@@ -228,6 +228,7 @@ SIGNATURES = {
     "mgx_dg_vmult_residual": (C.c_int, [vp, vp, vp, vp]),
     "mgx_dg_jacobi_vmult": (C.c_int, [vp, vp, vp]),
     "mgx_dg_vmult_with_chebyshev_update": (C.c_int, [vp, vp, C.c_uint, C.c_double, C.c_double, vp, vp]),
+    "mgx_dg_vmult_with_cg_update": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, vp, vp, f64p]),
     "mgx_dg_operator_info": (C.c_int, [vp, f64p, f64p, f64p]),
     "mgx_dg_operator_basis": (C.c_int, [vp, f64p, f64p, f64p]),
     "mgx_dg_solver_create": (C.c_int, [vp, C.POINTER(DGSolverDesc), C.POINTER(vp)]),
@@ -237,6 +238,7 @@ SIGNATURES = {
     "mgx_dg_solver_solve_cg": (C.c_int, [vp, C.c_double, vp, vp, C.POINTER(C.c_uint), f64p]),
     "mgx_dg_restrict_to_cg": (C.c_int, [vp, vp, vp]),
     "mgx_dg_prolongate_add_cg_to_dg": (C.c_int, [vp, vp, vp]),
+    "mgx_dg_vmult_residual_and_restrict_to_cg": (C.c_int, [vp, vp, vp, vp]),
     "mgx_dg_cheby_mesh": (C.c_int, [C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_double * 9)]),
     "mgx_dg_box_neighbours": (C.c_int, [C.POINTER(C.c_int * 3), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

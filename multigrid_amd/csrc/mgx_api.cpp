@@ -147,6 +147,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"exchange_unfused", &exchange_unfused, nullptr},
     {"no_graph", &no_graph, nullptr},
     {"dg_no_overlap", &dg_no_overlap, nullptr},
+    {"dg_unmerged_restrict", &dg_unmerged_restrict, nullptr},
     // emulation of a rank of a decomposed mesh on one GPU (tools/rank_emulation.py): the results are WRONG
     {"rccl_selftest", &rccl_selftest, nullptr},
   };

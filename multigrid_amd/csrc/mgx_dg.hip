@@ -89,11 +89,23 @@ namespace
     uint32_t          n_owned;   // owned cells of the operator: neighbour entries >= n_owned are ghosts
     T                 f1, f2;
     int               iteration_index;
+    // cells of a launch without a list: cell_first + cell_stride * i
+    uint32_t          cell_stride;
+    // kCgSums: [gridDim.x][4] block sums.  kRestrict: the FE_Q vector the transformed residual is added into,
+    // the compressed index table of the FE_Q cells (in the order of the DG cells), the 1D change of basis
+    // [n][n] and whether the cells of the launch share no FE_Q DoF (plain adds instead of atomics)
+    double           *partials;
+    T                *cg;
+    const uint32_t   *idx27;
+    const T          *P1;
+    int               plain;
   };
 
   enum Action
   {
     kVmult     = 0,
+    kRestrict  = 1, // residual, changed to the FE_Q basis and added into the FE_Q vector
+    kCgSums    = 2, // product stored, the four sums of the merged CG iteration
     kChebyshev = 3, // numbering of laplace_operator_dg.h:957-962
     kResidual  = 4,
     kJacobi    = 5  // P^-1 only (scaled by f2)
@@ -403,13 +415,85 @@ namespace
       }
   }
 
+  // residual x-lines in registers -> coefficients of the FE_Q basis of the cell: r <- (P1 x P1 x P1)^T r
+  // (the transposed embedding, laplace_operator_dg.h:1803 local_basis_transformer->apply<true>).  U is scratch.
+  template <int P, typename T>
+  __device__ __forceinline__ void to_fe_q_local(const T *__restrict__ P1, T *U, bool active, int a, int b, T (&r)[P + 1])
+  {
+    using C         = DGCfg<P, T>;
+    constexpr int N = C::N, PX = C::PX;
+    T             q[N];
+    auto mulT = [&](const T(&in)[N], T(&out)[N]) { // out[m] = sum_i P1[i][m] in[i]
+#pragma unroll
+      for (int m = 0; m < N; ++m)
+        {
+          T s = P1[m] * in[0];
+#pragma unroll
+          for (int i = 1; i < N; ++i)
+            s = fma(P1[i * N + m], in[i], s);
+          out[m] = s;
+        }
+    };
+    if (active)
+      {
+        mulT(r, q);
+        st_line<N>(U, (b * N + a) * PX, 1, q);
+      }
+    __syncthreads();
+    if (active)
+      {
+        ld_line<N>(U, b * N * PX + a, PX, r);
+        mulT(r, q);
+        st_line<N>(U, b * N * PX + a, PX, q);
+      }
+    __syncthreads();
+    if (active)
+      {
+        ld_line<N>(U, b * PX + a, N * PX, r);
+        mulT(r, q);
+        st_line<N>(U, b * PX + a, N * PX, q);
+      }
+    __syncthreads();
+    if (active)
+      ld_line<N>(U, (b * N + a) * PX, 1, r);
+  }
+
+  // r[0 .. p] of the x-line (j, k) of an FE_Q cell added into the vector through the compressed index table
+  // (27 entities per cell: first DoF of every vertex / line / quad / hex entity, vector_access_reduced.h:153-247)
+  template <int P, typename T>
+  __device__ __forceinline__ void add_fe_q_line(T *__restrict__ dst, const uint32_t *__restrict__ idx27, uint32_t cell, int j,
+                                                int k, const T (&r)[P + 1], bool plain)
+  {
+    const int       cy = j == 0 ? 0 : (j == P ? 2 : 1), cz = k == 0 ? 0 : (k == P ? 2 : 1);
+    const int       oy = cy == 1 ? j - 1 : 0, oz = cz == 1 ? k - 1 : 0;
+    const uint32_t *ind = idx27 + 27u * (size_t)cell + 3 * (3 * cz + cy);
+    const uint32_t  off = (uint32_t)((cy == 1 ? P - 1 : 1) * oz + oy);
+    const uint32_t  b0 = ind[0], b1 = ind[1], b2 = ind[2];
+    auto add = [&](uint32_t at, T v) {
+      if (plain)
+        dst[at] += v;
+      else
+        unsafeAtomicAdd(&dst[at], v);
+    };
+    if (b0 != 0xFFFFFFFFu)
+      add(b0 + off, r[0]);
+    if (b1 != 0xFFFFFFFFu)
+      {
+#pragma unroll
+        for (int i = 0; i < P - 1; ++i)
+          add(b1 + off * (uint32_t)(P - 1) + (uint32_t)i, r[1 + i]);
+      }
+    if (b2 != 0xFFFFFFFFu)
+      add(b2 + off, r[P]);
+  }
+
   // GHOSTS (Hermite-like basis on a decomposed mesh): neighbour entries >= A.n_owned are ghost faces
   template <int P, typename T, int TYPE, int ACTION, bool GHOSTS = false>
   __global__ void __launch_bounds__((DGCfg<P, T>::THREADS), (DGCfg<P, T>::MINW)) dg_cell_kernel(const DGArgs<T> A)
   {
     using C         = DGCfg<P, T>;
     constexpr int N = C::N, NN2 = C::NN2, N3 = C::N3, PX = C::PX, VOL = C::VOL, FS = C::FS;
-    __shared__ T  lds[C::CPW * C::CELL];
+    __shared__ __attribute__((aligned(16))) T lds[C::CPW * C::CELL];
 #ifdef MGX_DG_LDS_PAD // occupancy experiment (tools/experiments): extra LDS per workgroup, in bytes
     __shared__ char lds_pad[MGX_DG_LDS_PAD];
     if (A.n_cells == 0xFFFFFFFFu) // never true; keeps the array allocated
@@ -436,7 +520,7 @@ namespace
     const bool store  = active && cell < A.n_cells;
     if (cell >= A.n_cells)
       cell = A.n_cells - 1;
-    cell = A.cell_list ? A.cell_list[cell] : cell + A.cell_first;
+    cell = A.cell_list ? A.cell_list[cell] : cell * A.cell_stride + A.cell_first;
 
     T *U  = lds + (active ? cw : 0) * C::CELL;
     T *GY = U + VOL, *GZ = U + 2 * VOL;
@@ -816,6 +900,59 @@ namespace
 #pragma unroll
             for (int i = 0; i < N; ++i)
               A.dst[lbase + i] = A.rhs[lbase + i] - y[i];
+          }
+      }
+    else if constexpr (ACTION == kRestrict)
+      {
+        // laplace_operator_dg.h:1798-1819
+        if (active)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              y[i] = A.rhs[lbase + i] - y[i];
+          }
+        __syncthreads(); // the x-lines above were read from U
+        to_fe_q_local<P, T>(A.P1, U, active, a, b, y);
+        if (store)
+          add_fe_q_line<P, T>(A.cg, A.idx27, cell, a, b, y, A.plain != 0);
+      }
+    else if constexpr (ACTION == kCgSums)
+      {
+        // laplace_operator_dg.h:1827-1838: dst.src, rhs.rhs, dst.rhs, dst.dst over the cells of the launch
+        double sum[4] = {0., 0., 0., 0.};
+        if (store)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              {
+                const T r        = A.rhs[lbase + i];
+                A.dst[lbase + i] = y[i];
+                sum[0] += (double)(y[i] * xs[i]);
+                sum[1] += (double)(r * r);
+                sum[2] += (double)(y[i] * r);
+                sum[3] += (double)(y[i] * y[i]);
+              }
+          }
+        constexpr int WAVES = C::THREADS / 64;
+        double       *red   = reinterpret_cast<double *>(lds);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+              sum[k] += __shfl_down(sum[k], o);
+            if ((tid & 63) == 0)
+              red[(tid >> 6) * 4 + k] = sum[k];
+          }
+        __syncthreads();
+        if (tid < 4)
+          {
+            double t4 = red[tid];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w)
+              t4 += red[w * 4 + tid];
+            A.partials[(size_t)blockIdx.x * 4 + tid] = t4;
           }
       }
     else
@@ -1485,6 +1622,10 @@ namespace
       {
         case kVmult:
           return launch_one<P, T, TYPE, kVmult>(s, a, ghosts);
+        case kRestrict:
+          return launch_one<P, T, TYPE, kRestrict>(s, a, ghosts);
+        case kCgSums:
+          return launch_one<P, T, TYPE, kCgSums>(s, a, ghosts);
         case kChebyshev:
           return launch_one<P, T, TYPE, kChebyshev>(s, a, ghosts);
         case kResidual:
@@ -1559,6 +1700,9 @@ struct mgx_dg_operator_s
   // (data_per_face of laplace_operator_dg.h:565)
   uint32_t               ghost_stride = 0;
   std::vector<uint8_t *> nb_faces_dev; // Hermite-like basis: face of every sent cell towards the neighbour rank
+  // block sums of the merged CG iteration (action 2) and their total, allocated at the first use
+  double  *cg_partials = nullptr, *cg_sums = nullptr;
+  uint32_t cg_capacity = 0;
 };
 
 // MultigridSolverDG (common/multigrid_solver_dg.h:55-747): the DG level on top of an FE_Q hierarchy
@@ -1690,9 +1834,28 @@ namespace
     return ghosts_exchange(op, vec, nullptr);
   }
 
+  // operands of the merged actions 1 and 2 (DGArgs)
+  struct MergedArgs
+  {
+    uint32_t        cell_stride = 1;
+    double         *partials    = nullptr;
+    void           *cg          = nullptr;
+    const uint32_t *idx27       = nullptr;
+    const void     *P1          = nullptr;
+    int             plain       = 0;
+  };
+
+  template <typename T>
+  uint32_t dg_grid(int p, uint32_t n_cells)
+  {
+    static const uint32_t cpw[10] = {1, DGCfg<1, T>::CPW, DGCfg<2, T>::CPW, DGCfg<3, T>::CPW, DGCfg<4, T>::CPW, DGCfg<5, T>::CPW,
+                                     DGCfg<6, T>::CPW, DGCfg<7, T>::CPW, DGCfg<8, T>::CPW, DGCfg<9, T>::CPW};
+    return (n_cells + cpw[p] - 1) / cpw[p];
+  }
+
   int launch_cells(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
                    int iteration_index, const uint32_t *cell_list, uint32_t n_cells, hipStream_t stream = nullptr,
-                   uint32_t cell_first = 0)
+                   uint32_t cell_first = 0, const MergedArgs &m = MergedArgs())
   {
     if (n_cells == 0)
       return MGX_OK;
@@ -1701,14 +1864,14 @@ namespace
       {
         DGArgs<double> a{(const double *)src, (const double *)rhs, (double *)dst, op->neigh,
                          (const DGConst<double> *)op->consts, (const double *)op->inv_diag, cell_list, cell_first, n_cells, op->n_cells, f1, f2,
-                         iteration_index};
+                         iteration_index, m.cell_stride, m.partials, (double *)m.cg, m.idx27, (const double *)m.P1, m.plain};
         launch_degree<double>(s, op->degree, op->basis, action, a, op->n_ghost > 0);
       }
     else
       {
         DGArgs<float> a{(const float *)src, (const float *)rhs, (float *)dst, op->neigh,
                         (const DGConst<float> *)op->consts, (const float *)op->inv_diag, cell_list, cell_first, n_cells, op->n_cells, (float)f1,
-                        (float)f2, iteration_index};
+                        (float)f2, iteration_index, m.cell_stride, m.partials, (float *)m.cg, m.idx27, (const float *)m.P1, m.plain};
         launch_degree<float>(s, op->degree, op->basis, action, a, op->n_ghost > 0);
       }
     DG_HIP(hipGetLastError());
@@ -1719,10 +1882,10 @@ namespace
   // refreshed first; the cells without a ghost neighbour run while that exchange is in flight on the
   // context's side stream (with the blocking callback transport: while the host waits in it).
   int run(mgx_dg_operator_t op, int action, void *dst, const void *rhs, const void *src, double f1, double f2,
-          int iteration_index, bool with_ghosts = false)
+          int iteration_index, bool with_ghosts = false, const MergedArgs &m = MergedArgs())
   {
     if (!with_ghosts || op->n_ghost == 0)
-      return launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, nullptr, op->n_cells);
+      return launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, nullptr, op->n_cells, nullptr, 0, m);
     void *ghosted = const_cast<void *>(src);
     MGX_DG_TRY(ghosts_pack(op, src));
     hipStream_t side = (op->n_interior > 0 && !mgx::context_tunables(op->ctx).dg_no_overlap) ? mgx::side_stream_begin(op->ctx)
@@ -1730,7 +1893,7 @@ namespace
     if (!side)
       {
         MGX_DG_TRY(ghosts_exchange(op, ghosted, nullptr));
-        return launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, nullptr, op->n_cells);
+        return launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, nullptr, op->n_cells, nullptr, 0, m);
       }
     // main stream: interior cells; side stream: exchange, then the cells next to a ghost cell (they
     // write other cells of dst than the interior launch and share its read-only operands)
@@ -1739,12 +1902,16 @@ namespace
     const uint32_t *lb = op->interior_is_prefix ? nullptr : op->boundary_cells;
     // whatever fails below, the main stream is ordered behind the side stream again before returning:
     // nothing of this application may still be in flight when the caller reuses src / dst
-    int status = launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, li, op->n_interior);
+    int status = launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, li, op->n_interior, nullptr, 0, m);
     if (status == MGX_OK)
       status = ghosts_exchange(op, ghosted, side);
+    MergedArgs mb = m; // the block sums of the second launch behind those of the first
+    if (m.partials)
+      mb.partials += 4 * (size_t)(op->number == MGX_F64 ? dg_grid<double>(op->degree, op->n_interior)
+                                                        : dg_grid<float>(op->degree, op->n_interior));
     if (status == MGX_OK)
       status = launch_cells(op, action, dst, rhs, src, f1, f2, iteration_index, lb, op->n_boundary, side,
-                            op->interior_is_prefix ? op->n_interior : 0);
+                            op->interior_is_prefix ? op->n_interior : 0, mb);
     const int joined = mgx::side_stream_end(op->ctx);
     return status != MGX_OK ? status : joined;
   }
@@ -1974,6 +2141,8 @@ int mgx_dg_operator_destroy(mgx_dg_operator_t op)
   (void)hipFree(op->inv_diag);
   (void)hipFree(op->interior_cells);
   (void)hipFree(op->boundary_cells);
+  (void)hipFree(op->cg_partials);
+  (void)hipFree(op->cg_sums);
   for (auto *p : op->nb_cells_dev)
     (void)hipFree(p);
   for (auto *p : op->nb_send)
@@ -2033,6 +2202,48 @@ int mgx_dg_vmult_with_chebyshev_update(mgx_dg_operator_t op, const void *rhs, un
   if (!solution_old || solution_old == solution)
     return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_with_chebyshev_update: solution_old is null or aliases solution");
   return run(op, kChebyshev, solution_old, rhs, solution, factor1, factor2, (int)iteration_index, true);
+}
+
+int mgx_dg_vmult_with_cg_update(mgx_dg_operator_t op, double alpha, double beta, const void *r, void *q, void *p, void *x,
+                                double sums[4])
+{
+  if (!op || !r || !q || !p || !x || !sums || q == p)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_with_cg_update: null or aliased vectors");
+  hipStream_t    s      = (hipStream_t)mgx_context_stream(op->ctx);
+  const bool     f64    = op->number == MGX_F64;
+  const bool     split  = op->n_ghost > 0 && op->n_interior > 0;
+  const uint32_t blocks = f64 ? (split ? dg_grid<double>(op->degree, op->n_interior) + dg_grid<double>(op->degree, op->n_boundary)
+                                       : dg_grid<double>(op->degree, op->n_cells))
+                              : (split ? dg_grid<float>(op->degree, op->n_interior) + dg_grid<float>(op->degree, op->n_boundary)
+                                       : dg_grid<float>(op->degree, op->n_cells));
+  if (blocks > op->cg_capacity)
+    {
+      if (op->cg_partials)
+        DG_HIP(hipFree(op->cg_partials));
+      op->cg_partials = nullptr;
+      op->cg_capacity = 0;
+      DG_HIP(hipMalloc(&op->cg_partials, sizeof(double) * 4 * (size_t)blocks));
+      op->cg_capacity = blocks;
+    }
+  if (!op->cg_sums)
+    DG_HIP(hipMalloc(&op->cg_sums, sizeof(double) * 4));
+  // laplace_operator_dg.h:871-902: x += alpha p ; p = beta p + q (alpha == 0: p = q) on the owned entries
+  mgx::launch_cg_pre(s, op->number, x, p, q, alpha, beta, (size_t)mgx_dg_operator_n_dofs(op));
+  // :903 q = A p with the sums of the next iteration
+  if (op->n_cells == 0)
+    DG_HIP(hipMemsetAsync(op->cg_sums, 0, sizeof(double) * 4, s));
+  else
+    {
+      // without the overlap of the ghost exchange the cells run in one launch: its blocks are not the split's
+      DG_HIP(hipMemsetAsync(op->cg_partials, 0, sizeof(double) * 4 * (size_t)blocks, s));
+      MergedArgs m;
+      m.partials = op->cg_partials;
+      MGX_DG_TRY(run(op, kCgSums, q, r, p, 0, 0, 0, true, m));
+      mgx::launch_reduce4(s, op->cg_partials, blocks, nullptr, op->cg_sums);
+    }
+  DG_HIP(hipMemcpyAsync(sums, op->cg_sums, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+  DG_HIP(hipStreamSynchronize(s));
+  return mgx::allreduce_sum(op->ctx, sums, 4); // :904-906
 }
 
 int mgx_dg_operator_info(mgx_dg_operator_t op, double *hderiv, double penalty[3], double eigenvalues_1d[MGX_MAX_DEGREE + 1])
@@ -2201,18 +2412,51 @@ namespace
     return MGX_OK;
   }
 
+  // vmult_residual_and_restrict_to_cg (laplace_operator_dg.h:853-861, action 1 :1798-1819): cg = sum over the cells of
+  // P^T (rhs - A lhs), inside the cell kernel.  Cells c, c + 8, ... share no FE_Q DoF when the mesh is in forest order:
+  // eight launches with plain adds (the sum is then the same in every run); one launch with atomics otherwise.
+  int dg_residual_and_restrict(mgx_dg_solver_t S, void *cg, const void *rhs, const void *lhs)
+  {
+    hipStream_t       s  = (hipStream_t)mgx_context_stream(S->ctx);
+    mgx_dg_operator_t op = S->A;
+    DG_HIP(hipMemsetAsync(cg, 0, dg_nsz(S->number) * S->n_cg, s));
+    if (op->n_ghost > 0)
+      MGX_DG_TRY(update_ghosts(op, const_cast<void *>(lhs)));
+    MergedArgs m;
+    m.cg    = cg;
+    m.idx27 = S->idx27;
+    m.P1    = S->P1;
+    if (!S->cg_eight_colours)
+      MGX_DG_TRY(launch_cells(op, kRestrict, nullptr, rhs, lhs, 0, 0, 0, nullptr, op->n_cells, nullptr, 0, m));
+    else
+      {
+        m.plain       = 1;
+        m.cell_stride = 8;
+        for (uint32_t k = 0; k < 8 && k < op->n_cells; ++k)
+          MGX_DG_TRY(launch_cells(op, kRestrict, nullptr, rhs, lhs, 0, 0, 0, nullptr, (op->n_cells - k + 7) / 8, nullptr, k, m));
+      }
+    if (S->decomposed) // FE_Q DoFs on a rank interface collect the contributions of all sharers
+      MGX_DG_TRY(mgx_exchange_add(S->fe, cg));
+    return MGX_OK;
+  }
+
   // dg_v_cycle(1) (multigrid_solver_dg.h:605-633): defect in, update out
   int dg_v_cycle(mgx_dg_solver_t S)
   {
     hipStream_t s = (hipStream_t)mgx_context_stream(S->ctx);
     MGX_DG_TRY(dg_smoother_apply(S, false));
-    // vmult_residual_and_restrict_to_cg (:616-618; laplace_operator_dg.h:1798-1819)
-    MGX_DG_TRY(mgx_dg_vmult_residual(S->A, S->t, S->defect, S->update));
-    DG_HIP(hipMemsetAsync(S->cg_defect, 0, dg_nsz(S->number) * S->n_cg, s));
-    mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, S->cg_defect, S->t, S->idx27, S->n_cells, S->P1,
-                               S->cg_eight_colours);
-    if (S->decomposed) // FE_Q DoFs on a rank interface collect the contributions of all sharers
-      MGX_DG_TRY(mgx_exchange_add(S->fe, S->cg_defect));
+    // vmult_residual_and_restrict_to_cg (:616-618)
+    if (!mgx::context_tunables(S->ctx).dg_unmerged_restrict)
+      MGX_DG_TRY(dg_residual_and_restrict(S, S->cg_defect, S->defect, S->update));
+    else
+      {
+        MGX_DG_TRY(mgx_dg_vmult_residual(S->A, S->t, S->defect, S->update));
+        DG_HIP(hipMemsetAsync(S->cg_defect, 0, dg_nsz(S->number) * S->n_cg, s));
+        mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, S->cg_defect, S->t, S->idx27, S->n_cells, S->P1,
+                                   S->cg_eight_colours);
+        if (S->decomposed) // FE_Q DoFs on a rank interface collect the contributions of all sharers
+          MGX_DG_TRY(mgx_exchange_add(S->fe, S->cg_defect));
+      }
     MGX_DG_TRY(mgx_solver_v_cycle(S->cfe)); // :622
     // prolongate_add_cg_to_dg (:625; laplace_operator_dg.h:1863-1894)
     mgx::launch_dg_cg_transfer(s, S->number, S->degree, true, S->update, S->cg_update, S->idx27, S->n_cells, S->P1);
@@ -2269,6 +2513,8 @@ int mgx_dg_solver_create(mgx_context_t ctx, const mgx_dg_solver_desc *desc, mgx_
           {
             const uint32_t v = h27[27 * (size_t)c + e];
             if (v == 0xFFFFFFFFu || v >= ncg)
+              continue;
+            if (S->degree == 1 && (e % 3 == 1 || (e / 3) % 3 == 1 || e / 9 == 1)) // entity without DoFs
               continue;
             // an entity's first DoF identifies it; stamp = class * nc + cell would overflow: class and cell apart
             const uint32_t mark = k * 0x10000000u + (c >> 3);
@@ -2432,6 +2678,13 @@ int mgx_dg_restrict_to_cg(mgx_dg_solver_t S, void *cg_dst, const void *dg_src)
   mgx::launch_dg_cg_transfer(s, S->number, S->degree, false, cg_dst, dg_src, S->idx27, S->n_cells, S->P1, S->cg_eight_colours);
   DG_HIP(hipGetLastError());
   return MGX_OK;
+}
+
+int mgx_dg_vmult_residual_and_restrict_to_cg(mgx_dg_solver_t S, void *cg_dst, const void *rhs, const void *lhs)
+{
+  if (!S || !cg_dst || !rhs || !lhs)
+    return dg_fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dg_vmult_residual_and_restrict_to_cg: null argument");
+  return dg_residual_and_restrict(S, cg_dst, rhs, lhs);
 }
 
 int mgx_dg_prolongate_add_cg_to_dg(mgx_dg_solver_t S, void *dg_dst, const void *cg_src)

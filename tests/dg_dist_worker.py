@@ -58,6 +58,15 @@ def main():
         op.vmult_with_chebyshev_update(b, 2, 0.6, 0.2, out, inp)
         ro, ri = o.vmult_with_chebyshev_update(rhs, 2, 0.6, 0.2, ro, ri)
     assert rel(owned(out), mine(ro)) < 50 * tol, "loop"
+    # merged CG iteration (action 2): the sums cover every rank's owned cells
+    r, q, pv = (rng.standard_normal(o.shape) for _ in range(3))
+    R, Q, Pv, X = (op.initialize_dof_vector(mine(a)) for a in (r, q, pv, x))
+    sums = op.vmult_with_cg_update(0.37, 0.81, R, Q, Pv, X)
+    p_ref = 0.81 * pv + q
+    q_ref = o.vmult(p_ref)
+    assert rel(owned(Q), mine(q_ref)) < 5 * tol and rel(owned(X), mine(x + 0.37 * pv)) < 5 * tol, "cg update"
+    ref = np.array([(q_ref * p_ref).sum(), (r * r).sum(), (q_ref * r).sum(), (q_ref * q_ref).sum()])
+    assert np.allclose(sums, ref, rtol=100 * tol, atol=100 * tol * abs(ref).max()), ("cg sums", sums, ref)
     print("rank %d dg ok: %d owned cells, %d ghost cells, %d neighbours" % (rank, len(ijk), part["n_ghost"], len(part["exchange"])),
           flush=True)
     op.clear()

@@ -135,6 +135,35 @@ def test_block_jacobi_and_merged_chebyshev_update(ctx, p, kind, number):
     case.close()
 
 
+@pytest.mark.parametrize("number", [mg.F64, mg.F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", [dg.HERMITE, dg.GAUSS_LOBATTO, dg.GAUSS], ids=["hermite", "gl", "gauss"])
+@pytest.mark.parametrize("p", [2, 3, 4, 6])
+def test_merged_cg_update(ctx, p, kind, number):
+    """vmult_with_cg_update (laplace_operator_dg.h:863-908, action 2): the vector updates, q = A p and the four
+    sums of the cell kernel's epilogue; then the CG loop built on it converges like the textbook one"""
+    cells, jac = dg.cheby_mesh(5)
+    case = Case(ctx, p, kind, cells, jac, number)
+    o = case.orc
+    rng = np.random.default_rng(11 + p)
+    r, q, pv, x = (rng.standard_normal(o.shape) for _ in range(4))
+    tol = TOL[number] * 5
+    for alpha, beta in ((0.0, 0.0), (0.37, 0.81)):
+        R, Q, Pv, X = case.up(r), case.up(q), case.up(pv), case.up(x)
+        sums = case.op.vmult_with_cg_update(alpha, beta, R, Q, Pv, X)
+        if alpha == 0.0:
+            x_ref, p_ref = x, q
+        else:
+            x_ref, p_ref = x + alpha * pv, beta * pv + q
+        q_ref = o.vmult(p_ref)
+        assert rel(case.down(X), x_ref) < tol and rel(case.down(Pv), p_ref) < tol
+        assert rel(case.down(Q), q_ref) < tol
+        ref = np.array([(q_ref * p_ref).sum(), (r * r).sum(), (q_ref * r).sum(), (q_ref * q_ref).sum()])
+        assert np.allclose(sums, ref, rtol=tol * 20, atol=tol * 20 * abs(ref).max())
+        again = case.op.vmult_with_cg_update(alpha, beta, case.up(r), case.up(q), case.up(pv), case.up(x))
+        assert np.array_equal(again, sums)   # block sums added in a fixed order
+    case.close()
+
+
 def test_operator_properties_at_benchmark_size(ctx):
     """FE_DGQHermite(4) on the harness mesh after 15 steps (32^3 cells, 4.1 M DoFs, fp32): symmetry,
     definiteness and reproducibility -- the oracle cannot run this size in seconds"""

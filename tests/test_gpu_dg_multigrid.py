@@ -83,6 +83,33 @@ def test_transfers_between_dg_and_fe_q(ctx, p, nr, basis, number, tol):
     P.close()
 
 
+@pytest.mark.parametrize("number,tol", [(mg.F64, 1e-10), (mg.F32, 1e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("p,nr,basis", [(2, 2, 0), (3, 2, 0), (4, 2, 0), (3, 2, 1), (3, 2, 2), (1, 3, 0), (5, 1, 0), (3, 3, 0)])
+def test_merged_residual_and_restriction(ctx, p, nr, basis, number, tol):
+    """vmult_residual_and_restrict_to_cg (laplace_operator_dg.h:852-861, action 1) against the two steps of the
+    oracle, and bit for bit against itself (eight colours of cells, plain adds)"""
+    P = Pair(ctx, p, nr, basis, number)
+    rng = np.random.default_rng(3 * p + nr)
+    l = P.cube.max_level
+    rhs, lhs = rng.standard_normal(P.dgo.shape), rng.standard_normal(P.dgo.shape)
+    b, x = (ctx.vector(P.solver.m(), number, P.to_product(a)) for a in (rhs, lhs))
+    cg = ctx.vector(P.cube.n_dofs(l), number, np.full(P.cube.n_dofs(l), 7.0))
+    P.solver.vmult_residual_and_restrict_to_cg(cg, b, x)
+    ref = P.orc.restrict_to_cg(rhs - P.dgo.vmult(lhs))[P.cg_to_oracle]
+    got = cg.download()
+    assert rel(got.astype(float), ref) < tol
+    # the unmerged pair of kernels gives the same vector up to rounding
+    t = ctx.vector(P.solver.m(), number)
+    P.solver.matrix_dg.vmult_residual(t, b, x)
+    cg2 = ctx.vector(P.cube.n_dofs(l), number)
+    P.solver.restrict_to_cg(cg2, t)
+    assert rel(got.astype(float), cg2.download().astype(float)) < (1e-12 if number == mg.F64 else 1e-5)
+    if P.cube.n_cells(l) >= 64:   # eight colours of cells; atomics below
+        P.solver.vmult_residual_and_restrict_to_cg(cg, b, x)
+        assert np.array_equal(cg.download(), got)
+    P.close()
+
+
 @pytest.mark.parametrize("p,nr,basis", [(2, 2, 0), (3, 2, 0), (4, 2, 0), (3, 3, 0), (3, 2, 2), (2, 2, 1)])
 def test_dg_v_cycle_and_pcg_fp64(ctx, p, nr, basis):
     P = Pair(ctx, p, nr, basis, mg.F64)

@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--vcycle", choices=["f32", "f64"], default="f32")
     ap.add_argument("--basis", type=int, default=0)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="context option (include/mgx.h mgx_context_set_option), e.g. dg_unmerged_restrict=1")
     ap.add_argument("--solution", choices=["reference", "vanishing"], default="reference",
                     help="reference: prod sin(3 pi x_d) as program.cc:95-100; vanishing: zero on the boundary (convergence check)")
     a = ap.parse_args()
@@ -86,7 +88,7 @@ def main():
 
     vnum = mg.F32 if a.vcycle == "f32" else mg.F64
     t0 = time.time()
-    ctx = mg.Context(local_rank)
+    ctx = mg.Context(local_rank, options={k: float(v) for k, v in (o.split("=") for o in a.option)})
     if world > 1:
         comm = mg.Communicator(ctx, dist)
         if comm.native_ready:
