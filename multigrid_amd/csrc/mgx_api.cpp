@@ -148,6 +148,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"no_graph", &no_graph, nullptr},
     {"dg_no_overlap", &dg_no_overlap, nullptr},
     {"dg_unmerged_restrict", &dg_unmerged_restrict, nullptr},
+    {"no_fused_decomposed", &no_fused_decomposed, nullptr},
     // emulation of a rank of a decomposed mesh on one GPU (tools/rank_emulation.py): the results are WRONG
     {"rccl_selftest", &rccl_selftest, nullptr},
   };
@@ -244,6 +245,7 @@ struct mgx_context_s
   int         device = 0;
   Tunables    tun; // environment switches, read once in mgx_context_create
   hipStream_t stream = nullptr;
+  bool        borrowed_stream = false; // the stream of the context of the decomposed hierarchy above (agglomerated levels)
   // interface exchange overlapped with the interior bricks: side stream and the two events that
   // order it against `stream` (created with the communicator)
   hipStream_t side     = nullptr;
@@ -815,7 +817,10 @@ int mgx_context_destroy(mgx_context_t ctx)
 {
   if (!ctx)
     return MGX_OK;
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->borrowed_stream)
+    (void)hipDeviceSynchronize(); // the stream's owner may be gone already
+  else
+    (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->partial_dev);
   (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
@@ -834,7 +839,8 @@ int mgx_context_destroy(mgx_context_t ctx)
     (void)hipEventDestroy(ctx->ev_iface);
   if (ctx->ev_side)
     (void)hipEventDestroy(ctx->ev_side);
-  (void)hipStreamDestroy(ctx->stream);
+  if (!ctx->borrowed_stream)
+    (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MGX_OK;
 }
@@ -2125,7 +2131,7 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 //   4 with out == 0 on entry.  sm->tmp carries the partial sums of brick-surface DoFs.
 static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, const void *old, void *out,
                                 const void *b, double f1, double f2, double f0 = 0., const void *coarse = nullptr,
-                                const uint32_t *coarse_blocks = nullptr)
+                                const uint32_t *coarse_blocks = nullptr, const TransferData *prolong_tr = nullptr)
 {
   mgx_operator_t op = sm->op;
   hipStream_t    s  = op->ctx->stream;
@@ -2138,8 +2144,12 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
                         coarse_blocks, g0, g1, fr);
     },
     [&](hipStream_t st) {
-      launch_cheb_constrained(st, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
-                              op->plan->n_shared, sm->tmp, old, f0);
+      if (mode == 9) // the shared DoFs start from x + P x_coarse as well (and store it: x_old of the next iteration)
+        launch_interface_prolong_cheb(st, op->d.number, *prolong_tr, op->plan->shared_dev, coarse, const_cast<void *>(cur), out, b,
+                                      op->d.inv_diag, f2, sm->tmp);
+      else
+        launch_cheb_constrained(st, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->plan->shared_dev,
+                                op->plan->n_shared, sm->tmp, old, f0);
     },
     fr,
     [&](hipStream_t st, uint32_t first, uint32_t count) {
@@ -2161,7 +2171,7 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
 // prolong_coarse / prolong_blocks (step only): the coarse-grid correction P x_coarse is added to x on
 // the fly by the first iteration (mode 9) instead of by a prolongation kernel before the call
 static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_step, const void *prolong_coarse = nullptr,
-                          const uint32_t *prolong_blocks = nullptr)
+                          const uint32_t *prolong_blocks = nullptr, const TransferData *prolong_tr = nullptr)
 {
   const mgx_smoother_info &I  = sm->info;
   mgx_operator_t           op = sm->op;
@@ -2236,7 +2246,7 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
         out = k == 1 ? Y : (k == 2 ? Z : (k == 3 ? X : ((cur == X) ? Y : X)));
       if (k == 1)
         MGX_TRY(cheb_fused_iteration(sm, prolong_blocks ? 9 : 3, cur, nullptr, out, b, 0., sm->first_factor(), 0.,
-                                     prolong_coarse, prolong_blocks));
+                                     prolong_coarse, prolong_blocks, prolong_tr));
       else
         {
           double f1, f2;
@@ -2266,6 +2276,149 @@ int mgx_smoother_step(mgx_smoother_t sm, void *x, const void *b)
 /* ------------------------------------------------------------------------------------------
  * MGTransferMatrixFree (one level pair)
  * ------------------------------------------------------------------------------------------ */
+// Fused level transfers on a decomposed mesh (TransferData::ifr_*, ifp_*): the brick loop restricts / prolongates the
+// DoFs it completes itself; the DoFs on the rank interface are completed after the exchange, by list kernels that
+// need their rows of P spelled out.  P is interpolatory: a fine DoF on a shared mesh entity couples to coarse DoFs of
+// that entity only, so the first parent found holds its whole row.  idxc: the coarse operator's index table (host).
+static int build_interface_transfer(mgx_transfer_s *tr, const mgx_transfer_desc *desc, const std::vector<uint32_t> &idxc)
+{
+  mgx_operator_t      fine = tr->fine, coarse = tr->coarse;
+  const int           p = fine->d.p, n = p + 1;
+  const uint32_t      npar = coarse->d.n_cells, nsh = fine->plan->n_shared;
+  const ExchangePlan &pl = *fine->plan;
+  std::vector<uint32_t> shared(nsh), pos(fine->d.n_dofs, kInvalid);
+  if (nsh)
+    MGX_HIP(hipMemcpy(shared.data(), pl.shared_dev, sizeof(uint32_t) * nsh, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < nsh; ++i)
+    pos[shared[i]] = i;
+  std::vector<uint8_t> foreign(nsh, 0), done(nsh, 0);
+  for (uint32_t d : pl.not_owned_host)
+    if (pos[d] != kInvalid)
+      foreign[pos[d]] = 1;
+  std::vector<uint32_t> idxf(27 * (size_t)fine->d.n_cells);
+  MGX_HIP(hipMemcpy(idxf.data(), fine->d.idx27, sizeof(uint32_t) * idxf.size(), hipMemcpyDeviceToHost));
+  auto dof_of = [p](const uint32_t *ind, int ix, int iy, int iz) {
+    const int      i[3] = {ix, iy, iz};
+    int            code[3], off[3], len[3];
+    for (int d = 0; d < 3; ++d)
+      {
+        code[d] = i[d] == 0 ? 0 : (i[d] == p ? 2 : 1);
+        off[d]  = code[d] == 1 ? i[d] - 1 : 0;
+        len[d]  = code[d] == 1 ? p - 1 : 1;
+      }
+    const uint32_t base = ind[(code[2] * 3 + code[1]) * 3 + code[0]];
+    return base == kInvalid ? kInvalid : base + (uint32_t)((off[2] * len[1] + off[1]) * len[0] + off[0]);
+  };
+  struct Entry
+  {
+    uint32_t si, cdof;
+    double   w;
+  };
+  std::vector<Entry> ent;
+  for (uint32_t pc = 0; pc < npar; ++pc)
+    for (int ch = 0; ch < 8; ++ch)
+      {
+        const uint32_t *indf = &idxf[27 * (size_t)desc->children[8 * (size_t)pc + ch]];
+        bool            any = false;
+        for (int e = 0; e < 27 && !any; ++e)
+          any = indf[e] != kInvalid && indf[e] < fine->d.n_dofs && pos[indf[e]] != kInvalid &&
+                (p > 1 || (e % 3 != 1 && (e / 3) % 3 != 1 && e / 9 != 1));
+        if (!any)
+          continue;
+        for (int iz = 0; iz < n; ++iz)
+          for (int iy = 0; iy < n; ++iy)
+            for (int ix = 0; ix < n; ++ix)
+              {
+                const uint32_t d = dof_of(indf, ix, iy, iz);
+                if (d == kInvalid || pos[d] == kInvalid || done[pos[d]])
+                  continue;
+                const uint32_t si = pos[d];
+                done[si]          = 1;
+                const int F[3]    = {(ch & 1) * p + ix, ((ch >> 1) & 1) * p + iy, ((ch >> 2) & 1) * p + iz};
+                for (int az = 0; az < n; ++az)
+                  for (int ay = 0; ay < n; ++ay)
+                    for (int ax = 0; ax < n; ++ax)
+                      {
+                        const double w = desc->prolong_1d[F[0] * n + ax] * desc->prolong_1d[F[1] * n + ay] *
+                                         desc->prolong_1d[F[2] * n + az];
+                        if (std::fabs(w) < 1e-14)
+                          continue;
+                        const uint32_t c = dof_of(&idxc[27 * (size_t)pc], ax, ay, az);
+                        if (c != kInvalid)
+                          ent.push_back({si, c, w});
+                      }
+              }
+      }
+  for (uint32_t i = 0; i < nsh; ++i)
+    if (!done[i])
+      return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_transfer_create: a shared DoF of the fine level lies in no cell");
+  const int    num = fine->d.number;
+  const size_t wsz = number_size(num);
+  auto upload_w = [&](const std::vector<double> &w, void **dev) -> int {
+    MGX_HIP(hipMalloc(dev, wsz * std::max<size_t>(1, w.size())));
+    if (num == MGX_F64)
+      MGX_HIP(hipMemcpy(*dev, w.data(), 8 * w.size(), hipMemcpyHostToDevice));
+    else
+      {
+        std::vector<float> wf(w.begin(), w.end());
+        MGX_HIP(hipMemcpy(*dev, wf.data(), 4 * wf.size(), hipMemcpyHostToDevice));
+      }
+    return MGX_OK;
+  };
+  auto upload_u = [&](const std::vector<uint32_t> &v, uint32_t **dev) -> int {
+    MGX_HIP(hipMalloc((void **)dev, sizeof(uint32_t) * std::max<size_t>(1, v.size())));
+    MGX_HIP(hipMemcpy(*dev, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice));
+    return MGX_OK;
+  };
+  // prolongation: rows in the order of the shared list
+  {
+    std::stable_sort(ent.begin(), ent.end(), [](const Entry &a, const Entry &b) { return a.si < b.si; });
+    std::vector<uint32_t> start(nsh + 1, 0), cd(ent.size());
+    std::vector<double>   w(ent.size());
+    for (const Entry &e : ent)
+      start[e.si + 1]++;
+    for (uint32_t i = 0; i < nsh; ++i)
+      start[i + 1] += start[i];
+    for (size_t k = 0; k < ent.size(); ++k)
+      {
+        cd[k] = ent[k].cdof;
+        w[k]  = ent[k].w;
+      }
+    MGX_TRY(upload_u(start, &tr->d.ifp_start));
+    MGX_TRY(upload_u(cd, &tr->d.ifp_cdof));
+    MGX_TRY(upload_w(w, &tr->d.ifp_w));
+    tr->d.n_ifp = nsh;
+  }
+  // restriction: rows by coarse DoF, only the fine DoFs this rank owns (the coarse sums are added over the ranks)
+  {
+    std::vector<Entry> own;
+    for (const Entry &e : ent)
+      if (!foreign[e.si])
+        own.push_back(e);
+    std::stable_sort(own.begin(), own.end(), [](const Entry &a, const Entry &b) { return a.cdof < b.cdof; });
+    std::vector<uint32_t> cdof, start, fd(own.size());
+    std::vector<double>   w(own.size());
+    for (size_t k = 0; k < own.size(); ++k)
+      {
+        if (k == 0 || own[k].cdof != own[k - 1].cdof)
+          {
+            cdof.push_back(own[k].cdof);
+            start.push_back((uint32_t)k);
+          }
+        fd[k] = shared[own[k].si];
+        w[k]  = own[k].w;
+      }
+    start.push_back((uint32_t)own.size());
+    MGX_TRY(upload_u(cdof, &tr->d.ifr_cdof));
+    MGX_TRY(upload_u(start, &tr->d.ifr_start));
+    MGX_TRY(upload_u(fd, &tr->d.ifr_fdof));
+    MGX_TRY(upload_w(w, &tr->d.ifr_w));
+    tr->d.n_ifr = (uint32_t)cdof.size();
+  }
+  MGX_TRACE("transfer_create: interface rows: %u shared fine DoFs, %zu entries, %u coarse rows", nsh, ent.size(), tr->d.n_ifr);
+  return MGX_OK;
+}
+
 int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_transfer_desc *desc,
                         mgx_transfer_t *out)
 {
@@ -2480,8 +2633,9 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   // transfer kernels they replace (measured V-cycle at 64^3 cells: p = 7 10.4 ms fused, 9.4 ms separate;
   // p = 8 13.7 / 13.3 ms; p = 5, 6, 9 are 5-8 % faster fused) -- no coarse blocks, so neither fused form runs
   const bool fused_pays = (p != 7 && p != 8) || coarse->ctx->tun.force_fused_transfers;
-  if (fine->d.bricks.available() && fine->d.separable && !fine->plan && !coarse->plan && fused_pays &&
-      !coarse->ctx->tun.no_fused_restrict)
+  // (decomposed mesh: both levels decomposed alike -- not across an agglomeration -- and interface rows, above)
+  if (fine->d.bricks.available() && fine->d.separable && (!fine->plan == !coarse->plan) && fused_pays &&
+      !coarse->ctx->tun.no_fused_restrict && !(fine->plan && coarse->ctx->tun.no_fused_decomposed))
     {
       bool forest = true;
       for (size_t i = 0; i < 8 * (size_t)npar && forest; ++i)
@@ -2534,6 +2688,15 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
                   tab[(size_t)sb * CE3 + e] = word;
                 }
             }
+          if (consistent && fine->plan)
+            {
+              const int status = build_interface_transfer(tr.get(), desc, idxc);
+              if (status != MGX_OK)
+                {
+                  (void)mgx_transfer_destroy(tr.release());
+                  return status;
+                }
+            }
           if (consistent)
             {
               MGX_HIP(hipMalloc((void **)&tr->d.coarse_blocks, sizeof(uint32_t) * tab.size()));
@@ -2560,6 +2723,9 @@ int mgx_transfer_destroy(mgx_transfer_t tr)
   (void)hipFree(tr->d.own27);
   (void)hipFree(tr->d.patch);
   (void)hipFree(tr->d.coarse_blocks);
+  for (void *q : {(void *)tr->d.ifr_cdof, (void *)tr->d.ifr_start, (void *)tr->d.ifr_fdof, tr->d.ifr_w, (void *)tr->d.ifp_start,
+                  (void *)tr->d.ifp_cdof, tr->d.ifp_w})
+    (void)hipFree(q);
   (void)hipFree(tr->scratch);
   delete tr;
   return MGX_OK;
@@ -2845,11 +3011,17 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
           MGX_HIP(hipStreamSynchronize(s));
         }
     }
-  MGX_HIP(hipEventRecord(S->agg_in, s));
-  MGX_HIP(hipStreamWaitEvent(sg, S->agg_in, 0));
+  if (sg != s)
+    {
+      MGX_HIP(hipEventRecord(S->agg_in, s));
+      MGX_HIP(hipStreamWaitEvent(sg, S->agg_in, 0));
+    }
   MGX_TRY(v_cycle(G, L, my_n_cycles));
-  MGX_HIP(hipEventRecord(S->agg_out, sg));
-  MGX_HIP(hipStreamWaitEvent(s, S->agg_out, 0));
+  if (sg != s)
+    {
+      MGX_HIP(hipEventRecord(S->agg_out, sg));
+      MGX_HIP(hipStreamWaitEvent(s, S->agg_out, 0));
+    }
   launch_pack(s, num, S->solution_update[L], G->solution_update[L], S->agg_map, (uint32_t)nl);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
@@ -2878,6 +3050,14 @@ int mgx_solver_set_agglomeration(mgx_solver_t S, int level, mgx_solver_t coarse,
   MGX_HIP(hipMemcpy(S->agg_owned, owned, n_local, hipMemcpyHostToDevice));
   MGX_HIP(hipEventCreateWithFlags(&S->agg_in, hipEventDisableTiming));
   MGX_HIP(hipEventCreateWithFlags(&S->agg_out, hipEventDisableTiming));
+  // the copy runs in line with the decomposed levels: on their stream (no event hops around its graph)
+  if (!coarse->ctx->borrowed_stream && coarse->ctx->device == S->ctx->device)
+    {
+      MGX_HIP(hipStreamSynchronize(coarse->ctx->stream));
+      MGX_HIP(hipStreamDestroy(coarse->ctx->stream));
+      coarse->ctx->stream          = S->ctx->stream;
+      coarse->ctx->borrowed_stream = true;
+    }
   S->agg_solver = coarse;
   S->agg_level  = level;
   return MGX_OK;
@@ -2948,9 +3128,29 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
           Stopwatch      sw(S, level, 0);
           mgx_operator_t A = S->matrix[level];
           MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s)); // :667
-          ProfileBracket pb(A, 7);
-          launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level],
-                            0., 0., nullptr, 0., S->defect[level - 1], S->transfer[level]->d.coarse_blocks);
+          if (!A->plan)
+            {
+              ProfileBracket pb(A, 7);
+              launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level],
+                                0., 0., nullptr, 0., S->defect[level - 1], S->transfer[level]->d.coarse_blocks);
+            }
+          else
+            {
+              // decomposed: the residuals of the DoFs on the rank interface exist after the exchange of their sums
+              // in t; their owners restrict them (interior bricks, which may still run, touch no interface DoF of
+              // either level), then the coarse defect is summed over the ranks like any restricted vector
+              const TransferData &T = S->transfer[level]->d;
+              MGX_TRY(brick_loop_with_exchange(
+                A, 7, S->t[level],
+                [&](hipStream_t st, int g0, int g1) {
+                  launch_brick_loop(st, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level], 0.,
+                                    0., nullptr, 0., S->defect[level - 1], T.coarse_blocks, g0, g1, false);
+                },
+                [&](hipStream_t st) {
+                  launch_interface_restrict(st, A->d.number, T, S->defect[level - 1], S->defect[level], S->t[level]);
+                }));
+              MGX_TRY(exchange_add(S->matrix[level - 1], S->defect[level - 1]));
+            }
         }
       else
         {
@@ -2975,7 +3175,7 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
         {
           Stopwatch sw(S, level, 5);
           MGX_TRY(smoother_apply(S->smooth[level], S->solution_update[level], S->defect[level], true,
-                                 S->solution_update[level - 1], S->transfer[level]->d.coarse_blocks));
+                                 S->solution_update[level - 1], S->transfer[level]->d.coarse_blocks, &S->transfer[level]->d));
         }
       else
         {

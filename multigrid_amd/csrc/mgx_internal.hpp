@@ -32,6 +32,7 @@ namespace mgx
     bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
     uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads
     bool     dg_no_overlap    = false; // MGX_DG_NO_OVERLAP        DG ghost exchange before all cells instead of under the interior ones
+    bool     no_fused_decomposed = false; // decomposed levels: residual / restriction / prolongation as separate kernels
     bool     dg_unmerged_restrict = false; // DG V-cycle: residual and DG -> FE_Q restriction as two kernels instead of the merged action 1
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
     bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
@@ -174,6 +175,16 @@ namespace mgx
     // colour-sorted brick order, the first coarse DoF (constrained: invalid) of the (2 PB + 1)^3 mesh
     // entities of the PB^3 parents the brick's cells belong to (PB = 2 for p <= 4, 1 for p >= 5)
     uint32_t           *coarse_blocks = nullptr;
+    // ... on a decomposed mesh: the DoFs on the rank interface, which no brick completes, are transferred by two
+    // list kernels after the exchange.  Restriction (CSR by coarse DoF over the interface DoFs this rank owns):
+    // coarse[ifr_cdof[i]] += sum_k ifr_w[k] r[ifr_fdof[k]], k in [ifr_start[i], ifr_start[i+1]).  Prolongation (CSR by
+    // entry i of the fine plan's list of shared DoFs): (P e)[shared[i]] = sum_k ifp_w[k] e[ifp_cdof[k]]
+    uint32_t           *ifr_cdof = nullptr, *ifr_start = nullptr, *ifr_fdof = nullptr;
+    void               *ifr_w = nullptr;
+    uint32_t            n_ifr = 0;
+    uint32_t           *ifp_start = nullptr, *ifp_cdof = nullptr;
+    void               *ifp_w = nullptr;
+    uint32_t            n_ifp = 0;
     mutable uint32_t    pipe_grid[4] = {0, 0, 0, 0}; // persistent grid of prolongate(add), prolongate, restrict x2
     bool                owner_weights = false;   // restriction: weight 1 for the parent that owns a fine entity, 0 for the others (multi-block meshes)
     bool                coarse_coloured = false; // coarse cells c and c' with c % 8 == c' % 8 share no DoF
@@ -336,6 +347,11 @@ namespace mgx
   // kernels appended at `partials` (added up by launch_reduce4)
   uint32_t launch_cg_list_update(hipStream_t s, int number, const uint32_t *list, uint32_t count, double alpha,
                                  double beta, const void *r, void *q, void *p, void *x, double *partials);
+  // fused transfers on a decomposed level (TransferData::ifr_* / ifp_*, mgx_vector.hip):
+  // coarse += R (b - ax) over the owned interface DoFs;  xi = x + P e, out = xi + f2 dinv (b - ax), x = xi on the shared DoFs
+  void launch_interface_restrict(hipStream_t s, int number, const TransferData &tr, void *coarse, const void *b, const void *ax);
+  void launch_interface_prolong_cheb(hipStream_t s, int number, const TransferData &tr, const uint32_t *shared, const void *e,
+                                     void *x, void *out, const void *b, const void *dinv, double f2, const void *ax);
   uint32_t launch_axpy_norm(hipStream_t s, int number, void *r, const void *q, double factor, size_t n, double *partials);
   void     launch_cg_pre(hipStream_t s, int number, void *x, void *p, void *q, double alpha, double beta, size_t n);
   uint32_t launch_dot4(hipStream_t s, int number, const void *q, const void *p, const void *r, size_t n, double *partials);

@@ -56,6 +56,24 @@ def test_agglomerated_coarse_levels(monkeypatch, world, p, nr, extra, limit):
     assert all(("agglomerated" in o) == (limit != "0") for o in outs), outs
 
 
+@pytest.mark.parametrize("world,p,nr,extra,overlap", [(2, 4, 3, (), True), (4, 4, 3, ("strong",), True), (2, 2, 4, ("strong",), False),
+                                                       (2, 5, 2, (), True), (2, 4, 3, ("f32",), False), (4, 3, 3, (), False)])
+def test_fused_transfers_on_decomposed_levels(monkeypatch, world, p, nr, extra, overlap):
+    """residual + restriction and prolongation + first post-smoothing iteration inside the brick loop on decomposed
+    levels (eight-colour schedule forced on every level, no agglomeration): the DoFs on the rank interface are
+    restricted by their owners / corrected by every holder in list kernels after the exchange.  V-cycle, FMG and PCG
+    against the single-domain oracle; the same runs with the separate kernels are the other tests of this file"""
+    monkeypatch.setenv("MGX_FREE_ONE_MAX", "0")
+    monkeypatch.setenv("MGX_FREE_MAX_BRICKS", "0")
+    monkeypatch.setenv("MGX_AGGLOMERATE", "0")
+    monkeypatch.setenv("MGX_TRACE", "1")
+    if overlap:
+        monkeypatch.setenv("MGX_OVERLAP_MIN_BRICKS", "1")
+    outs = launch("gpu", world, p, nr, extra=extra)
+    assert all("gpu ok" in o for o in outs), outs
+    assert all("transfer_create: interface rows" in o for o in outs), [o[-2000:] for o in outs]
+
+
 def test_bench_launches_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts two ranks itself; here over gloo, both on the one GPU"""
     import json

@@ -8,7 +8,8 @@ deg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ns, nr = cells, 0
 while ns % 2 == 0 and ns > 1:
     ns //= 2; nr += 1
-ctx = mg.Context(0)
+# further arguments NAME=VALUE: context options (include/mgx.h mgx_context_set_option)
+ctx = mg.Context(0, options={k: float(v) for k, v in (o.split("=") for o in sys.argv[3:])})
 cube = mg.Cube(deg, ns, nr)
 solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64)
 n = cube.n_dofs(cube.max_level)
