@@ -149,6 +149,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"dg_no_overlap", &dg_no_overlap, nullptr},
     {"dg_unmerged_restrict", &dg_unmerged_restrict, nullptr},
     {"no_fused_decomposed", &no_fused_decomposed, nullptr},
+    {"no_fused_assembly", &no_fused_assembly, nullptr},
     // emulation of a rank of a decomposed mesh on one GPU (tools/rank_emulation.py): the results are WRONG
     {"rccl_selftest", &rccl_selftest, nullptr},
   };
@@ -2105,6 +2106,21 @@ int mgx_smoother_set_polynomial_type(mgx_smoother_t sm, int polynomial_type)
   return MGX_OK;
 }
 
+// Levels without a brick schedule, ordered assembly on one rank with the constrained DoFs last: the update is the
+// post-operation of the assembly kernel (two launches per iteration instead of three on levels that are launch-bound)
+static bool cheb_in_assembly(mgx_operator_t op)
+{
+  return op->d.asm_start && !op->plan && op->constrained_last && !op->ctx->tun.no_fused_assembly;
+}
+
+static void cheb_assembly_iteration(mgx_smoother_t sm, void *x, const void *b, double f1, double f2, bool three_term)
+{
+  mgx_operator_t op = sm->op;
+  ProfileBracket pb(op, three_term ? 2 : 3);
+  const ChebPost post{sm->x_old, b, op->d.inv_diag, f1, f2, three_term};
+  launch_cell_loop(op->ctx->stream, op->d, x, x, nullptr, op->d.n_dofs - op->d.n_constrained, &post);
+}
+
 // legacy path (levels without a brick schedule): matvec into tmp, then an elementwise update
 static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
 {
@@ -2116,11 +2132,17 @@ static int cheb_loop(mgx_smoother_t sm, void *x, const void *b)
   double rhok = I.delta / I.theta;
   for (int k = 0; k < I.degree - 1; ++k)
     {
-      MGX_TRY(mgx_vmult(op, sm->tmp, x));
       double f1, f2;
       sm->next_factors(k, rhok, f1, f2);
+      if (cheb_in_assembly(op))
+        {
+          cheb_assembly_iteration(sm, x, b, f1, f2, true);
+          continue;
+        }
+      MGX_TRY(mgx_vmult(op, sm->tmp, x));
       launch_cheb_update(s, op->d.number, 2, x, sm->x_old, b, sm->tmp, op->d.inv_diag, f1, f2, op->d.n_dofs);
     }
+  MGX_HIP(hipGetLastError());
   return MGX_OK;
 }
 
@@ -2181,7 +2203,9 @@ static int smoother_apply(mgx_smoother_t sm, void *x, const void *b, bool is_ste
   // levels without a brick schedule: matvec + elementwise update
   if (!op->d.bricks.available())
     {
-      if (is_step)
+      if (is_step && cheb_in_assembly(op))
+        cheb_assembly_iteration(sm, x, b, 0., sm->first_factor(), false);
+      else if (is_step)
         {
           MGX_TRY(mgx_vmult(op, sm->tmp, x));
           launch_cheb_update(s, num, 1, x, sm->x_old, b, sm->tmp, op->d.inv_diag, 0., sm->first_factor(), n);

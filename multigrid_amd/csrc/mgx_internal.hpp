@@ -32,6 +32,7 @@ namespace mgx
     bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
     uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads
     bool     dg_no_overlap    = false; // MGX_DG_NO_OVERLAP        DG ghost exchange before all cells instead of under the interior ones
+    bool     no_fused_assembly = false;  // per-cell levels: Chebyshev update as a kernel after the assembly kernel
     bool     no_fused_decomposed = false; // decomposed levels: residual / restriction / prolongation as separate kernels
     bool     dg_unmerged_restrict = false; // DG V-cycle: residual and DG -> FE_Q restriction as two kernels instead of the merged action 1
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
@@ -220,8 +221,19 @@ namespace mgx
   // dst += A_cells * src  (MatrixFree::cell_loop(local_apply), laplace_operator.h:527-558)
   // op.asm_start (ordered assembly): dst is WRITTEN (no zeroing by the caller), and dst[d] = tail_src[d] for
   // d >= n_head if tail_src is given; otherwise dst must be zero on entry
+  // post (ordered assembly only): the Chebyshev update of PreconditionChebyshev inside the assembly kernel instead of
+  // a kernel of its own -- src is the iterate x, updated in place after every cell has read it:
+  //   x_new = x + f2 dinv (b - A x) [+ f1 (x - x_old), three_term];  x_old = x;  rows >= n_head: A x = x (identity rows)
+  struct ChebPost
+  {
+    void       *x_old;
+    const void *b, *dinv;
+    double      f1, f2;
+    bool        three_term;
+  };
   void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src = nullptr,
-                        uint32_t n_head = 0);
+                        uint32_t n_head = 0,
+                        const ChebPost *post = nullptr);
   // mode 0: dst = ordered sums of op.cell_scratch (tail as above), mode 1: dst += them
   void launch_assemble(hipStream_t s, const OperatorData &op, int mode, void *dst, const void *tail_src, uint32_t n_head);
   // brick cell loop with fused post-operation (mgx_brick.hip); mode = BrickMode

@@ -182,6 +182,31 @@ namespace mgx
       dst[d] = (tail_src && d >= n_head) ? tail_src[d] : sum;
   }
 
+  // the assembly with the Chebyshev update as its post-operation (ChebPost): t = (A x)[d] never reaches memory
+  template <typename T, bool THREE>
+  __global__ void __launch_bounds__(256)
+    assemble_cheb_kernel(T *__restrict__ x, const T *__restrict__ scratch, const uint32_t *__restrict__ start,
+                         const uint32_t *__restrict__ pos, uint32_t n_dofs, uint32_t n_head, T *__restrict__ x_old,
+                         const T *__restrict__ b, const T *__restrict__ dinv, T f1, T f2)
+  {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dofs)
+      return;
+    const T xi = x[d];
+    T       t  = xi; // identity rows
+    if (d < n_head)
+      {
+        t = T(0);
+        for (uint32_t k = start[d]; k < start[d + 1]; ++k)
+          t += scratch[pos[k]];
+      }
+    T xn = xi + f2 * dinv[d] * (b[d] - t);
+    if (THREE)
+      xn += f1 * (xi - x_old[d]);
+    x_old[d] = xi;
+    x[d]     = xn;
+  }
+
   // ------------------------------------------------------------------------------------------
   // Cell loop: dst += sum_cells  S^T [ sum_d D_d^T (c_d w) D_d ] S  src   (diagonal coefficient)
   // = local_apply of laplace_operator.h:527-558 with the quadrature-point operation :471-487.
@@ -851,7 +876,7 @@ namespace mgx
   // read-modify-writes (op.cell_order), or one launch with atomic adds (fallback).
   template <int P, typename T>
   static void cell_loop_t(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src,
-                          uint32_t n_head)
+                          uint32_t n_head, const ChebPost *post)
   {
     using C            = Cfg<P>;
     const uint32_t nb  = (op.n_cells + C::CPB - 1) / C::CPB;
@@ -884,7 +909,19 @@ namespace mgx
       hipLaunchKernelGGL((cell_loop_kernel<P, T>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
                          op.idx27, op.n_cells, (const Basis1D<T> *)op.basis, (T)op.coef[0], (T)op.coef[1],
                          (T)op.coef[2], scratch);
-    if (scratch)
+    if (scratch && post)
+      {
+        const uint32_t nba = (op.n_dofs + 255) / 256;
+        if (post->three_term)
+          hipLaunchKernelGGL((assemble_cheb_kernel<T, true>), dim3(nba), dim3(256), 0, s, (T *)dst, (const T *)scratch, op.asm_start,
+                             op.asm_pos, op.n_dofs, n_head, (T *)post->x_old, (const T *)post->b, (const T *)post->dinv,
+                             (T)post->f1, (T)post->f2);
+        else
+          hipLaunchKernelGGL((assemble_cheb_kernel<T, false>), dim3(nba), dim3(256), 0, s, (T *)dst, (const T *)scratch, op.asm_start,
+                             op.asm_pos, op.n_dofs, n_head, (T *)post->x_old, (const T *)post->b, (const T *)post->dinv,
+                             (T)post->f1, (T)post->f2);
+      }
+    else if (scratch)
       assemble_t<T>(s, op, 0, dst, tail_src, n_head);
   }
 
@@ -1026,15 +1063,15 @@ namespace mgx
   }
 
   void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src,
-                        uint32_t n_head)
+                        uint32_t n_head, const ChebPost *post)
   {
     if (op.number == 1)
       {
-        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, dst, src, tail_src, n_head));
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, double>(s, op, dst, src, tail_src, n_head, post));
       }
     else
       {
-        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src, tail_src, n_head));
+        MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src, tail_src, n_head, post));
       }
   }
 
