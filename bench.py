@@ -57,6 +57,8 @@ def parse():
                     help="skip the end-to-end check after the timed region (PCG iteration count and L2 error of the "
                          "manufactured problem, README.md:135-159)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-rhs", action="store_true",
+                    help="assemble the right-hand sides on the host instead of on the GPU (set-up only: not in the timed region)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: split the --cells^3 mesh over the ranks (strong) or give every rank a --cells^3 cube (weak)")
@@ -314,7 +316,7 @@ def main():
         else:
             cube = mg.Cube(args.degree, n_refine=nr, box=procs, procs=procs, rank=rank)
         solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, comm=comm,
-                                    polynomial=polynomial)
+                                    polynomial=polynomial, device_rhs=not args.host_rhs)
         # RCCL send/recv issued by the library on its own stream (no host round trip per exchange),
         # switched on only after one exchange + one reduction agree bitwise with the torch transport
         native = comm.verify_and_enable_native(solver.matrix_dp(cube.max_level), cube.n_dofs(cube.max_level))
@@ -324,7 +326,8 @@ def main():
     else:
         procs = (1, 1, 1)
         cube = mg.Cube(args.degree, ns, nr)
-        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, polynomial=polynomial)
+        solver = mg.MultigridSolver(ctx, cube, args.smoother_degree, args.smoother_degree, 1, vnum, polynomial=polynomial,
+                                    device_rhs=not args.host_rhs)
     lmax = cube.max_level
     n_dofs = cube.n_dofs(lmax)
     if not decomposed:
@@ -463,6 +466,7 @@ def main():
                    "transport": transport if decomposed else None},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
+        "rhs_assembly": "host" if args.host_rhs else "device",
         "roofline": roof(2) or roof(0),
         "roofline_matvec": roof(0),
         # the other finest-level forms of the step (HIP events around every application, as above)

@@ -251,6 +251,14 @@ int mgx_exchange_add(mgx_operator_t op, void *vec);
 int mgx_operator_number(mgx_operator_t op);
 /* LaplaceOperator::vmult(dst, src) laplace_operator.h:573-601 */
 int mgx_vmult(mgx_operator_t op, void *dst, const void *src);
+/* LaplaceOperator::compute_residual (laplace_operator.h:804-845) on the device:
+ *   dst_i = sum over the cells of  integral( phi_i f )  -  integral( grad phi_i . K grad u )
+ * with u = the boundary values in the constrained entries of src (device vector of the operator's number type, zero
+ * elsewhere; NULL: homogeneous) read without the constraints (:816-824), K the operator's coefficient (:826-838) and
+ * rhs_q[cell][(p+1)^3] = f(x_q) JxW_q at the quadrature points of every cell (device, cell order of the index table,
+ * points lexicographic with x fastest; NULL: f = 0) (:839).  Rows of constrained DoFs stay zero; the result is summed
+ * over the rank interfaces (:843).  No atomics: the cells are added up in a fixed order. */
+int mgx_compute_residual(mgx_operator_t op, void *dst, const void *src, const void *rhs_q);
 /* LaplaceOperator::vmult_residual(rhs, lhs, residual) laplace_operator.h:605-634 */
 int mgx_vmult_residual(mgx_operator_t op, const void *rhs, const void *lhs, void *residual);
 /* LaplaceOperator::compute_diagonal() laplace_operator.h:745-800; the inverse diagonal is kept
@@ -332,7 +340,8 @@ typedef struct
    * The two may be the same object when the number types coincide. */
   const mgx_transfer_t *transfer;
   const mgx_transfer_t *transfer_dp;
-  /* per level: rhs[level] as computed by compute_residual (:261), host fp64, n_dofs entries */
+  /* per level: rhs[level] as computed by compute_residual (:261), host fp64, n_dofs entries; rhs or rhs[level] NULL:
+   * the level's right-hand side is assembled on the device afterwards (mgx_solver_compute_rhs) */
   const double *const *rhs;
   /* per level: inhomogeneous_bc[level] (:225-253) as index/value lists (host) */
   const uint32_t *const *bc_index;
@@ -360,6 +369,10 @@ int mgx_operator_device_indices(mgx_operator_t op, const uint32_t **idx27, uint3
 /* polynomial type of the smoothers above the coarsest level (which keeps the first kind with the
  * degree from its tolerance, multigrid_solver.h:955-959) */
 int mgx_solver_set_polynomial_type(mgx_solver_t solver, int polynomial_type);
+/* MultigridSolver ctor, multigrid_solver.h:225-261: the right-hand side of a level assembled on the device --
+ * mgx_compute_residual of the level's fp64 operator with the solver's boundary values and rhs_q = f(x_q) JxW_q
+ * (device, [n_cells][(p+1)^3]; NULL: f = 0) -- into the level's rhs vector (mgx_solver_desc::rhs[level] == NULL) */
+int mgx_solver_compute_rhs(mgx_solver_t solver, int level, const double *rhs_q);
 /* MultigridSolver::solve(do_analyze) :387-476.  trace (may be NULL) receives for every level
  * l >= 1 the residual norms {start, end} at trace[2*l], trace[2*l+1] when do_analyze != 0
  * (the L2 errors printed next to them need the analytic solution and are computed by the

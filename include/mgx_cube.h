@@ -146,7 +146,10 @@ const double   *mgx_cube_prolong_1d(mgx_cube_t cube);
 
 /* MultigridSolver ctor pieces computed on the host (multigrid_solver.h:225-261):
  * inhomogeneous boundary values and rhs = int f phi - int grad u_bc . grad phi */
-const double   *mgx_cube_rhs(mgx_cube_t cube, int level);
+const double   *mgx_cube_rhs(mgx_cube_t cube, int level); /* assembled at the first call */
+/* the integrand of the right-hand side alone: out[cell][(p+1)^3] = f(x_q) JxW_q (laplace_operator.h:839), cells
+ * in the order of the index table, points lexicographic -- the input of mgx_compute_residual (include/mgx.h) */
+int             mgx_cube_rhs_quadrature(mgx_cube_t cube, int level, double *out);
 uint32_t        mgx_cube_bc_count(mgx_cube_t cube, int level);
 const uint32_t *mgx_cube_bc_index(mgx_cube_t cube, int level);
 const double   *mgx_cube_bc_value(mgx_cube_t cube, int level);
@@ -182,6 +185,10 @@ typedef struct
 
 int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vcycle_number, int degree_pre, int n_cycles,
                            mgx_cube_solver *out);
+/* The same; device_rhs != 0: the right-hand sides of all levels are assembled on the GPU (mgx_solver_compute_rhs,
+ * LaplaceOperator::compute_residual laplace_operator.h:804-845) from mgx_cube_rhs_quadrature instead of on the host */
+int mgx_cube_solver_create_opt(mgx_context_t ctx, mgx_cube_t cube, int vcycle_number, int degree_pre, int n_cycles,
+                               int device_rhs, mgx_cube_solver *out);
 int mgx_cube_solver_destroy(mgx_cube_solver *s);
 
 #ifdef __cplusplus

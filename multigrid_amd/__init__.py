@@ -505,6 +505,12 @@ class Cube:
     def rhs(self, l):
         return self._arr("mgx_cube_rhs", (self.n_dofs(l),), l)
 
+    def rhs_quadrature(self, l):
+        """f(x_q) JxW_q, [n_cells, (p+1)^3]: the integrand of the right-hand side (input of compute_residual)"""
+        out = np.empty((self.n_cells(l), (self.degree + 1) ** 3))
+        check(self.lib.mgx_cube_rhs_quadrature(self.h, l, out.ctypes.data_as(_lib.f64p)))
+        return out
+
     def bc(self, l):
         n = self.lib.mgx_cube_bc_count(self.h, l)
         return self._arr("mgx_cube_bc_index", (n,), l), self._arr("mgx_cube_bc_value", (n,), l)
@@ -590,6 +596,12 @@ class LaplaceOperator:
 
     def vmult_residual(self, rhs, lhs, residual):
         check(self.lib.mgx_vmult_residual(self.h, rhs.ptr, lhs.ptr, residual.ptr))
+
+    def compute_residual(self, dst, src=None, rhs_q=None):
+        """LaplaceOperator::compute_residual (laplace_operator.h:804-845) on the device: dst = int f phi - A u_bc with the
+        boundary values in the constrained entries of src and rhs_q = f JxW at the quadrature points (device vectors)"""
+        check(self.lib.mgx_compute_residual(self.h, dst.ptr, src.ptr if src is not None else None,
+                                            rhs_q.ptr if rhs_q is not None else None))
 
     def compute_diagonal(self):
         check(self.lib.mgx_compute_diagonal(self.h))
@@ -678,8 +690,9 @@ class MultigridSolver:
     `vcycle_number` is the template parameter Number (program.cc:76: float; BASELINE: double)."""
 
     def __init__(self, ctx, cube, degree_pre=3, degree_post=3, n_cycles=1, vcycle_number=F64, comm=None,
-                 polynomial="first_kind", agglomerate=True):
-        """polynomial: Chebyshev polynomial type of the level smoothers: "first_kind" is what
+                 polynomial="first_kind", agglomerate=True, device_rhs=False):
+        """device_rhs: the right-hand sides are assembled on the GPU (mgx_solver_compute_rhs) instead of on the host.
+        polynomial: Chebyshev polynomial type of the level smoothers: "first_kind" is what
         MultigridSolver<dim,p,Number,Number2> sets (multigrid_solver.h:277-278), "fourth_kind" what
         the Number == Number2 specialisation sets (:951-952)"""
         assert degree_pre == degree_post  # multigrid_solver.h:126
@@ -690,7 +703,8 @@ class MultigridSolver:
         if cube.size > 1:
             if comm is None:
                 raise ValueError("a decomposed cube needs a Communicator")
-        check(self.lib.mgx_cube_solver_create(ctx.h, cube.h, vcycle_number, degree_pre, n_cycles, C.byref(self.s)))
+        check(self.lib.mgx_cube_solver_create_opt(ctx.h, cube.h, vcycle_number, degree_pre, n_cycles, int(bool(device_rhs)),
+                                                  C.byref(self.s)))
         self.n_levels = self.s.n_levels
         self.max_level = self.n_levels - 1
         self.h = C.c_void_p(self.s.solver)
@@ -734,7 +748,7 @@ class MultigridSolver:
         whole = Cube(cube.degree, n_refine=level, box=d["box"], procs=(1, 1, 1), rank=0, numbering=d["numbering"],
                      origin=d["origin"], h0=d["h0"], geometry=d["geometry"], problem=d["problem"])
         ctx2 = Context(self.ctx.device)
-        coarse = MultigridSolver(ctx2, whole, degree, degree, n_cycles, vnumber)
+        coarse = MultigridSolver(ctx2, whole, degree, degree, n_cycles, vnumber, device_rhs=True)  # its rhs is never used
         gg = whole.dof_grid(level)
         pos = np.full(int(gg.max()) + 1, INVALID_INDEX, dtype=np.uint32)
         pos[gg] = np.arange(gg.size, dtype=np.uint32)

@@ -209,6 +209,10 @@ SIGNATURES = {
     "mgx_cube_l2_error": (C.c_double, [vp, C.c_int, f64p]),
     "mgx_cube_seeded_vector": (C.c_int, [vp, C.c_int, C.c_uint64, f64p]),
     "mgx_cube_solver_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(CubeSolver)]),
+    "mgx_cube_solver_create_opt": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CubeSolver)]),
+    "mgx_cube_rhs_quadrature": (C.c_int, [vp, C.c_int, f64p]),
+    "mgx_compute_residual": (C.c_int, [vp, vp, vp, vp]),
+    "mgx_solver_compute_rhs": (C.c_int, [vp, C.c_int, vp]),
     "mgx_cube_solver_destroy": (C.c_int, [C.POINTER(CubeSolver)]),
     "mgx_smoother_set_polynomial_type": (C.c_int, [vp, C.c_int]),
     "mgx_solver_set_polynomial_type": (C.c_int, [vp, C.c_int]),

@@ -1868,6 +1868,65 @@ int mgx_vmult_with_cg_update(mgx_operator_t op, double alpha, double beta, const
   return MGX_OK;
 }
 
+// Cells of a brick level in launches whose cells share no DoF: brick colour by brick colour (bricks of one launch
+// group share no DoF), inside a brick the cells with the same position m mod 8 in Morton order -- the same child of
+// every parent -- do not touch.  64 lists; plain adds in an order that does not depend on the run.
+static void brick_cell_lists(mgx_operator_t op, std::vector<uint32_t> &lists, std::vector<uint32_t> &list_start)
+{
+  const BrickData &bd = op->d.bricks;
+  const uint32_t   cb = op->d.n_cells / bd.n_bricks; // cells per brick: 64 or 8
+  lists.clear();
+  list_start.assign(1, 0);
+  lists.reserve(op->d.n_cells);
+  for (int g = 0; g < bd.n_colours; ++g)
+    for (uint32_t q = 0; q < 8; ++q)
+      {
+        for (uint32_t pos = bd.colour_start[g]; pos < bd.colour_start[g + 1]; ++pos)
+          for (uint32_t m = q; m < cb; m += 8)
+            lists.push_back(bd.order[pos] * cb + m);
+        list_start.push_back((uint32_t)lists.size());
+      }
+}
+
+int mgx_compute_residual(mgx_operator_t op, void *dst, const void *src, const void *rhs_q)
+{
+  MGX_REQUIRE(op && dst, "mgx_compute_residual: null argument");
+  MGX_REQUIRE(dst != src, "mgx_compute_residual: dst and src must not alias");
+  hipStream_t  s     = op->ctx->stream;
+  const size_t bytes = number_size(op->d.number) * op->d.n_dofs;
+  void        *zero  = nullptr;
+  if (!src) // homogeneous boundary values
+    {
+      MGX_HIP(hipMalloc(&zero, bytes));
+      MGX_HIP(hipMemsetAsync(zero, 0, bytes, s));
+      src = zero;
+    }
+  MGX_HIP(hipMemsetAsync(dst, 0, bytes, s));
+  // assembly without atomics, as for the diagonal (mgx_compute_diagonal)
+  if (op->d.bricks.available())
+    {
+      std::vector<uint32_t> lists, list_start;
+      brick_cell_lists(op, lists, list_start);
+      uint32_t *lists_dev = nullptr;
+      MGX_HIP(hipMalloc((void **)&lists_dev, sizeof(uint32_t) * (lists.size() + 1)));
+      MGX_HIP(hipMemcpyAsync(lists_dev, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice, s));
+      launch_cell_residual(s, op->d, dst, src, rhs_q, lists_dev, list_start.data(), (int)list_start.size() - 1);
+      MGX_HIP(hipStreamSynchronize(s));
+      MGX_HIP(hipFree(lists_dev));
+    }
+  else if (op->d.cell_order && !op->d.asm_start)
+    launch_cell_residual(s, op->d, dst, src, rhs_q, op->d.cell_order, op->d.cell_colour_start, op->d.n_cell_colours);
+  else
+    launch_cell_residual(s, op->d, dst, src, rhs_q);
+  MGX_HIP(hipGetLastError());
+  if (zero)
+    {
+      MGX_HIP(hipStreamSynchronize(s));
+      MGX_HIP(hipFree(zero));
+    }
+  return exchange_add(op, dst); // dst.compress(add), laplace_operator.h:843
+}
+
 int mgx_compute_diagonal(mgx_operator_t op)
 {
   MGX_REQUIRE(op, "mgx_compute_diagonal: null argument");
@@ -1896,18 +1955,8 @@ int mgx_compute_diagonal(mgx_operator_t op)
   // cell-coloured levels colour by colour, the others through the ordered assembly.
   if (op->d.bricks.available())
     {
-      const BrickData      &bd = op->d.bricks;
-      const uint32_t        cb = op->d.n_cells / bd.n_bricks; // cells per brick: 64 or 8
-      std::vector<uint32_t> lists, list_start(1, 0);
-      lists.reserve(op->d.n_cells);
-      for (int g = 0; g < bd.n_colours; ++g)
-        for (uint32_t q = 0; q < 8; ++q)
-          {
-            for (uint32_t pos = bd.colour_start[g]; pos < bd.colour_start[g + 1]; ++pos)
-              for (uint32_t m = q; m < cb; m += 8)
-                lists.push_back(bd.order[pos] * cb + m);
-            list_start.push_back((uint32_t)lists.size());
-          }
+      std::vector<uint32_t> lists, list_start;
+      brick_cell_lists(op, lists, list_start);
       uint32_t *lists_dev = nullptr;
       MGX_HIP(hipMalloc((void **)&lists_dev, sizeof(uint32_t) * (lists.size() + 1)));
       MGX_HIP(hipMemcpyAsync(lists_dev, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice, s));
@@ -2857,7 +2906,7 @@ int mgx_solver_destroy(mgx_solver_t S)
 int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver_t *out)
 {
   MGX_REQUIRE(ctx && desc && out, "mgx_solver_create: null argument");
-  MGX_REQUIRE(desc->n_levels >= 1 && desc->matrix && desc->matrix_dp && desc->rhs && desc->bc_count,
+  MGX_REQUIRE(desc->n_levels >= 1 && desc->matrix && desc->matrix_dp && desc->bc_count,
               "mgx_solver_create: incomplete descriptor");
   MGX_REQUIRE(desc->n_levels == 1 || (desc->transfer && desc->transfer_dp), "mgx_solver_create: missing transfers");
   MGX_REQUIRE(desc->degree_pre >= 1 && desc->n_cycles >= 1, "mgx_solver_create: bad smoother degree / cycle count");
@@ -2893,10 +2942,15 @@ int mgx_solver_create(mgx_context_t ctx, const mgx_solver_desc *desc, mgx_solver
       MGX_HIP(hipMemsetAsync(p, 0, 8 * n, ctx->stream));
       S->solution.push_back(p);
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
-      MGX_HIP(hipMemcpy(p, desc->rhs[l], 8 * n, hipMemcpyHostToDevice));
-      // a rank assembles the rhs over its own cells: complete the interface entries
-      // (dst.compress(add) in compute_residual, laplace_operator.h:843)
-      MGX_TRY(exchange_add(desc->matrix_dp[l], p));
+      if (desc->rhs && desc->rhs[l])
+        {
+          MGX_HIP(hipMemcpy(p, desc->rhs[l], 8 * n, hipMemcpyHostToDevice));
+          // a rank assembles the rhs over its own cells: complete the interface entries
+          // (dst.compress(add) in compute_residual, laplace_operator.h:843)
+          MGX_TRY(exchange_add(desc->matrix_dp[l], p));
+        }
+      else // assembled on the device afterwards: mgx_solver_compute_rhs
+        MGX_HIP(hipMemsetAsync(p, 0, 8 * n, ctx->stream));
       S->rhs.push_back(p);
       MGX_HIP(hipMalloc((void **)&p, 8 * n));
       MGX_HIP(hipMemsetAsync(p, 0, 8 * n, ctx->stream));
@@ -3215,6 +3269,21 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
         }
     }
   return MGX_OK;
+}
+
+int mgx_solver_compute_rhs(mgx_solver_t S, int level, const double *rhs_q)
+{
+  MGX_REQUIRE(S && level >= 0 && level < S->n_levels, "mgx_solver_compute_rhs: bad argument");
+  // the boundary values in a vector of their own (the level's solution vector is the caller's)
+  mgx_operator_t A = S->matrix_dp[level];
+  double        *u = nullptr;
+  MGX_HIP(hipMalloc((void **)&u, 8 * (size_t)A->d.n_dofs));
+  MGX_HIP(hipMemsetAsync(u, 0, 8 * (size_t)A->d.n_dofs, S->ctx->stream));
+  set_bc(S, level, u, false);
+  const int status = mgx_compute_residual(A, S->rhs[level], u, rhs_q);
+  (void)hipStreamSynchronize(S->ctx->stream);
+  (void)hipFree(u);
+  return status;
 }
 
 int mgx_solver_solve(mgx_solver_t S, int do_analyze, double *reduction_rate, double *trace)

@@ -195,8 +195,12 @@ namespace
     {
       if (id == MGX_CUBE_PROBLEM_SHELL)
         return std::sin(2. * kPi * (x + y));
-      return std::sin(kPi * x * 3.) * std::sin(kPi * y * 3.) * std::sin(kPi * z * 3.);
+      return f1(x) * f1(y) * f1(z);
     }
+    // the cube problem's right-hand side is a product of one function per coordinate: f = f_scale f1(x) f1(y) f1(z)
+    bool   f_is_product() const { return id != MGX_CUBE_PROBLEM_SHELL; }
+    double f_scale() const { return 3. * kPi * 3. * kPi * 3.; }
+    double f1(double x) const { return std::sin(kPi * x * 3.); }
     double a(const double *x) const
     {
       if (id != MGX_CUBE_PROBLEM_SHELL)
@@ -212,7 +216,7 @@ namespace
     double f(double x, double y, double z) const
     {
       if (id != MGX_CUBE_PROBLEM_SHELL)
-        return 3. * kPi * 3. * kPi * 3. * u(x, y, z);
+        return f_scale() * u(x, y, z);
       const double X[3]  = {x, y, z};
       const double arg   = 2. * kPi * (x + y);
       const double lap_u = -8. * kPi * kPi * std::sin(arg), du = 2. * kPi * std::cos(arg); // du/dx = du/dy
@@ -696,10 +700,10 @@ namespace
     }
   }
 
-  // boundary values + rhs (multigrid_solver.h:225-261, laplace_operator.h:804-845)
-  void build_rhs(const mgx_cube_s &C, Level &L)
+  // boundary values (multigrid_solver.h:225-253)
+  void build_bc(const mgx_cube_s &C, Level &L)
   {
-    const int    p = C.p, n = p + 1, n3 = n * n * n;
+    const int    p = C.p;
     const Basis &B = C.basis;
     // inhomogeneous_bc: analytic solution at the support points of boundary DoFs, nonzero only
     std::vector<double> bc_full(L.n_dofs, 0.);
@@ -764,8 +768,59 @@ namespace
           L.bc_index.push_back(i);
           L.bc_value.push_back(bc_full[i]);
         }
-    L.rhs.assign(L.n_dofs, 0.);
+  }
+
+  // f(x_q) JxW_q at the n^3 quadrature points of cell c (laplace_operator.h:839)
+  void rhs_quadrature_cell(const mgx_cube_s &C, const Level &L, uint32_t c, double *t0)
+  {
+    const int    n = C.p + 1, n3 = n * n * n;
+    const Basis &B = C.basis;
+    if (!L.coef_q.empty())
+      {
+        for (int q = 0; q < n3; ++q)
+          {
+            const double *xp = &L.xq[((size_t)c * n3 + q) * 3];
+            t0[q]            = C.problem.f(xp[0], xp[1], xp[2]) * L.jxw[(size_t)c * n3 + q];
+          }
+        return;
+      }
     const double h = L.h, h3 = h * h * h;
+    const double x0 = C.origin + h * (L.off[0] + L.coords[3 * (size_t)c]), y0 = C.origin + h * (L.off[1] + L.coords[3 * (size_t)c + 1]),
+                 z0 = C.origin + h * (L.off[2] + L.coords[3 * (size_t)c + 2]);
+    if (C.problem.f_is_product())
+      {
+        // 3 n evaluations of the 1D factor instead of n^3 of f; the products in the order of Problem::f and of the
+        // general expression below (the values are the same to the last bit)
+        double fx[16], fy[16], fz[16];
+        for (int i = 0; i < n; ++i)
+          {
+            fx[i] = C.problem.f1(x0 + h * B.gq[i]);
+            fy[i] = C.problem.f1(y0 + h * B.gq[i]);
+            fz[i] = C.problem.f1(z0 + h * B.gq[i]);
+          }
+        for (int k = 0, q = 0; k < n; ++k)
+          for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i, ++q)
+              t0[q] = C.problem.f_scale() * (fx[i] * fy[j] * fz[k]) * h3 * (B.gw[i] * B.gw[j] * B.gw[k]);
+        return;
+      }
+    for (int k = 0, q = 0; k < n; ++k)
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i, ++q)
+          t0[q] = C.problem.f(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]) * h3 * (B.gw[i] * B.gw[j] * B.gw[k]);
+  }
+
+  // rhs on the host (laplace_operator.h:804-845), built when first asked for (mgx_cube_rhs; a solver created with
+  // device_rhs assembles it on the GPU, mgx_solver_compute_rhs)
+  void build_rhs(const mgx_cube_s &C, Level &L)
+  {
+    const int    p = C.p, n = p + 1, n3 = n * n * n;
+    const Basis &B = C.basis;
+    std::vector<double> bc_full(L.n_dofs, 0.);
+    for (size_t i = 0; i < L.bc_index.size(); ++i)
+      bc_full[L.bc_index[i]] = L.bc_value[i];
+    L.rhs.assign(L.n_dofs, 0.);
+    const double h = L.h;
 #pragma omp parallel
     {
       std::vector<double> buf(5 * (size_t)n3);
@@ -782,9 +837,6 @@ namespace
           apply_1d(n, 0, B.D, false, t0, gx, false);
           apply_1d(n, 1, B.D, false, t0, gy, false);
           apply_1d(n, 2, B.D, false, t0, gz, false);
-          const double x0 = C.origin + h * (L.off[0] + L.coords[3 * (size_t)c]),
-                       y0 = C.origin + h * (L.off[1] + L.coords[3 * (size_t)c + 1]),
-                       z0 = C.origin + h * (L.off[2] + L.coords[3 * (size_t)c + 2]);
           if (!L.coef_q.empty()) // general branch: full tensor per quadrature point
             for (int q = 0; q < n3; ++q)
               {
@@ -793,8 +845,6 @@ namespace
                 gx[q] = Cq[q] * a + Cq[3 * n3 + q] * b + Cq[4 * n3 + q] * cc;
                 gy[q] = Cq[3 * n3 + q] * a + Cq[n3 + q] * b + Cq[5 * n3 + q] * cc;
                 gz[q] = Cq[4 * n3 + q] * a + Cq[5 * n3 + q] * b + Cq[2 * n3 + q] * cc;
-                const double *xp = &L.xq[((size_t)c * n3 + q) * 3];
-                t0[q]            = C.problem.f(xp[0], xp[1], xp[2]) * L.jxw[(size_t)c * n3 + q];
               }
           else
           for (int k = 0, q = 0; k < n; ++k)
@@ -805,8 +855,8 @@ namespace
                   gx[q] *= h * w; // merged coefficient diag(h,h,h) times w_q
                   gy[q] *= h * w;
                   gz[q] *= h * w;
-                  t0[q] = C.problem.f(x0 + h * B.gq[i], y0 + h * B.gq[j], z0 + h * B.gq[k]) * h3 * w; // :839
                 }
+          rhs_quadrature_cell(C, L, c, t0); // :839
           apply_1d(n, 0, B.D, true, gx, t0, true);
           apply_1d(n, 1, B.D, true, gy, t0, true);
           apply_1d(n, 2, B.D, true, gz, t0, true);
@@ -906,7 +956,7 @@ static int create_impl(const mgx_cube_box_desc &bd, mgx_cube_t *out)
       build_interfaces(*C, C->levels[l]);
       if (C->mapped())
         build_geometry(*C, C->levels[l]);
-      build_rhs(*C, C->levels[l]);
+      build_bc(*C, C->levels[l]);
     }
   *out = C.release();
   return MGX_OK;
@@ -997,7 +1047,7 @@ int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int prob
           localise_shell_level(*C, whole, C->levels[l], n_coarse / n_ranks);
         }
       build_geometry(*C, C->levels[l]);
-      build_rhs(*C, C->levels[l]);
+      build_bc(*C, C->levels[l]);
     }
   *out = C.release();
   return MGX_OK;
@@ -1068,7 +1118,24 @@ const double *mgx_cube_qpoints(mgx_cube_t c) { return c->basis.gq; }
 const double *mgx_cube_gll(mgx_cube_t c) { return c->basis.gll; }
 const double *mgx_cube_prolong_1d(mgx_cube_t c) { return c->basis.P1; }
 
-const double   *mgx_cube_rhs(mgx_cube_t c, int l) { return c->levels[l].rhs.data(); }
+const double *mgx_cube_rhs(mgx_cube_t c, int l)
+{
+  if (c->levels[l].rhs.empty()) // assembled when first asked for
+    build_rhs(*c, c->levels[l]);
+  return c->levels[l].rhs.data();
+}
+
+int mgx_cube_rhs_quadrature(mgx_cube_t c, int l, double *out)
+{
+  if (!c || !out || l < 0 || l >= (int)c->levels.size())
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_rhs_quadrature: bad argument");
+  const Level &L  = c->levels[l];
+  const size_t n3 = (size_t)(c->p + 1) * (c->p + 1) * (c->p + 1);
+#pragma omp parallel for schedule(static)
+  for (uint32_t cell = 0; cell < L.n_cells; ++cell)
+    rhs_quadrature_cell(*c, L, cell, out + (size_t)cell * n3);
+  return MGX_OK;
+}
 uint32_t        mgx_cube_bc_count(mgx_cube_t c, int l) { return (uint32_t)c->levels[l].bc_index.size(); }
 const uint32_t *mgx_cube_bc_index(mgx_cube_t c, int l) { return c->levels[l].bc_index.data(); }
 const double   *mgx_cube_bc_value(mgx_cube_t c, int l) { return c->levels[l].bc_value.data(); }
@@ -1226,7 +1293,12 @@ int mgx_cube_solver_destroy(mgx_cube_solver *s)
   return MGX_OK;
 }
 
-int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int degree_pre, int n_cycles,
+int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int degree_pre, int n_cycles, mgx_cube_solver *out)
+{
+  return mgx_cube_solver_create_opt(ctx, cube, vnumber, degree_pre, n_cycles, 0, out);
+}
+
+int mgx_cube_solver_create_opt(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int degree_pre, int n_cycles, int device_rhs,
                            mgx_cube_solver *out)
 {
   if (!ctx || !cube || !out || (vnumber != MGX_F32 && vnumber != MGX_F64))
@@ -1286,7 +1358,7 @@ int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int 
       std::vector<uint32_t>         bcn(nl);
       for (int l = 0; l < nl; ++l)
         {
-          rhs[l] = cube->levels[l].rhs.data();
+          rhs[l] = device_rhs ? nullptr : mgx_cube_rhs(cube, l);
           bci[l] = cube->levels[l].bc_index.data();
           bcv[l] = cube->levels[l].bc_value.data();
           bcn[l] = (uint32_t)cube->levels[l].bc_index.size();
@@ -1304,6 +1376,29 @@ int mgx_cube_solver_create(mgx_context_t ctx, mgx_cube_t cube, int vnumber, int 
       sd.bc_value    = bcv.data();
       sd.bc_count    = bcn.data();
       status         = mgx_solver_create(ctx, &sd, &out->solver);
+      // the right-hand sides on the device (laplace_operator.h:804-845): the host only evaluates f JxW at the
+      // quadrature points
+      for (int l = 0; l < nl && status == MGX_OK && device_rhs; ++l)
+        {
+          const size_t        n3 = (size_t)(cube->p + 1) * (cube->p + 1) * (cube->p + 1), count = n3 * cube->levels[l].n_cells;
+          std::vector<double> fq(count);
+          void               *fq_dev = nullptr;
+          status                     = mgx_cube_rhs_quadrature(cube, l, fq.data());
+          if (status == MGX_OK)
+            status = mgx_malloc(ctx, &fq_dev, sizeof(double) * count);
+          if (status == MGX_OK)
+            status = mgx_upload(ctx, fq_dev, fq.data(), sizeof(double) * count);
+          if (status == MGX_OK)
+            status = mgx_solver_compute_rhs(out->solver, l, (const double *)fq_dev);
+          if (fq_dev)
+            {
+              const std::string keep = status != MGX_OK ? mgx_last_error() : "";
+              (void)mgx_sync(ctx);
+              (void)mgx_free(ctx, fq_dev);
+              if (status != MGX_OK)
+                mgx::report_error(status, keep.c_str());
+            }
+        }
     }
   if (status != MGX_OK)
     {

@@ -247,6 +247,11 @@ namespace mgx
                          const void *b, void *out, void *partial, double f1, double f2, const void *old = nullptr,
                          double f0 = 0., void *coarse = nullptr, const uint32_t *coarse_blocks = nullptr,
                          int group_begin = 0, int group_end = -1, bool free_schedule = false);
+  // LaplaceOperator::compute_residual (laplace_operator.h:804-845) through the general per-cell kernel:
+  // dst += sum over the cells of  S^T [ rhs_q - D^T (K D S (-src)) ], src read through idx27_plain; assembly as in
+  // launch_cell_diagonal (lists of cells that share no DoF / ordered assembly / atomics).  dst zeroed by the caller.
+  void launch_cell_residual(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *rhs_q,
+                            const uint32_t *lists = nullptr, const uint32_t *list_start = nullptr, int n_lists = 0);
   // free_schedule (modes 0..6, op.bricks.fr.available()): the launch groups are those of the reduced-colour
   // schedule; the caller completes the private DoFs with launch_surf_finish: DoFs [first, first + count)
   // of op.bricks.fr.surf_dof; those below n_surf_shared: carrier[d] = sum only

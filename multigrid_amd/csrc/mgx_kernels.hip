@@ -369,11 +369,16 @@ namespace mgx
   // ------------------------------------------------------------------------------------------
   // cell_list != nullptr: the launch covers the n_cells cells cell_list[0 .. n_cells) of one colour
   // (no shared DoFs among them) and adds to dst without atomics
-  template <int P, typename T, bool PERQ>
+  // RESID (LaplaceOperator::compute_residual, laplace_operator.h:804-845): the source is read through the
+  // unconstrained index table idx_gather (boundary values in the constrained entries) and negated (:823-824),
+  // rhs_q[cell][q] = f(x_q) JxW_q is added to the integrand of the test function values (:839); the rows of
+  // constrained DoFs are still skipped on the way out.
+  template <int P, typename T, bool PERQ, bool RESID = false>
   __global__ void __launch_bounds__((Cfg<P, MGX_GENERAL_WG_THREADS>::THREADS))
     cell_loop_general_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
                              uint32_t n_cells, const Basis1D<T> *__restrict__ B, const T *__restrict__ coef_q, T c0,
-                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list, T *__restrict__ scratch)
+                             T c1, T c2, T c3, T c4, T c5, const uint32_t *__restrict__ cell_list, T *__restrict__ scratch,
+                             const uint32_t *__restrict__ idx_gather = nullptr, const T *__restrict__ rhs_q = nullptr)
   {
     using C           = Cfg<P, MGX_GENERAL_WG_THREADS>;
     constexpr int N   = C::N;
@@ -400,7 +405,15 @@ namespace mgx
     if (active) // nodal -> quadrature along x
       {
         L = line_index<P>(idx27, cell, a, b);
-        gather_line<P, T>(src, L, r);
+        if (RESID)
+          {
+            gather_line<P, T>(src, line_index<P>(idx_gather, cell, a, b), r);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r[i] = -r[i];
+          }
+        else
+          gather_line<P, T>(src, L, r);
         mv<N, T>(B->S, r, q);
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -507,6 +520,12 @@ namespace mgx
 #pragma unroll
         for (int i = 0; i < N; ++i)
           r[i] = Uc[zl + i * PL] + gz[i];
+        if (RESID && rhs_q)
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              r[i] += rhs_q[(size_t)cell * N3 + (size_t)((i * N + b) * N + a)];
+          }
         mvT<N, T>(B->S, r, q);
 #pragma unroll
         for (int i = 0; i < N; ++i)
@@ -1124,6 +1143,48 @@ namespace mgx
     else
       {
         MGX_DISPATCH_P(op.p, cell_diag_t<P, float>(s, op, diag, a, m, lists, list_start, n_lists));
+      }
+  }
+
+  // compute_residual (cell_loop_general_kernel, RESID) with the assembly variants of the diagonal above
+  template <int P, typename T>
+  static void cell_residual_t(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *rhs_q,
+                              const uint32_t *lists, const uint32_t *list_start, int n_lists)
+  {
+    using C            = Cfg<P, MGX_GENERAL_WG_THREADS>;
+    T        *scratch  = (n_lists == 0 && op.asm_start) ? (T *)op.cell_scratch : nullptr;
+    const int n_launch = n_lists > 0 ? n_lists : 1;
+    for (int k = 0; k < n_launch; ++k)
+      {
+        const uint32_t  count = n_lists > 0 ? list_start[k + 1] - list_start[k] : op.n_cells;
+        const uint32_t *list  = n_lists > 0 ? lists + list_start[k] : nullptr;
+        if (count == 0)
+          continue;
+        const uint32_t nb = (count + C::CPB - 1) / C::CPB;
+        if (op.coef_q)
+          hipLaunchKernelGGL((cell_loop_general_kernel<P, T, true, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst, (const T *)src,
+                             op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)op.coef_q, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0,
+                             list, scratch, op.idx27_plain, (const T *)rhs_q);
+        else
+          hipLaunchKernelGGL((cell_loop_general_kernel<P, T, false, true>), dim3(nb), dim3(C::THREADS), 0, s, (T *)dst,
+                             (const T *)src, op.idx27, count, (const Basis1D<T> *)op.basis, (const T *)nullptr, (T)op.coef[0],
+                             (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5], list, scratch,
+                             op.idx27_plain, (const T *)rhs_q);
+      }
+    if (scratch)
+      assemble_t<T>(s, op, 0, dst, nullptr, 0u);
+  }
+
+  void launch_cell_residual(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *rhs_q,
+                            const uint32_t *lists, const uint32_t *list_start, int n_lists)
+  {
+    if (op.number == 1)
+      {
+        MGX_DISPATCH_P(op.p, cell_residual_t<P, double>(s, op, dst, src, rhs_q, lists, list_start, n_lists));
+      }
+    else
+      {
+        MGX_DISPATCH_P(op.p, cell_residual_t<P, float>(s, op, dst, src, rhs_q, lists, list_start, n_lists));
       }
   }
 

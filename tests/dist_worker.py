@@ -98,7 +98,13 @@ def main():
     else:
         ctx = mg.Context(0)
         comm = mg.Communicator(ctx, dist)
-        solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32 if vfloat else mg.F64, comm=comm)
+        device_rhs = os.environ.get("MGX_TEST_DEVICE_RHS", "0") == "1"
+        solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F32 if vfloat else mg.F64, comm=comm, device_rhs=device_rhs)
+        if device_rhs:  # assembled per rank on the GPU and summed over the interface: the oracle's rhs of the whole mesh
+            for lev in range(cube.n_levels):
+                ref = lex_of(orc, lev, orc.rhs(lev))[cube.dof_grid(lev)]
+                got = solver.get_vector(lev, "rhs").download()
+                assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), ("device rhs", lev, np.abs(got - ref).max())
         tol_v, tol_r, tol_l2 = (2e-4, 2e-3, 1e-4) if vfloat else (1e-9, 1e-6, 1e-8)
         if mode == "nccl":
             assert comm.native_ready, "library-side RCCL communicator was not created"

@@ -74,6 +74,15 @@ def test_fused_transfers_on_decomposed_levels(monkeypatch, world, p, nr, extra, 
     assert all("transfer_create: interface rows" in o for o in outs), [o[-2000:] for o in outs]
 
 
+@pytest.mark.parametrize("world,p,nr,extra", [(2, 4, 3, ()), (4, 3, 2, ("strong",)), (2, 4, 2, ("shell_sector",))])
+def test_right_hand_side_assembled_on_the_device(monkeypatch, world, p, nr, extra):
+    """mgx_solver_compute_rhs on a decomposed mesh: every rank integrates over its cells on the GPU, the interface
+    entries are summed over the ranks; the vectors against the single-domain oracle, then FMG / PCG as usual"""
+    monkeypatch.setenv("MGX_TEST_DEVICE_RHS", "1")
+    outs = launch("gpu", world, p, nr, extra=extra)
+    assert all("gpu ok" in o for o in outs), outs
+
+
 def test_bench_launches_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts two ranks itself; here over gloo, both on the one GPU"""
     import json
