@@ -11,10 +11,16 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    p, basis, steps, number = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], dist, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run(p, basis, steps, number, dist, rank, world, say=print):
+    """`dist`: torch.distributed or an object with its interface (tests/thread_ranks.py)"""
     import multigrid_amd as mg
     from oracle import dg_oracle as dg
 
@@ -67,12 +73,10 @@ def main():
     assert rel(owned(Q), mine(q_ref)) < 5 * tol and rel(owned(X), mine(x + 0.37 * pv)) < 5 * tol, "cg update"
     ref = np.array([(q_ref * p_ref).sum(), (r * r).sum(), (q_ref * r).sum(), (q_ref * q_ref).sum()])
     assert np.allclose(sums, ref, rtol=100 * tol, atol=100 * tol * abs(ref).max()), ("cg sums", sums, ref)
-    print("rank %d dg ok: %d owned cells, %d ghost cells, %d neighbours" % (rank, len(ijk), part["n_ghost"], len(part["exchange"])),
+    say("rank %d dg ok: %d owned cells, %d ghost cells, %d neighbours" % (rank, len(ijk), part["n_ghost"], len(part["exchange"])),
           flush=True)
     op.clear()
     ctx.close()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

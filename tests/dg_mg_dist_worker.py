@@ -10,10 +10,16 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    p, nr, basis, number = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], dist, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run(p, nr, basis, number, dist, rank, world, say=print):
+    """`dist`: torch.distributed or an object with its interface (tests/thread_ranks.py)"""
     import multigrid_amd as mg
     from oracle import Oracle, dg_oracle as dg
 
@@ -48,11 +54,9 @@ def main():
     xo, oits, ored = orc.solve_cg(rhs, 1e-9)
     assert abs(its - oits) <= (0 if num == mg.F64 else 1), (its, oits)
     assert rel(sol.download()[:n], mine(xo)) < (1e-7 if num == mg.F64 else 1e-6), "solution"
-    print("rank %d dg multigrid ok: %d iterations, lambda_max %.6f" % (rank, its, info["lambda_max"]), flush=True)
+    say("rank %d dg multigrid ok: %d iterations, lambda_max %.6f" % (rank, its, info["lambda_max"]), flush=True)
     solver.close()
     ctx.close()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -25,19 +25,26 @@ def lex_of(o, l, v):
 
 
 def main():
-    mode, p, nr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    vfloat = "f32" in sys.argv[4:]  # V-cycle number type (reference default: float)
-    strong = "strong" in sys.argv[4:]  # block-split of the square mesh with n_subdiv = 2 (bench.py --scaling strong)
-    # poisson_shell slice: shell sector (or sheared box) with the variable coefficient, block-split like "strong"
-    mapped = [g for g in ("shell_sector", "sheared") if g in sys.argv[4:]]
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
-    if mode == "nccl":
+    if sys.argv[1] == "nccl":
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    run(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4:], dist, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run(mode, p, nr, flags, dist, rank, world, say=print):
+    """the checks of one rank; `dist`: torch.distributed or an object with its interface (tests/thread_ranks.py)"""
+    import torch
+    vfloat = "f32" in flags  # V-cycle number type (reference default: float)
+    strong = "strong" in flags  # block-split of the square mesh with n_subdiv = 2 (bench.py --scaling strong)
+    # poisson_shell slice: shell sector (or sheared box) with the variable coefficient, block-split like "strong"
+    mapped = [g for g in ("shell_sector", "sheared") if g in flags]
 
     import multigrid_amd as mg
     from oracle import Oracle
@@ -94,7 +101,7 @@ def main():
             t = torch.tensor([owned.sum()])
             dist.all_reduce(t)
             assert int(t.item()) == orc.n_dofs(lev), (int(t.item()), orc.n_dofs(lev))
-        print("rank %d host ok" % rank, flush=True)
+        say("rank %d host ok" % rank, flush=True)
     else:
         ctx = mg.Context(0)
         comm = mg.Communicator(ctx, dist)
@@ -134,7 +141,8 @@ def main():
             assert err < 1e-12, ("residual", lev, err)
             assert abs(ctx.l2_norm(src) - np.linalg.norm(xo)) < 1e-12 * np.linalg.norm(xo)
             gi, oi = solver.smoother(lev).info(), orc.cheb_info(lev)
-            assert gi["degree"] == oi["degree"] and gi["cg_its"] == oi["cg_its"], (lev, gi, oi)
+            # (level 0 iterates to convergence: in fp32 the count moves with the order of the interface sums)
+            assert gi["degree"] == oi["degree"] and abs(gi["cg_its"] - oi["cg_its"]) <= (2 if vfloat and lev == 0 else 0), (lev, gi, oi)
             assert abs(gi["lambda_max"] - oi["lambda_max"]) < (1e-4 if vfloat else 1e-8) * oi["lambda_max"], (lev, gi, oi)
         # V-cycle, FMG, PCG
         x = cube.seeded_vector(l, 5)
@@ -157,12 +165,10 @@ def main():
         l2 = solver.compute_l2_error()
         assert abs(l2 - orc.l2_error()) < tol_l2 * l2
         agg = (", coarse levels <= %d agglomerated" % solver.coarse_level) if solver.coarse is not None else ""
-        print("rank %d gpu ok: FMG L2 %.6e, cg its %d%s%s" % (rank, l2, its, ", native RCCL" if comm.native_enabled else "", agg),
-              flush=True)
+        say("rank %d gpu ok: FMG L2 %.6e, cg its %d%s%s" % (rank, l2, its, ", native RCCL" if comm.native_enabled else "", agg),
+            flush=True)
         solver.close()
         ctx.close()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,60 @@
+"""The 2x2x2 decomposition of an 8-GPU run (bench.py --gpus 8, strong scaling layout) on the one GPU of the test box:
+eight ranks as threads (tests/thread_ranks.py), every rank with its own context, cube and solver, exchanging through
+the callback transport; the checks are those of the multi-process tests (tests/dist_worker.py): operator, smoother
+parameters, V-cycle, FMG and PCG against the single-domain oracle on the same global mesh."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+mg = pytest.importorskip("multigrid_amd")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dg_dist_worker  # noqa: E402
+import dg_mg_dist_worker  # noqa: E402
+import dist_worker  # noqa: E402
+from thread_ranks import run_ranks  # noqa: E402
+
+
+def eight(p, nr, flags):
+    lines = []
+    run_ranks(8, lambda dist, r: dist_worker.run("gpu", p, nr, flags, dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
+    assert len(lines) == 8 and all("gpu ok" in s for s in lines), lines
+    return lines
+
+
+@pytest.mark.parametrize("p,nr", [(2, 3), (4, 2)])
+def test_eight_ranks_block_split_cube(p, nr):
+    eight(p, nr, ("strong",))
+
+
+def test_eight_ranks_fused_transfers_and_device_rhs(monkeypatch):
+    """eight-colour schedule on every level, no agglomeration: the fused residual + restriction / prolongation forms with
+    the interface rows of DoFs shared by up to eight ranks; right-hand sides assembled on the device"""
+    monkeypatch.setenv("MGX_FREE_ONE_MAX", "0")
+    monkeypatch.setenv("MGX_FREE_MAX_BRICKS", "0")
+    monkeypatch.setenv("MGX_AGGLOMERATE", "0")
+    monkeypatch.setenv("MGX_OVERLAP_MIN_BRICKS", "1")
+    monkeypatch.setenv("MGX_TEST_DEVICE_RHS", "1")
+    eight(4, 3, ("strong",))
+
+
+def test_eight_ranks_mixed_precision(monkeypatch):
+    eight(3, 3, ("strong", "f32"))
+
+
+@pytest.mark.parametrize("p,basis,steps,number", [(3, 0, 9, "f64"), (4, 1, 9, "f32")])
+def test_eight_ranks_dg_operator(p, basis, steps, number):
+    """DG-SIP operator with ghost cells on 2x2x2 ranks (cells with ghost neighbours in all three directions): operator,
+    merged Chebyshev update and merged CG sums against the single-domain face-based oracle"""
+    lines = []
+    run_ranks(8, lambda dist, r: dg_dist_worker.run(p, basis, steps, number, dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
+    assert len(lines) == 8 and all("dg ok" in s for s in lines), lines
+
+
+def test_eight_ranks_dg_multigrid():
+    """MultigridSolverDG on 2x2x2 ranks: the merged residual + restriction to the decomposed FE_Q hierarchy below"""
+    lines = []
+    run_ranks(8, lambda dist, r: dg_mg_dist_worker.run(2, 2, 0, "f64", dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
+    assert len(lines) == 8 and all("dg multigrid ok" in s for s in lines), lines
