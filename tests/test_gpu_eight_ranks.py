@@ -58,3 +58,28 @@ def test_eight_ranks_dg_multigrid():
     lines = []
     run_ranks(8, lambda dist, r: dg_mg_dist_worker.run(2, 2, 0, "f64", dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
     assert len(lines) == 8 and all("dg multigrid ok" in s for s in lines), lines
+
+
+def benchmark_problem(cells_log2):
+    """what `bench.py --gpus 8 --cells 2^k` solves in its verification: PCG iterations and global L2 error"""
+    def rank_body(dist, r):
+        ctx = mg.Context(0)
+        comm = mg.Communicator(ctx, dist)
+        cube = mg.Cube(4, n_refine=cells_log2 - 1, box=(2, 2, 2), procs=(2, 2, 2), rank=r, origin=-0.9, h0=0.95)
+        solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, mg.F64, comm=comm, device_rhs=True)
+        its, _ = solver.solve_cg()
+        l2 = solver.compute_l2_error()
+        agglomerated = solver.coarse is not None
+        solver.close()
+        cube.close()
+        ctx.close()
+        return its, l2, agglomerated
+    return run_ranks(8, rank_body)
+
+
+def test_eight_ranks_benchmark_problem_64_cubed():
+    """FE_Q(4) on 64^3 cells block-split over 2x2x2 ranks (2.1 M DoFs and 512 bricks per rank: one-launch schedule on the
+    finest level, agglomerated coarse levels): 8 PCG iterations to the README's L2 error (README.md:135-159)"""
+    res = benchmark_problem(6)
+    assert all(r[0] == 8 and r[2] for r in res), res
+    assert all(abs(r[1] / 1.327e-8 - 1) < 5e-3 for r in res), res
