@@ -57,6 +57,9 @@ def parse():
                     help="skip the end-to-end check after the timed region (PCG iteration count and L2 error of the "
                          "manufactured problem, README.md:135-159)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="context option for A/B timings of numerically equivalent code paths (include/mgx.h, "
+                         "mgx_context_set_option); recorded in the JSON line")
     ap.add_argument("--host-rhs", action="store_true",
                     help="assemble the right-hand sides on the host instead of on the GPU (set-up only: not in the timed region)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of domain decomposition")
@@ -295,7 +298,7 @@ def main():
 
     import multigrid_amd as mg
 
-    ctx = mg.Context(local_rank)
+    ctx = mg.Context(local_rank, options={k: float(v) for k, v in (o.split("=") for o in args.option)})
     ns, nr = split_size(args.cells)
     t_setup = time.time()
     vnum = mg.F64 if args.vcycle_number == "f64" else mg.F32
@@ -466,7 +469,7 @@ def main():
                    "transport": transport if decomposed else None},
         "matvec_dofs_per_s": total_dofs / t_mv, "vcycle_dofs_per_s": total_dofs / t_vc,
         "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": t_setup,
-        "rhs_assembly": "host" if args.host_rhs else "device",
+        "rhs_assembly": "host" if args.host_rhs else "device", "options": args.option or None,
         "roofline": roof(2) or roof(0),
         "roofline_matvec": roof(0),
         # the other finest-level forms of the step (HIP events around every application, as above)
