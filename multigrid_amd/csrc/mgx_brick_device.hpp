@@ -394,7 +394,7 @@ namespace mgx
             acc[pnt] = cv[k];
           }
       }
-    __syncthreads();
+    lds_barrier(); // LDS only: the gathered source values of the brick stay in flight
     // z: lines (x, y) with x, y < CN
     for (int l = tid; l < CN * CN; l += NT)
       {
@@ -408,7 +408,7 @@ namespace mgx
         for (int i = 0; i < G; ++i)
           acc[(i * G + y) * G + x] = f[i];
       }
-    __syncthreads();
+    lds_barrier(); // LDS only: the gathered source values of the brick stay in flight
     // y: lines (x < CN, z)
     for (int l = tid; l < CN * G; l += NT)
       {
@@ -422,7 +422,7 @@ namespace mgx
         for (int i = 0; i < G; ++i)
           acc[(z * G + i) * G + x] = f[i];
       }
-    __syncthreads();
+    lds_barrier(); // LDS only: the gathered source values of the brick stay in flight
     // x: lines (y, z)
     for (int l = tid; l < G * G; l += NT)
       {
@@ -435,6 +435,6 @@ namespace mgx
         for (int i = 0; i < G; ++i)
           acc[l * G + i] = f[i];
       }
-    __syncthreads();
+    lds_barrier(); // LDS only: the gathered source values of the brick stay in flight
   }
 } // namespace mgx

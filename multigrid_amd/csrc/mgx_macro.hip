@@ -501,10 +501,31 @@ namespace mgx
     constexpr int  CNP = (C::NB / 2) * P + 1, NCV = CNP * CNP * CNP / NT + 1, CE3 = (C::NB + 1) * (C::NB + 1) * (C::NB + 1);
     T              cvv[NCV];
     T    g[NG][IT];
-    auto gather_issue = [&](const uint32_t *E, uint32_t brick) {
+    uint32_t cw[NCV]; // first coarse DoF of the entities of this thread's coarse points (next brick)
+    // The coarse values travel ahead of the source: their table words are requested with the entity table of the
+    // next brick (loop top, in flight during the sweeps), the values before the write-out (they land under it), and
+    // the interpolation sweeps then run while the gathered source values are still in flight -- nothing of the
+    // prolongation waits for memory after the first brick (phase stamps before: 21 500 cycles between the write-out and
+    // the next loop top, as much as the write-out and the sweeps together; colour launch 189 -> 168.5 us)
+    auto coarse_words = [&](uint32_t brick) {
       if (kProlong)
         {
           const uint32_t *ctab = post.coarse_blocks + (size_t)(brick_first + brick) * CE3;
+#pragma unroll
+          for (int k = 0; k < NCV; ++k)
+            {
+              const int l = tid + k * NT;
+              int       slot = 0, pnt;
+              uint32_t  off;
+              if (l < CNP * CNP * CNP)
+                coarse_point<P>(l, slot, off, pnt);
+              cw[k] = ctab[slot];
+            }
+        }
+    };
+    auto coarse_values = [&]() {
+      if (kProlong)
+        {
 #pragma unroll
           for (int k = 0; k < NCV; ++k)
             {
@@ -515,12 +536,14 @@ namespace mgx
                   int      slot, pnt;
                   uint32_t off;
                   coarse_point<P>(l, slot, off, pnt);
-                  const uint32_t w = ctab[slot];
+                  const uint32_t w = cw[k];
                   const T        v = post.coarse[w != kInvalid ? w + off : 0u];
                   cvv[k]           = w != kInvalid ? v : T(0); // constrained coarse DoF: zero
                 }
             }
         }
+    };
+    auto gather_issue = [&](const uint32_t *E, uint32_t brick) {
       const rsrc_t r0 = MODE == kChebInit ? (DTAB ? R.a : R.b) : rsrc;
       const rsrc_t r1 = MODE == kCgUpdate ? R.b : R.a; // second operand
 #pragma unroll
@@ -569,11 +592,16 @@ namespace mgx
     };
 
     // kChebFirstProlong: x += P x_coarse on the brick array and in the registers (W is free here)
+    auto interpolate = [&]() {
+      if (kProlong)
+        {
+          lds_barrier(); // the entity table parked in W (prologue) has been read by everyone
+          prolong_brick<P, T, NT>(tid, W, B->P1, cvv);
+        }
+    };
     auto add_correction = [&]() {
       if (kProlong)
         {
-          __syncthreads(); // the entity table parked in W (prologue) has been read by everyone
-          prolong_brick<P, T, NT>(tid, W, B->P1, cvv);
 #pragma unroll
           for (int it = 0; it < IT; ++it)
             if (live(it))
@@ -591,6 +619,9 @@ namespace mgx
     __syncthreads();
     MGX_STAMP(1);
     gather_issue(reinterpret_cast<const uint32_t *>(W), b);
+    coarse_words(b);
+    coarse_values();
+    interpolate();
     gather_land();
     add_correction();
     MGX_STAMP(2);
@@ -607,7 +638,10 @@ namespace mgx
         const bool     has_next = bn < brick_count;
         MGX_STAMP_IT(3);
         if (has_next)
-          table_load(bn, en); // in flight during the sweeps
+          {
+            table_load(bn, en); // in flight during the sweeps
+            coarse_words(bn);
+          }
         // keep what is derived from the item words (LDS addresses, offsets) out of the registers
         // that live across the sweeps: the compiler must not hoist it out of the brick loop
 #pragma unroll
@@ -788,6 +822,8 @@ namespace mgx
         constexpr bool kPipeGather = (MODE != kChebInit || DTAB) && MODE != kCgUpdate && MODE != kChebFirstProlong;
         if (has_next && kPipeGather)
           gather_issue(E2, bn);
+        if (has_next)
+          coarse_values(); // land under the write-out
         MGX_STAMP_IT(7);
 
         // ---- write-out with the fused post-operation, same item -> thread mapping as the gather.
@@ -957,6 +993,7 @@ namespace mgx
 #pragma unroll
         for (int j = 0; j < NEW; ++j)
           ec[j] = en[j];
+        interpolate(); // (kChebFirstProlong) on W, while the source values are in flight
         gather_land();
         add_correction();
         MGX_STAMP_IT(9);

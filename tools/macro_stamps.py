@@ -1,6 +1,7 @@
 """Phase timeline of the macro-element brick kernel (diagnostic build: make -C multigrid_amd/csrc
 MACROFLAGS=-DMGX_MACRO_STAMPS).  Prints median cycles per phase over the workgroups of the last
-colour launch.  usage: macro_stamps.py [cells] [vmult|cheb]"""
+colour launch.  usage: macro_stamps.py [cells] [vmult|cheb|prolong]
+(prolong: a V-cycle with Chebyshev degree 1, whose last finest-level launch is the prolongation form, mode 9)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +20,10 @@ y = ctx.vector(cube.n_dofs(l))
 if mode == "vmult":
     for _ in range(5):
         op.vmult(y, x)
+elif mode == "prolong":
+    solver = mg.MultigridSolver(ctx, cube, 1, 1, 1, mg.F64)
+    for _ in range(3):
+        solver.vmult(y, x)
 else:
     sm = mg.Chebyshev(op, 20., 3, 15)
     for _ in range(3):
