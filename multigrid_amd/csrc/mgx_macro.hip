@@ -506,7 +506,7 @@ namespace mgx
     // next brick (loop top, in flight during the sweeps), the values before the write-out (they land under it), and
     // the interpolation sweeps then run while the gathered source values are still in flight -- nothing of the
     // prolongation waits for memory after the first brick (phase stamps before: 21 500 cycles between the write-out and
-    // the next loop top, as much as the write-out and the sweeps together; colour launch 189 -> 168.5 us)
+    // the next loop top, as much as the write-out and the sweeps together; colour launch on one box, A/B: 188.7 -> 183 us)
     auto coarse_words = [&](uint32_t brick) {
       if (kProlong)
         {
