@@ -121,8 +121,7 @@ def test_production_path_equals_plain_path_at_scale(monkeypatch, p, ns, nr):
     in a cross-check build also the cell-by-cell brick kernel).  The two differ in summation order only."""
     monkeypatch.delenv("MGX_BRICK_MIN", raising=False)
     monkeypatch.delenv("MGX_RESTRICT_COLOUR_MIN", raising=False)
-    # degrees 7 and 8 run the separate transfer kernels by default (faster there): their fused forms
-    # stay under test
+    # degree 7 runs the separate transfer kernels by default (faster there): its fused forms stay under test
     ctx = mg.Context(0, options={"force_fused_transfers": 1})
     cube = mg.Cube(p, ns, nr)
     l = cube.max_level
