@@ -150,6 +150,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"dg_unmerged_restrict", &dg_unmerged_restrict, nullptr},
     {"no_fused_decomposed", &no_fused_decomposed, nullptr},
     {"no_fused_assembly", &no_fused_assembly, nullptr},
+    {"no_fused_residual", &no_fused_residual, nullptr},
     // emulation of a rank of a decomposed mesh on one GPU (tools/rank_emulation.py): the results are WRONG
     {"rccl_selftest", &rccl_selftest, nullptr},
   };
@@ -3201,7 +3202,7 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
       // their own: the fused forms below need the eight colour launches, each as long as a brick's
       // whole latency chain on such a level (2 M DoFs: 63 instead of 147 us, 52 instead of 180 us)
       const bool one_launch = S->matrix[level]->d.bricks.fr.available() && S->matrix[level]->d.bricks.fr.n_classes == 1;
-      if (S->transfer[level]->d.coarse_blocks && !one_launch)
+      if (S->transfer[level]->d.coarse_blocks && !one_launch && !S->ctx->tun.no_fused_residual)
         {
           // residual and restriction in one pass of the cell loop: t only carries the partial sums
           // of brick-surface DoFs between the colour launches, the residual is never stored

@@ -32,6 +32,7 @@ namespace mgx
     bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
     uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads
     bool     dg_no_overlap    = false; // MGX_DG_NO_OVERLAP        DG ghost exchange before all cells instead of under the interior ones
+    bool     no_fused_residual = false;  // V-cycle: residual and restriction as separate kernels, the prolongation form stays fused
     bool     no_fused_assembly = false;  // per-cell levels: Chebyshev update as a kernel after the assembly kernel
     bool     no_fused_decomposed = false; // decomposed levels: residual / restriction / prolongation as separate kernels
     bool     dg_unmerged_restrict = false; // DG V-cycle: residual and DG -> FE_Q restriction as two kernels instead of the merged action 1
