@@ -46,3 +46,23 @@ def test_gpus_flag_must_match_world_size():
     out = run_bench("--gpus", "4", "--dry-run", "--cells", "16",
                     env_extra={"WORLD_SIZE": "1", "RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert out.returncode != 0 and b"--gpus 4 but WORLD_SIZE=1" in out.stderr
+
+
+def test_under_torch_distributed_run():
+    """the driver's launch line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- the ranks exist already, bench.py joins them"""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                          "--cells", "16"], cwd=ROOT, env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.decode().strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1   # rank 0 alone prints the JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["exchange_ok"]
