@@ -58,11 +58,14 @@
 // Diagnostic build only (make MACROFLAGS=-DMGX_MACRO_STAMPS): thread 0 of every workgroup records
 // s_memtime at the phase boundaries; tools/macro_stamps.py reads them back.  Never compiled into
 // the production library.
+#ifndef MGX_MACRO_STAMP_MODE
+#define MGX_MACRO_STAMP_MODE -1 // >= 0: only launches of this BrickMode leave stamps
+#endif
 __device__ unsigned long long g_mgx_stamps[8192 * 16];
 #define MGX_STAMP(k)                                                                    \
   do                                                                                    \
     {                                                                                   \
-      if (threadIdx.x == 0 && blockIdx.x < 8192)                                        \
+      if (threadIdx.x == 0 && blockIdx.x < 8192 && (MGX_MACRO_STAMP_MODE < 0 || MODE == MGX_MACRO_STAMP_MODE)) \
         g_mgx_stamps[blockIdx.x * 16 + (k)] = ((k) == 15 || (k) == 13) ? __builtin_amdgcn_s_memrealtime() \
                                                         : __builtin_amdgcn_s_memtime();  \
     }                                                                                   \

@@ -11,7 +11,9 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "vmult"
 ns, nr = cells, 0
 while ns % 2 == 0 and ns > 1:
     ns //= 2; nr += 1
-ctx = mg.Context(0)
+# (prolong: the level below the finest one on the one-launch schedule, whose transfers are kernels of their own: the
+# stamped launches of the fused transfer forms then all belong to the finest level)
+ctx = mg.Context(0, options={"free_one_max": 8192} if mode == "prolong" else None)
 cube = mg.Cube(4, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
