@@ -3217,19 +3217,17 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
             }
           else
             {
-              // decomposed: the residuals of the DoFs on the rank interface exist after the exchange of their sums
-              // in t; their owners restrict them (interior bricks, which may still run, touch no interface DoF of
-              // either level), then the coarse defect is summed over the ranks like any restricted vector
+              // decomposed: every rank's bricks restrict their own shares of A x on all their points and b on the
+              // points they complete; a DoF on the rank interface is completed by no brick, its b comes from its owner
+              // (list kernel); no exchange on the fine level, the coarse defect is summed over the ranks like any
+              // restricted vector
               const TransferData &T = S->transfer[level]->d;
-              MGX_TRY(brick_loop_with_exchange(
-                A, 7, S->t[level],
-                [&](hipStream_t st, int g0, int g1) {
-                  launch_brick_loop(st, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level], 0.,
-                                    0., nullptr, 0., S->defect[level - 1], T.coarse_blocks, g0, g1, false);
-                },
-                [&](hipStream_t st) {
-                  launch_interface_restrict(st, A->d.number, T, S->defect[level - 1], S->defect[level], S->t[level]);
-                }));
+              {
+                ProfileBracket pb(A, 7);
+                launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level], 0.,
+                                  0., nullptr, 0., S->defect[level - 1], T.coarse_blocks);
+              }
+              launch_interface_restrict(s, A->d.number, T, S->defect[level - 1], S->defect[level], nullptr);
               MGX_TRY(exchange_add(S->matrix[level - 1], S->defect[level - 1]));
             }
         }

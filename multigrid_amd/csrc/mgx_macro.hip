@@ -315,7 +315,8 @@ namespace mgx
   __device__ __forceinline__ void post_issue(const PostRsrc<T> &R, uint32_t w, uint32_t off, PostOps<T> &o)
   {
     const bool valid        = w != kInvalid;
-    const bool need_partial = valid && !(w & 0x40000000u); // not FIRST
+    // (kResidualRestrict hands nothing over between the bricks, see post_finish)
+    const bool need_partial = valid && !(w & 0x40000000u) && MODE != kResidualRestrict; // not FIRST
     const bool last         = valid && (w >> 31);
     o.pv[0] = o.pv[1] = o.av[0] = o.av[1] = o.bv[0] = o.bv[1] = o.ov[0] = o.ov[1] = T(0);
     const uint32_t ol = last ? off : kOob, op = need_partial ? off : kOob;
@@ -346,7 +347,14 @@ namespace mgx
     val += pv; // out-of-range loads returned zero
     if (MODE == kPlain || MODE == kCgUpdate)
       return val;
-    else if (MODE == kResidual || MODE == kResidualRestrict)
+    else if (MODE == kResidualRestrict)
+      // The restriction is linear: R (b - A x) = sum over the bricks of R_brick (b_brick - (A x)_brick), with
+      // (A x)_brick the brick's own partial sums on ALL its points and b_brick = b on the points the brick
+      // completes (every DoF has exactly one LAST visitor).  No partial sum travels between the bricks, nothing is
+      // stored on the fine level; on a decomposed mesh the interface DoFs (never LAST) miss only their b, which the
+      // owner adds (launch_interface_restrict).
+      return (last ? av : T(0)) - val;
+    else if (MODE == kResidual)
       return last ? av - val : val;
     else
       {
@@ -926,15 +934,13 @@ namespace mgx
                       };
                       if (MODE == kResidualRestrict)
                         {
-                          // completed residuals stay in W for the restriction, partial sums go to the
-                          // carrier, everything that is not a completed residual becomes zero
-                          if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
-                            st(R.partial, last ? kOob : off);
+                          // the brick's share of the residual stays in W for the restriction (rows of constrained
+                          // DoFs: zero)
                           if (ulive(u))
                             {
-                              W[item_point(mw[v0])] = last ? res[0] : T(0);
+                              W[item_point(mw[v0])] = vld ? res[0] : T(0);
                               if (pair)
-                                W[item_point(mw[v0 + 1])] = last ? res[1] : T(0);
+                                W[item_point(mw[v0 + 1])] = vld ? res[1] : T(0);
                             }
                         }
                       else if (MODE == kCgUpdate)

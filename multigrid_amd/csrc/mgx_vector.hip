@@ -163,7 +163,7 @@ namespace mgx
       {
         T sum = T(0);
         for (uint32_t k = start[i] + lane; k < start[i + 1]; k += LANES)
-          sum += w[k] * (b[fdof[k]] - ax[fdof[k]]);
+          sum += w[k] * (ax ? b[fdof[k]] - ax[fdof[k]] : b[fdof[k]]);
 #pragma unroll
         for (int o = LANES / 2; o > 0; o >>= 1)
           sum += __shfl_xor(sum, o, LANES);
