@@ -151,6 +151,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"no_fused_decomposed", &no_fused_decomposed, nullptr},
     {"no_fused_assembly", &no_fused_assembly, nullptr},
     {"no_fused_residual", &no_fused_residual, nullptr},
+    {"no_restrict_scratch", &no_restrict_scratch, nullptr},
     // emulation of a rank of a decomposed mesh on one GPU (tools/rank_emulation.py): the results are WRONG
     {"rccl_selftest", &rccl_selftest, nullptr},
   };
@@ -2778,6 +2779,52 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
               MGX_HIP(hipMalloc((void **)&tr->d.coarse_blocks, sizeof(uint32_t) * tab.size()));
               MGX_HIP(hipMemcpy(tr->d.coarse_blocks, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
             }
+          // scratch form of the fused residual + restriction: every brick stores its (PB p + 1)^3 restricted values
+          // in a block of its own; the coarse vector is assembled from the blocks in brick order
+          const uint64_t CN = (uint64_t)PB * p + 1, NC = CN * CN * CN;
+          // (levels on the reduced-colour schedules only: there a colour launch is as long as a brick's latency chain and
+          // one launch instead of eight pays -- 17 M DoFs 179 -> 164 us; on the finest level of C2 the blocks' extra traffic
+          // costs more than the seven launch ramps it saves, 1.184 against 1.138 ms)
+          if (consistent && (uint64_t)nb * NC < 0xFFFFFFF0ull && !coarse->ctx->tun.no_restrict_scratch &&
+              nb <= coarse->ctx->tun.free_max_bricks)
+            {
+              auto layer = [p](int a, int &e, int &o, int &len) {
+                const int q = a / p, rr = a - q * p;
+                e           = 2 * q + (rr != 0);
+                o           = rr ? rr - 1 : 0;
+                len         = rr ? p - 1 : 1;
+              };
+              const uint32_t        ncd = coarse->d.n_dofs;
+              std::vector<uint32_t> start(ncd + 1, 0), dof((size_t)nb * NC, kInvalid);
+#pragma omp parallel for schedule(static)
+              for (uint32_t sb = 0; sb < nb; ++sb)
+                for (uint32_t l = 0; l < NC; ++l)
+                  {
+                    const int x = (int)(l % CN), y = (int)((l / CN) % CN), z = (int)(l / (CN * CN));
+                    int       ex, ey, ez, ox, oy, oz, nx, ny, nz;
+                    layer(x, ex, ox, nx);
+                    layer(y, ey, oy, ny);
+                    layer(z, ez, oz, nz);
+                    const uint32_t w = tab[(size_t)sb * CE3 + (size_t)((ez * CE1 + ey) * CE1 + ex)];
+                    if (w != kInvalid)
+                      dof[(size_t)sb * NC + l] = w + (uint32_t)((oz * ny + oy) * nx + ox);
+                  }
+              for (uint32_t d : dof)
+                if (d != kInvalid)
+                  start[d + 1]++;
+              for (uint32_t d = 0; d < ncd; ++d)
+                start[d + 1] += start[d];
+              std::vector<uint32_t> pos(start[ncd]), fill(start.begin(), start.end() - 1);
+              for (size_t k = 0; k < dof.size(); ++k) // ascending position = ascending brick: the order of the sums
+                if (dof[k] != kInvalid)
+                  pos[fill[dof[k]]++] = (uint32_t)k;
+              MGX_HIP(hipMalloc(&tr->d.coarse_scratch, number_size(fine->d.number) * (size_t)nb * NC));
+              MGX_HIP(hipMemset(tr->d.coarse_scratch, 0, number_size(fine->d.number) * (size_t)nb * NC));
+              MGX_HIP(hipMalloc((void **)&tr->d.cs_start, sizeof(uint32_t) * start.size()));
+              MGX_HIP(hipMemcpy(tr->d.cs_start, start.data(), sizeof(uint32_t) * start.size(), hipMemcpyHostToDevice));
+              MGX_HIP(hipMalloc((void **)&tr->d.cs_pos, sizeof(uint32_t) * std::max<size_t>(1, pos.size())));
+              MGX_HIP(hipMemcpy(tr->d.cs_pos, pos.data(), sizeof(uint32_t) * pos.size(), hipMemcpyHostToDevice));
+            }
         }
     }
   if (tr->d.owner_weights && !tr->d.patch)
@@ -2799,6 +2846,9 @@ int mgx_transfer_destroy(mgx_transfer_t tr)
   (void)hipFree(tr->d.own27);
   (void)hipFree(tr->d.patch);
   (void)hipFree(tr->d.coarse_blocks);
+  (void)hipFree(tr->d.coarse_scratch);
+  (void)hipFree(tr->d.cs_start);
+  (void)hipFree(tr->d.cs_pos);
   for (void *q : {(void *)tr->d.ifr_cdof, (void *)tr->d.ifr_start, (void *)tr->d.ifr_fdof, tr->d.ifr_w, (void *)tr->d.ifp_start,
                   (void *)tr->d.ifp_cdof, tr->d.ifp_w})
     (void)hipFree(q);
@@ -3202,31 +3252,36 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
       // their own: the fused forms below need the eight colour launches, each as long as a brick's
       // whole latency chain on such a level (2 M DoFs: 63 instead of 147 us, 52 instead of 180 us)
       const bool one_launch = S->matrix[level]->d.bricks.fr.available() && S->matrix[level]->d.bricks.fr.n_classes == 1;
-      if (S->transfer[level]->d.coarse_blocks && !one_launch && !S->ctx->tun.no_fused_residual)
+      // (with the scratch form of the restriction also on the one-launch schedule: it is one launch itself)
+      if (S->transfer[level]->d.coarse_blocks && (!one_launch || S->transfer[level]->d.coarse_scratch) &&
+          !S->ctx->tun.no_fused_residual)
         {
           // residual and restriction in one pass of the cell loop: t only carries the partial sums
           // of brick-surface DoFs between the colour launches, the residual is never stored
-          Stopwatch      sw(S, level, 0);
-          mgx_operator_t A = S->matrix[level];
-          MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s)); // :667
-          if (!A->plan)
-            {
-              ProfileBracket pb(A, 7);
-              launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level],
-                                0., 0., nullptr, 0., S->defect[level - 1], S->transfer[level]->d.coarse_blocks);
-            }
-          else
+          Stopwatch           sw(S, level, 0);
+          mgx_operator_t      A = S->matrix[level];
+          const TransferData &T = S->transfer[level]->d;
+          // scratch form: the bricks store their restricted values block by block (one launch for the level), the
+          // coarse defect is assembled from the blocks; otherwise they add into the zeroed coarse defect colour by
+          // colour.  (The form carries no partial sums: its `partial` argument names the scratch array.)
+          void *scratch = (T.coarse_scratch && !A->d.cells_form) ? T.coarse_scratch : nullptr;
+          if (!scratch)
+            MGX_HIP(hipMemsetAsync(S->defect[level - 1], 0, number_size(S->vnumber) * nc, s)); // :667
+          {
+            ProfileBracket pb(A, 7);
+            // (the cell-by-cell form of a cross-check build still hands partial sums over through t)
+            launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level],
+                              scratch ? scratch : (A->d.cells_form ? S->t[level] : nullptr), 0., 0., nullptr, 0.,
+                              S->defect[level - 1], T.coarse_blocks);
+            if (scratch)
+              launch_coarse_assemble(s, A->d.number, T, S->defect[level - 1]);
+          }
+          if (A->plan)
             {
               // decomposed: every rank's bricks restrict their own shares of A x on all their points and b on the
               // points they complete; a DoF on the rank interface is completed by no brick, its b comes from its owner
               // (list kernel); no exchange on the fine level, the coarse defect is summed over the ranks like any
               // restricted vector
-              const TransferData &T = S->transfer[level]->d;
-              {
-                ProfileBracket pb(A, 7);
-                launch_brick_loop(s, A->d, 7, S->solution_update[level], S->defect[level], nullptr, S->t[level], S->t[level], 0.,
-                                  0., nullptr, 0., S->defect[level - 1], T.coarse_blocks);
-              }
               launch_interface_restrict(s, A->d.number, T, S->defect[level - 1], S->defect[level], nullptr);
               MGX_TRY(exchange_add(S->matrix[level - 1], S->defect[level - 1]));
             }

@@ -79,6 +79,7 @@ namespace mgx
     T        f1, f2, f0;
     T              *coarse;        // kResidualRestrict: coarse-level vector the restriction adds to
     const uint32_t *coarse_blocks; // kResidualRestrict: coarse entity table of the brick's parents
+    T              *coarse_scratch; // kResidualRestrict: [brick][CN^3] restricted values per brick (nullptr: added into `coarse`)
     // kCgUpdate: a = r, b = q (second gathered operand), old = x, out = q, f1 = alpha, f2 = beta
     T              *src_w;         // kCgUpdate: the source vector p, written at completion
     T              *x_w;           // kCgUpdate: x, updated at completion
@@ -216,10 +217,13 @@ namespace mgx
   // spans two parents (p <= 4), two neighbouring lanes per line: 289 + 153 + 81 lines on 256 threads take
   // 3 + 2 + 1 passes of half the work instead of 2 + 1 + 1 passes of the whole.  The coarse point the two
   // parents share receives both contributions (minus the fine value counted by both) from the lower lane.
-  template <int P, typename T, int NT>
+  template <int P, typename T, int NT, bool SCRATCH = false>
   __device__ __forceinline__ void restrict_brick(int tid, T *acc, const T *__restrict__ p1, T *__restrict__ coarse,
-                                                 const uint32_t *__restrict__ ctab)
+                                                 const uint32_t *__restrict__ ctab, T *__restrict__ scratch = nullptr)
   {
+    // SCRATCH (scratch != nullptr): the CN^3 restricted values of the brick go to scratch[(z CN + y) CN + x]
+    // instead of being added into the coarse vector: no two bricks write the same address, the bricks of a level
+    // need no order among each other (coarse_assemble_kernel adds the blocks up per coarse DoF afterwards)
     using C           = BCfg<P>;
     constexpr int G   = C::G, PB = C::NB / 2, CN = PB * P + 1, CE1 = 2 * PB + 1, N = P + 1, M = 2 * P + 1;
     auto layer = [](int a, int &e, int &o, int &n) {
@@ -231,11 +235,11 @@ namespace mgx
     // the coarse values this thread will add to (z sweep, one coarse point per parent-half item): requested
     // now, two sweeps ahead of their use
     constexpr int NZ = (CN * CN * PB + NT - 1) / NT;
-    T            *cp[NZ][N];
-    T             cv[NZ][N];
-    bool          ok[NZ][N];
+    T            *cp[SCRATCH ? 1 : NZ][N];
+    T             cv[SCRATCH ? 1 : NZ][N];
+    bool          ok[SCRATCH ? 1 : NZ][N];
 #pragma unroll
-    for (int it = 0; it < NZ; ++it)
+    for (int it = 0; it < (SCRATCH ? 0 : NZ); ++it)
       {
         const int t = tid + it * NT, l = t / PB, pb = t % PB;
         const bool live = t < CN * CN * PB;
@@ -311,16 +315,28 @@ namespace mgx
       int it = 0;
       sweep(
         CN * CN, [&](int l) { return (l / CN) * G + l % CN; }, G * G,
-        [&](bool, int, int, const T(&o)[N]) {
+        [&](bool live, int l, int pb, const T(&o)[N]) {
+          if (SCRATCH)
+            {
+              if (live)
+                {
 #pragma unroll
-          for (int k = 0; k < NZ; ++k)
-            if (k == it)
-              {
+                  for (int j = (pb == 0 ? 0 : 1); j < N; ++j)
+                    scratch[(size_t)((pb * P + j) * CN * CN + l)] = o[j];
+                }
+            }
+          else
+            {
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                  if (ok[k][j])
-                    *cp[k][j] = cv[k][j] + o[j];
-              }
+              for (int k = 0; k < (SCRATCH ? 0 : NZ); ++k)
+                if (k == it)
+                  {
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                      if (ok[SCRATCH ? 0 : k][j])
+                        *cp[SCRATCH ? 0 : k][j] = cv[SCRATCH ? 0 : k][j] + o[j];
+                  }
+            }
           ++it;
         });
     }

@@ -32,6 +32,7 @@ namespace mgx
     bool     cells_form       = false; // MGX_BRICK_FORM=cells cell-by-cell brick kernel instead of the macro-element one
     uint32_t wide_max         = 1024;  // MGX_BRICK_WIDE_MAX   cell-by-cell form: launches below this use 512 threads
     bool     dg_no_overlap    = false; // MGX_DG_NO_OVERLAP        DG ghost exchange before all cells instead of under the interior ones
+    bool     no_restrict_scratch = false; // fused residual + restriction adds into the coarse vector colour by colour instead of through per-brick blocks
     bool     no_fused_residual = false;  // V-cycle: residual and restriction as separate kernels, the prolongation form stays fused
     bool     no_fused_assembly = false;  // per-cell levels: Chebyshev update as a kernel after the assembly kernel
     bool     no_fused_decomposed = false; // decomposed levels: residual / restriction / prolongation as separate kernels
@@ -177,6 +178,12 @@ namespace mgx
     // colour-sorted brick order, the first coarse DoF (constrained: invalid) of the (2 PB + 1)^3 mesh
     // entities of the PB^3 parents the brick's cells belong to (PB = 2 for p <= 4, 1 for p >= 5)
     uint32_t           *coarse_blocks = nullptr;
+    // ... restricted values per brick, [n_bricks][(PB p + 1)^3] in the number type, and the ordered assembly of the
+    // coarse vector from them: coarse[d] = sum of coarse_scratch[cs_pos[k]], k in [cs_start[d], cs_start[d + 1]),
+    // in ascending brick order (launch_coarse_assemble).  The bricks of a level then write disjoint addresses and the
+    // fused residual + restriction is ONE launch per level.
+    void               *coarse_scratch = nullptr;
+    uint32_t           *cs_start = nullptr, *cs_pos = nullptr;
     // ... on a decomposed mesh: the DoFs on the rank interface, which no brick completes, are transferred by two
     // list kernels after the exchange.  Restriction (CSR by coarse DoF over the interface DoFs this rank owns):
     // coarse[ifr_cdof[i]] += sum_k ifr_w[k] r[ifr_fdof[k]], k in [ifr_start[i], ifr_start[i+1]).  Prolongation (CSR by
@@ -367,6 +374,8 @@ namespace mgx
                                  double beta, const void *r, void *q, void *p, void *x, double *partials);
   // fused transfers on a decomposed level (TransferData::ifr_* / ifp_*, mgx_vector.hip):
   // coarse += R (b - ax) over the owned interface DoFs;  xi = x + P e, out = xi + f2 dinv (b - ax), x = xi on the shared DoFs
+  // coarse[d] = ordered sum of the bricks' restricted values (TransferData::coarse_scratch), every coarse DoF written
+  void launch_coarse_assemble(hipStream_t s, int number, const TransferData &tr, void *coarse);
   void launch_interface_restrict(hipStream_t s, int number, const TransferData &tr, void *coarse, const void *b, const void *ax);
   void launch_interface_prolong_cheb(hipStream_t s, int number, const TransferData &tr, const uint32_t *shared, const void *e,
                                      void *x, void *out, const void *b, const void *dinv, double f2, const void *ax);

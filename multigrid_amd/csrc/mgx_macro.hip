@@ -991,8 +991,12 @@ namespace mgx
           {
             constexpr int CE1 = C::NB + 1; // 2 PB + 1
             __syncthreads();
-            restrict_brick<P, T, NT>(tid, W, B->P1, post.coarse,
-                                     post.coarse_blocks + (size_t)(brick_first + b) * (CE1 * CE1 * CE1));
+            const uint32_t *ctab = post.coarse_blocks + (size_t)(brick_first + b) * (CE1 * CE1 * CE1);
+            if (post.coarse_scratch) // uniform
+              restrict_brick<P, T, NT, true>(tid, W, B->P1, nullptr, ctab,
+                                             post.coarse_scratch + (size_t)(brick_first + b) * (CNP * CNP * CNP));
+            else
+              restrict_brick<P, T, NT, false>(tid, W, B->P1, post.coarse, ctab);
           }
         if (!has_next)
           break;
@@ -1097,9 +1101,18 @@ namespace mgx
         if constexpr (MODE <= kChebOldInit)
           return macro_launch_free<P, T, MODE>(s, op, src, post, g0, g1);
       }
+    // kResidualRestrict with a coarse scratch array: the bricks hand nothing to each other and write disjoint
+    // addresses -- one launch for all of them
+    const bool one_launch = MODE == kResidualRestrict && post.coarse_scratch != nullptr;
     for (int c = g0; c < g1; ++c)
       {
-        const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
+        uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
+        if (one_launch)
+          {
+            if (c != g0)
+              break;
+            count = bd.colour_start[g1] - first;
+          }
         if (count == 0)
           continue;
         // persistent workgroups: as many as are resident at once (WGS per CU), each walks over
@@ -1313,6 +1326,8 @@ namespace mgx
     post.f0            = (T)f0;
     post.coarse        = (T *)coarse;
     post.coarse_blocks = coarse_blocks;
+    // (kResidualRestrict carries no partial sums: its `partial` argument names the coarse scratch array, if any)
+    post.coarse_scratch = mode == kResidualRestrict ? (T *)partial : nullptr;
     post.src_w         = (T *)const_cast<void *>(src); // kChebFirstProlong writes the corrected x back
     switch (op.p)
       {

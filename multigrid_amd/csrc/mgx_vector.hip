@@ -146,6 +146,21 @@ namespace mgx
     }
   }
 
+  // fused residual + restriction in its scratch form: the coarse vector from the bricks' blocks of restricted values
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_coarse_assemble(T *__restrict__ coarse, const T *__restrict__ scratch, const uint32_t *__restrict__ start,
+                      const uint32_t *__restrict__ pos, uint32_t n)
+  {
+    GRID_STRIDE(d, n)
+    {
+      T sum = T(0);
+      for (uint32_t k = start[d]; k < start[d + 1]; ++k)
+        sum += scratch[pos[k]];
+      coarse[d] = sum;
+    }
+  }
+
   // Fused level transfers on a decomposed mesh (TransferData::ifr_*, ifp_*): the part of the DoFs on the rank
   // interface, whose sums of A x are complete only after the exchange.  Restriction of their residuals, one thread
   // per coarse DoF (fixed order of the additions) ...
@@ -599,6 +614,15 @@ namespace mgx
     BY_NUMBER(number, hipLaunchKernelGGL((k_cheb_constrained<T>), stream_grid(count), dim3(256), 0, s, mode,
                                          (const T *)x, (T *)out, (const T *)b, (const T *)dinv, (T)f1, (T)f2, list,
                                          count, (const T *)ax, (const T *)old, (T)f0));
+  }
+
+  void launch_coarse_assemble(hipStream_t s, int number, const TransferData &tr, void *coarse)
+  {
+    const uint32_t n = tr.coarse->n_dofs;
+    if (n == 0)
+      return;
+    BY_NUMBER(number, hipLaunchKernelGGL((k_coarse_assemble<T>), stream_grid(n), dim3(256), 0, s, (T *)coarse,
+                                         (const T *)tr.coarse_scratch, tr.cs_start, tr.cs_pos, n));
   }
 
   void launch_interface_restrict(hipStream_t s, int number, const TransferData &tr, void *coarse, const void *b, const void *ax)
