@@ -12,7 +12,8 @@ while ns % 2 == 0 and ns > 1:
 # mode "all": the level below the finest one runs on the one-launch schedule with separate transfer kernels, so that
 # every launch of the fused transfer forms (and every 512-block launch of the eight-colour kernels) in the trace
 # belongs to the finest level
-ctx = mg.Context(0, options={"free_one_max": 8192} if mode == "all" else None)
+# (no_restrict_scratch: otherwise the fused residual + restriction would run there as well, as one launch)
+ctx = mg.Context(0, options={"free_one_max": 8192, "no_restrict_scratch": 1} if mode == "all" else None)
 cube = mg.Cube(deg, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
