@@ -63,3 +63,9 @@ rep("whole workgroup", t[:, 14] - t[:, 0])
 rt = t[:, 13] - t[:, 15]
 print("whole workgroup by s_memrealtime: median %.1f us; launch span %.1f us" %
       (np.median(rt) / 100.0, (t[:, 13].max() - t[:, 15].min()) / 100.0))
+# how the launch ends: start and end of every workgroup relative to the first start (s_memrealtime, 100 MHz)
+st, en = (t[:, 15] - t[:, 15].min()) / 100.0, (t[:, 13] - t[:, 15].min()) / 100.0
+pc = lambda a: " ".join("%6.1f" % np.percentile(a, q) for q in (0, 10, 50, 90, 100))   # noqa: E731
+print("workgroup start  [us] min p10 p50 p90 max:", pc(st))
+print("workgroup end    [us] min p10 p50 p90 max:", pc(en))
+print("workgroup length [us] min p10 p50 p90 max:", pc(en - st), "  mean %.1f" % (en - st).mean())
