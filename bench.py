@@ -111,6 +111,11 @@ def cpu_baseline(args):
     n_vc = 16 if cpu_cells <= 64 else 3
     t_vc = orc.time_vcycle(n_vc) / n_vc
     threads = orc.num_threads()
+    # one core on its own (the per-core rate of the threaded run includes what the cores cost each other)
+    orc.set_num_threads(1)
+    n_one = 2 if cpu_cells > 64 else 8
+    t_one = orc.time_vmult(orc.max_level, n_one) / n_one
+    orc.set_num_threads(0)
     orc.close()
     return {
         "value": n / (t_mv + t_vc), "unit": "DoFs/s", "cores": threads, "kind": "port",
@@ -121,6 +126,7 @@ def cpu_baseline(args):
         # per core, next to the only genuine deal.II figures there are (README.md:127, 12 Broadwell cores,
         # AVX2-vectorised over cells with even-odd sweeps; the oracle batches 8 cells per SIMD lane group with dense sweeps)
         "matvec_dofs_per_s_per_core": n / t_mv / max(1, threads),
+        "matvec_dofs_per_s_one_core_alone": n / t_one,
         "reference_readme_12c_broadwell": {"matvec_dofs_per_s": 8.74e8, "matvec_dofs_per_s_per_core": 8.74e8 / 12,
                                            "vcycle_mixed_precision_dofs_per_s": 9.7e7},
     }

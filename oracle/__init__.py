@@ -100,6 +100,8 @@ def lib():
     L.orc_time_vcycle.restype = C.c_double
     L.orc_time_vcycle.argtypes = [vp, C.c_int]
     L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_set_num_threads.restype = None
     L.orc_create_from_mesh.restype = vp
     L.orc_create_from_mesh.argtypes = [C.c_int, C.c_int, C.POINTER(MeshLevel), C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L
@@ -359,3 +361,7 @@ class Oracle:
 
     def num_threads(self):
         return self.L.orc_num_threads()
+
+    def set_num_threads(self, n):
+        """OpenMP threads of the following calls (n <= 0: the default)"""
+        self.L.orc_set_num_threads(int(n))

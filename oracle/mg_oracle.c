@@ -1608,6 +1608,16 @@ double orc_time_vcycle(orc_problem *P, int n)
   return t;
 }
 
+/* threads of the following calls (bench.py's one-core sample) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : effective_threads());
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -147,6 +147,7 @@ const double *orc_solution(orc_problem *P, int level);
 double orc_time_vmult(orc_problem *P, int level, int n);
 double orc_time_vcycle(orc_problem *P, int n);
 int orc_num_threads(void);
+void orc_set_num_threads(int n); /* n <= 0: back to the default (visible cores, cgroup quota) */
 
 #ifdef __cplusplus
 }
