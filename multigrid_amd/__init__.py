@@ -733,10 +733,11 @@ class MultigridSolver:
 
     def _agglomerate(self, degree, n_cycles, vnumber):
         """Coarse levels of a decomposed hierarchy on every rank as a whole (mgx_solver_set_agglomeration):
-        the levels whose global size is at most MGX_AGGLOMERATE_MAX_DOFS (default 600000: the ones a
-        single GPU replays as one HIP graph) -- there a level's work is a few microseconds and
-        every exchange a latency."""
-        cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "600000"))
+        the levels whose global size is at most MGX_AGGLOMERATE_MAX_DOFS (default 3 000 000) -- there a level's
+        work is microseconds and every exchange a latency.  (Up to 600 000 DoFs the copy is replayed as one HIP graph;
+        the 2.1 M-DoF level of the 128^3 problem on top of it costs every rank 0.24 ms and a 17 MB allreduce instead
+        of 0.45 ms of latency-bound exchanges: emulated rank at N = 8 2.71 -> 2.50 ms.)"""
+        cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "3000000"))
         level = -1
         for l in range(self.max_level):
             g = np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * cube.degree + 1
