@@ -737,7 +737,9 @@ class MultigridSolver:
         work is microseconds and every exchange a latency.  (Up to 600 000 DoFs the copy is replayed as one HIP graph;
         the 2.1 M-DoF level of the 128^3 problem on top of it costs every rank 0.24 ms and a 17 MB allreduce instead
         of 0.45 ms of latency-bound exchanges: emulated rank at N = 8 2.71 -> 2.50 ms.)"""
-        cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "3000000"))
+        # (with the callback transport the allreduce is staged through the host: the seam stays where the vector is small)
+        native = bool(getattr(self.comm, "native_ready", False)) or not hasattr(self.comm, "native_ready")
+        cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "3000000" if native else "600000"))
         level = -1
         for l in range(self.max_level):
             g = np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * cube.degree + 1
