@@ -91,7 +91,8 @@ int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
  * The multiplicities of the transfer are not powers of two where three blocks meet: levels carry no
  * weight_shift, mgx_transfer_create derives owner weights. */
 int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *cube);
-/* The same distributed over n_ranks ranks (n_ranks divides n_coarse): rank r owns the coarse cells
+/* The same distributed over n_ranks <= n_coarse ranks (equal shares where n_ranks divides n_coarse, else one cell more
+ * on some ranks -- 12 cells on 8 ranks: 1, 2, 1, 2, ...): rank r owns the coarse cells
  * [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks) with everything refined from them; DoFs on faces between
  * coarse cells of different ranks are duplicated and exchanged like the interface DoFs of the block-split cube
  * (mgx_cube_exchange_desc). */

@@ -385,7 +385,8 @@ class Cube:
         plain first-touch order), MGX_CUBE_NUMBERING_* in mgx_cube.h.
         shell=6 | 12: the mesh of poisson_shell instead, GridGenerator::hyper_shell(0, 0.5, 1.0, shell) refined
         n_refine times (mgx_cube_create_shell); problem "shell" (default there) or "cube"; procs=(n,1,1), rank=r:
-        the coarse cells distributed over n ranks (n divides `shell`)."""
+        the coarse cells distributed over n <= `shell` ranks (contiguous shares, one cell more on some ranks where n
+        does not divide them: 12 cells on 8 ranks)."""
         self.lib = _lib.load()
         h = C.c_void_p()
         num = self.NUMBERING[numbering]

@@ -1009,8 +1009,10 @@ int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int prob
     return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: unknown problem");
   if ((uint64_t)n_coarse << (3 * n_refine) >= 0x10000000ull)
     return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_create_shell: too many cells");
-  if (n_ranks < 1 || n_ranks > 12 || n_coarse % n_ranks != 0 || rank < 0 || rank >= n_ranks)
-    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: the number of ranks must divide the coarse cells");
+  // rank r holds the coarse cells [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks): equal shares where n_ranks divides
+  // them, otherwise one more on some ranks (12 cells on 8 ranks: 1, 2, 1, 2, ...)
+  if (n_ranks < 1 || n_ranks > n_coarse || rank < 0 || rank >= n_ranks)
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: at most one rank per coarse cell");
   omp_set_num_threads(effective_threads());
   auto C        = std::make_unique<mgx_cube_s>();
   C->p          = degree;
@@ -1022,7 +1024,8 @@ int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int prob
   C->shell      = shell_blocks(n_coarse);
   C->rank       = rank;
   C->size       = n_ranks;
-  C->shell_block0 = rank * (n_coarse / n_ranks);
+  C->shell_block0 = (rank * n_coarse) / n_ranks;
+  const int my_blocks = ((rank + 1) * n_coarse) / n_ranks - C->shell_block0;
   make_basis(C->basis, degree);
   C->levels.resize(n_refine + 1);
   for (int l = 0; l <= n_refine; ++l)
@@ -1044,7 +1047,7 @@ int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int prob
           C->shell_block0 = b0;
           if (!ok)
             return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
-          localise_shell_level(*C, whole, C->levels[l], n_coarse / n_ranks);
+          localise_shell_level(*C, whole, C->levels[l], my_blocks);
         }
       build_geometry(*C, C->levels[l]);
       build_bc(*C, C->levels[l]);

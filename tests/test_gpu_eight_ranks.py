@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dg_dist_worker  # noqa: E402
 import dg_mg_dist_worker  # noqa: E402
 import dist_worker  # noqa: E402
+import shell_dist_worker  # noqa: E402
 from thread_ranks import run_ranks  # noqa: E402
 
 
@@ -83,3 +84,11 @@ def test_eight_ranks_benchmark_problem_64_cubed():
     res = benchmark_problem(6)
     assert all(r[0] == 8 and r[2] for r in res), res
     assert all(abs(r[1] / 1.327e-8 - 1) < 5e-3 for r in res), res
+
+
+def test_eight_ranks_hyper_shell():
+    """BASELINE config 4 on eight ranks: the 12 coarse cells of hyper_shell(12) dealt out 1, 2, 1, 2, ... (the run of
+    poisson_shell on 8 GPUs), variable coefficient with the 1e6 contrast, against the single-domain oracle"""
+    lines = []
+    run_ranks(8, lambda dist, r: shell_dist_worker.run("gpu", 12, 3, 1, "shell", dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
+    assert len(lines) == 8 and all("gpu ok" in s for s in lines), lines
