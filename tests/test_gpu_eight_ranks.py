@@ -25,7 +25,7 @@ def eight(p, nr, flags):
     return lines
 
 
-@pytest.mark.parametrize("p,nr", [(2, 3), (4, 2)])
+@pytest.mark.parametrize("p,nr", [(2, 3), (4, 2), (8, 2)])   # (8, 2): BASELINE config 3 on 8 ranks
 def test_eight_ranks_block_split_cube(p, nr):
     eight(p, nr, ("strong",))
 
