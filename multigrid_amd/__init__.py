@@ -393,6 +393,7 @@ class Cube:
         self.shell = shell
         if shell is not None:
             self.box_desc = None
+            self.shell_desc = dict(shell=int(shell), problem=problem)
             n_ranks = int(procs[0]) * int(procs[1]) * int(procs[2])
             check(self.lib.mgx_cube_create_shell_ranks(degree, int(shell), n_refine, self.PROBLEM[problem], n_ranks, rank,
                                                        C.byref(h)))
@@ -710,7 +711,8 @@ class MultigridSolver:
         self.max_level = self.n_levels - 1
         self.h = C.c_void_p(self.s.solver)
         self.coarse = None
-        if cube.size > 1 and cube.box_desc is not None and agglomerate and os.environ.get("MGX_AGGLOMERATE", "1") != "0":
+        if cube.size > 1 and (cube.box_desc is not None or cube.shell is not None) and agglomerate and \
+                os.environ.get("MGX_AGGLOMERATE", "1") != "0":
             # the set-up is local; whether to use it is decided by all ranks together (a rank that
             # could not build its copy must not leave the others waiting in the allreduce)
             prepared = None
@@ -743,21 +745,28 @@ class MultigridSolver:
         cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "3000000" if native else "600000"))
         level = -1
         for l in range(self.max_level):
-            g = np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * cube.degree + 1
-            if int(g.prod()) <= limit:
+            if cube.shell is not None:   # (cells x p^3 + the DoFs of two spherical boundary layers: an upper bound will do)
+                size = cube.shell_desc["shell"] * 8 ** l * (cube.degree + 1) ** 3
+            else:
+                size = int((np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * cube.degree + 1).prod())
+            if size <= limit:
                 level = l
         if level < 0:
             return None
-        d = cube.box_desc
-        whole = Cube(cube.degree, n_refine=level, box=d["box"], procs=(1, 1, 1), rank=0, numbering=d["numbering"],
-                     origin=d["origin"], h0=d["h0"], geometry=d["geometry"], problem=d["problem"])
+        if cube.shell is not None:
+            whole = Cube(cube.degree, n_refine=level, shell=cube.shell_desc["shell"], problem=cube.shell_desc["problem"])
+        else:
+            d = cube.box_desc
+            whole = Cube(cube.degree, n_refine=level, box=d["box"], procs=(1, 1, 1), rank=0, numbering=d["numbering"],
+                         origin=d["origin"], h0=d["h0"], geometry=d["geometry"], problem=d["problem"])
         ctx2 = Context(self.ctx.device)
         coarse = MultigridSolver(ctx2, whole, degree, degree, n_cycles, vnumber, device_rhs=True)  # its rhs is never used
+        # local DoF -> DoF of the whole level through the run-independent id of a DoF
         gg = whole.dof_grid(level)
-        pos = np.full(int(gg.max()) + 1, INVALID_INDEX, dtype=np.uint32)
-        pos[gg] = np.arange(gg.size, dtype=np.uint32)
-        mine = np.ascontiguousarray(pos[cube.dof_grid(level)])
-        assert (mine != INVALID_INDEX).all()
+        order = np.argsort(gg)
+        at = np.searchsorted(gg[order], cube.dof_grid(level))
+        assert np.array_equal(gg[order][at], cube.dof_grid(level))
+        mine = np.ascontiguousarray(order[at].astype(np.uint32))
         owned = np.ones(mine.size, dtype=np.uint8)
         owned[cube.not_owned(level)] = 0
         return coarse, level, mine, owned

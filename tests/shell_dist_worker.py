@@ -129,7 +129,8 @@ def run(mode, n_coarse, p, nr, problem, dist, rank, world, say=print):
         its, _ = assert_same_cg(solver, View(orc))
         l2 = solver.compute_l2_error()
         assert abs(l2 - orc.l2_error()) < 2e-6 * l2, (l2, orc.l2_error())
-        say("rank %d gpu ok: FMG rate %.4f, cg its %d, L2 %.6e" % (rank, rate, its, l2), flush=True)
+        agg = (", coarse levels <= %d agglomerated" % solver.coarse_level) if solver.coarse is not None else ""
+        say("rank %d gpu ok: FMG rate %.4f, cg its %d, L2 %.6e%s" % (rank, rate, its, l2, agg), flush=True)
         solver.close()
         ctx.close()
 

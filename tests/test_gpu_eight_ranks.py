@@ -91,4 +91,4 @@ def test_eight_ranks_hyper_shell():
     poisson_shell on 8 GPUs), variable coefficient with the 1e6 contrast, against the single-domain oracle"""
     lines = []
     run_ranks(8, lambda dist, r: shell_dist_worker.run("gpu", 12, 3, 1, "shell", dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
-    assert len(lines) == 8 and all("gpu ok" in s for s in lines), lines
+    assert len(lines) == 8 and all("gpu ok" in s and "agglomerated" in s for s in lines), lines
