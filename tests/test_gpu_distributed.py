@@ -83,6 +83,32 @@ def test_right_hand_side_assembled_on_the_device(monkeypatch, world, p, nr, extr
     assert all("gpu ok" in o for o in outs), outs
 
 
+def test_poisson_shell_harness_on_ranks():
+    """tools/poisson_shell.py --gpus N (poisson_shell/program.cc on several ranks): the convergence table of the program --
+    FMG reduction, L2 errors, PCG iterations and reduction -- is the single-rank one"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGX_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def table(extra):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "poisson_shell.py"), "2", "40000", "--cycles", "2:6"] + extra,
+                             cwd=root, env=env, capture_output=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = out.stdout.decode().strip().splitlines()
+        rows = [ln.split() for ln in lines[[i for i, ln in enumerate(lines) if ln.strip().startswith("cells")][-1] + 1:]]
+        return [(int(r[0]), int(r[1]), float(r[4]), float(r[5]), float(r[7]), int(r[9]), float(r[10])) for r in rows]
+
+    one, three = table([]), table(["--gpus", "3"])
+    assert len(one) == len(three) == 4
+    for a, b in zip(one, three):
+        assert a[:2] == b[:2] and a[5] == b[5]
+        assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(a[2:5] + a[6:], b[2:5] + b[6:])), (a, b)
+
+
 def test_bench_launches_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` starts two ranks itself; here over gloo, both on the one GPU"""
     import json

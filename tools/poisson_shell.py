@@ -4,7 +4,11 @@
 0.1 e), :157-169; solution sin(2 pi (x + y)), :97-137) on GridGenerator::hyper_shell(0, 0.5, 1.0, 6 | 12) with
 curved cells, solved by the mixed-precision multigrid solver (V-cycle in float, :67-68).
 
-    poisson_shell.py degree maxsize [n_mg_cycles n_pre_smooth n_post_smooth] [--vcycle f32|f64] [--cycles A:B]
+    poisson_shell.py degree maxsize [n_mg_cycles n_pre_smooth n_post_smooth] [--vcycle f32|f64] [--cycles A:B] [--gpus N]
+
+--gpus N: N ranks, one per GPU (started here, or already there under torch.distributed.run), the coarse cells of the
+shell dealt out to them (contiguous shares; 8 ranks hold 1, 2, 1, 2, ... of the 12-cell shell and at most one cell
+each of the 6-cell one -- cycles whose shell has fewer cells than ranks are skipped).
 
 as `./program degree maxsize n_mg_cycles n_pre_smooth n_post_smooth` (:520-546).  run() (:413-446): cycle c uses
 the 6-cell shell for even c and the 12-cell one for odd c, refined c / 2 times, until the number of DoFs
@@ -29,7 +33,46 @@ def main():
     ap.add_argument("n_post_smooth", type=int, nargs="?", default=3)
     ap.add_argument("--vcycle", choices=["f32", "f64"], default="f32", help="vcycle_number (program.cc:67: float)")
     ap.add_argument("--cycles", default="0:35", help="first:last cycle of run() (default: all, as the program)")
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        codes = mg.spawn_ranks(__file__, sys.argv[1:], a.gpus, one_gpu=os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl")
+        if any(codes):
+            raise SystemExit("poisson_shell.py: rank exit codes %s" % codes)
+        return
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    dist = comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if os.environ.get("MGX_BENCH_BACKEND", "nccl") == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            dist.init_process_group(os.environ["MGX_BENCH_BACKEND"])
+    out = print
+    if rank != 0:
+        def out(*x, **k):
+            return None
+    _main(a, out, dist, rank, world, local_rank)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _main(a, print, dist, rank, world, local_rank):  # noqa: A002 (rank 0 prints)
+    def slowest(v):
+        if dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     print("Settings of parameters: ")
     print("Polynomial degree:              %d" % a.degree)
     print("Maximum size:                   %d" % a.maxsize)
@@ -38,7 +81,8 @@ def main():
     print("Number of post-smoother iters:  %d" % a.n_post_smooth)
     print()
     print("Testing FE_Q<3>(%d)" % a.degree)
-    ctx = mg.Context(0)
+    ctx = mg.Context(local_rank)
+    comm = mg.Communicator(ctx, dist) if dist is not None else None
     vnum = mg.F32 if a.vcycle == "f32" else mg.F64
     c0, c1 = (int(v) for v in a.cycles.split(":"))
     rows = []
@@ -52,10 +96,14 @@ def main():
             print("Max size reached, terminating.")
             print()
             break
+        if world > n_coarse:
+            print("(fewer coarse cells than ranks: cycle skipped)")
+            print()
+            continue
         t0 = time.time()
-        cube = mg.Cube(a.degree, n_refine=n_refine, shell=n_coarse, problem="shell")
-        assert cube.n_dofs(cube.max_level) == n_dofs
-        solver = mg.MultigridSolver(ctx, cube, a.n_pre_smooth, a.n_post_smooth, a.n_mg_cycles, vnum)
+        cube = mg.Cube(a.degree, n_refine=n_refine, shell=n_coarse, problem="shell", procs=(world, 1, 1), rank=rank)
+        assert world > 1 or cube.n_dofs(cube.max_level) == n_dofs
+        solver = mg.MultigridSolver(ctx, cube, a.n_pre_smooth, a.n_post_smooth, a.n_mg_cycles, vnum, comm=comm)
         print("Total setup time:      %gs" % (time.time() - t0))
         best_time, tot_time = 1e10, 0.
         for _ in range(5):                                                        # :334-343
@@ -63,7 +111,7 @@ def main():
             t = time.perf_counter()
             solver.solve(False)
             ctx.sync()
-            dt = time.perf_counter() - t
+            dt = slowest(time.perf_counter() - t)
             best_time, tot_time = min(best_time, dt), tot_time + dt
             print("Time solve   (CPU/wall)    %gs/%gs" % (dt, dt))
         reduction, _ = solver.solve(True)                                         # :344
@@ -73,7 +121,7 @@ def main():
         t = time.perf_counter()
         cg_its, cg_red = solver.solve_cg()                                        # :354
         ctx.sync()
-        time_cg = time.perf_counter() - t
+        time_cg = slowest(time.perf_counter() - t)
         l2_error_cg = solver.compute_l2_error()
         n_mv = 200 if n_dofs < 10000000 else 50
         best = {}
@@ -85,14 +133,14 @@ def main():
                 for _ in range(n_mv):
                     fn()
                 ctx.sync()
-                dt = (time.perf_counter() - t) / n_mv
+                dt = slowest((time.perf_counter() - t) / n_mv)
                 best[name] = min(best[name], dt)
                 if name == "mv":
                     print("matvec time dp %g [p0] %g %g [p0] DoFs/s: %g" % (dt, dt, dt, n_dofs / dt))
         print("Best timings for ndof = %d   mv %g    mv smooth %g   mg %g" % (n_dofs, best["mv"], best["mvs"], best_time))
         print("L2 error with ndof = %d  %g  with CG %g" % (n_dofs, l2_error, l2_error_cg))
         print()
-        rows.append((cube.n_cells(cube.max_level), n_dofs, best["mv"], best["mvs"], reduction, l2_error, best_time, l2_error_cg,
+        rows.append((n_coarse * 8 ** n_refine, n_dofs, best["mv"], best["mvs"], reduction, l2_error, best_time, l2_error_cg,
                      time_cg, cg_its, cg_red))
         solver.close()
         cube.close()
