@@ -2210,6 +2210,8 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
   hipStream_t    s  = op->ctx->stream;
   // the interface DoFs' partial sums of A cur sit in sm->tmp: complete them and apply the update there
   const bool fr = op->d.bricks.fr.available() && mode >= 2 && mode <= 6;
+  // (reduced-colour schedule on one rank: the update of the constrained rows rides on the finish kernel)
+  const bool folded = fr && !op->plan;
   MGX_TRY(brick_loop_with_exchange(
     op, mode, sm->tmp,
     [&](hipStream_t st, int g0, int g1) {
@@ -2226,10 +2228,13 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
     },
     fr,
     [&](hipStream_t st, uint32_t first, uint32_t count) {
-      launch_surf_finish(st, op->d, mode, first, count, sm->tmp, cur, out, b, op->d.inv_diag, old, f1, f2, f0);
+      // one rank: one call for the whole surface list, which takes the constrained rows along
+      launch_surf_finish(st, op->d, mode, first, count, sm->tmp, cur, out, b, op->d.inv_diag, old, f1, f2, f0,
+                         folded ? op->d.constrained : nullptr, folded ? op->d.n_constrained : 0u);
     }));
-  launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
-                          op->d.n_constrained, nullptr, old, f0);
+  if (!folded)
+    launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
+                            op->d.n_constrained, nullptr, old, f0);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }

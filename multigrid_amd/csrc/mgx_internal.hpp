@@ -263,9 +263,10 @@ namespace mgx
   // free_schedule (modes 0..6, op.bricks.fr.available()): the launch groups are those of the reduced-colour
   // schedule; the caller completes the private DoFs with launch_surf_finish: DoFs [first, first + count)
   // of op.bricks.fr.surf_dof; those below n_surf_shared: carrier[d] = sum only
+  // constrained / n_constrained (Chebyshev forms): rows where A x = x, updated by the same launch
   void launch_surf_finish(hipStream_t s, const OperatorData &op, int mode, uint32_t first, uint32_t count, void *carrier,
                           const void *x, void *out, const void *a, const void *dinv, const void *old, double f1, double f2,
-                          double f0);
+                          double f0, const uint32_t *constrained = nullptr, uint32_t n_constrained = 0);
   // macro-element form of the separable brick loop (mgx_macro.hip), one translation unit per number
   // type; false: mode / degree not covered (the caller falls back to the cell-by-cell form)
   bool launch_macro_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,

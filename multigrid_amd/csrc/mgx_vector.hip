@@ -224,18 +224,28 @@ namespace mgx
     k_surf_finish(int mode, const T *__restrict__ priv, const uint32_t *__restrict__ sdof,
                   const uint32_t *__restrict__ sstart, const uint32_t *__restrict__ spos, uint32_t first, uint32_t count,
                   uint32_t n_carrier_only, T *carrier, const T *x, T *out, const T *__restrict__ a,
-                  const T *__restrict__ dinv, const T *old, T f1, T f2, T f0)
+                  const T *__restrict__ dinv, const T *old, T f1, T f2, T f0, const uint32_t *__restrict__ clist, uint32_t n_c)
   {
-    GRID_STRIDE(i0, count)
+    // entries count ... count + n_c (Chebyshev forms on one rank): the constrained rows clist, where A x = x
+    // (laplace_operator.h:736-737) -- the list kernel they would otherwise get is folded in here
+    GRID_STRIDE(i0, count + n_c)
     {
-      const uint32_t i = first + (uint32_t)i0, d = sdof[i];
-      T              sum = T(0);
-      for (uint32_t k = sstart[i]; k < sstart[i + 1]; ++k)
-        sum += priv[spos[k]];
-      if (i < n_carrier_only)
+      const bool ident = i0 >= count;
+      uint32_t   d;
+      T          sum = T(0);
+      if (ident)
+        d = clist[i0 - count];
+      else
         {
-          carrier[d] = sum;
-          continue;
+          const uint32_t i = first + (uint32_t)i0;
+          d                = sdof[i];
+          for (uint32_t k = sstart[i]; k < sstart[i + 1]; ++k)
+            sum += priv[spos[k]];
+          if (i < n_carrier_only)
+            {
+              carrier[d] = sum;
+              continue;
+            }
         }
       if (mode == 0)
         out[d] = sum;
@@ -245,7 +255,7 @@ namespace mgx
         {
           const T bv = dinv[d], av = a[d];
           const T xi = mode == 5 ? f0 * bv * av : x[d];
-          T       xn = xi + f2 * bv * (av - sum);
+          T       xn = xi + f2 * bv * (av - (ident ? xi : sum));
           if (mode == 2)
             xn += f1 * (xi - old[d]);
           else if (mode == 6)
@@ -646,19 +656,21 @@ namespace mgx
 
   void launch_surf_finish(hipStream_t s, const OperatorData &op, int mode, uint32_t first, uint32_t count, void *carrier,
                           const void *x, void *out, const void *a, const void *dinv, const void *old, double f1, double f2,
-                          double f0)
+                          double f0, const uint32_t *constrained, uint32_t n_constrained)
   {
-    if (count == 0)
+    if (mode < 2)
+      n_constrained = 0; // the identity rows of the plain and residual forms are the caller's
+    if (count + n_constrained == 0)
       return;
     const FreeSchedule &bd = op.bricks.fr;
     if (!old)
       old = out;
     if (!x)
       x = a; // mode 5 never reads it
-    BY_NUMBER(op.number, hipLaunchKernelGGL((k_surf_finish<T>), stream_grid(count), dim3(256), 0, s, mode, (const T *)bd.priv,
-                                            bd.surf_dof, bd.surf_start, bd.surf_pos, first, count, bd.n_surf_shared,
-                                            (T *)carrier, (const T *)x, (T *)out, (const T *)a, (const T *)dinv,
-                                            (const T *)old, (T)f1, (T)f2, (T)f0));
+    BY_NUMBER(op.number, hipLaunchKernelGGL((k_surf_finish<T>), stream_grid((size_t)count + n_constrained), dim3(256), 0, s, mode,
+                                            (const T *)bd.priv, bd.surf_dof, bd.surf_start, bd.surf_pos, first, count,
+                                            bd.n_surf_shared, (T *)carrier, (const T *)x, (T *)out, (const T *)a,
+                                            (const T *)dinv, (const T *)old, (T)f1, (T)f2, (T)f0, constrained, n_constrained));
   }
 
   // dst[i] = 0 for i < n_head, dst[i] = src[i] behind: the zeroing before a cell loop that scatters
