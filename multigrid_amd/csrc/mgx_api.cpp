@@ -429,7 +429,10 @@ namespace
 
   // Vector::compress(add) for duplicated interface DoFs: every rank ends up with the sum of all
   // sharers' entries, added in ascending rank order on every rank (bitwise identical copies).
-  int exchange_add(mgx_operator_t op, void *vec, hipStream_t on = nullptr)
+  // post (fused exchange plans only; returns with *post_done = true): the Chebyshev update of the interface DoFs and
+  // of the constrained rows inside the unpack launch
+  int exchange_add(mgx_operator_t op, void *vec, hipStream_t on = nullptr, const ChebList *post = nullptr,
+                   bool *post_done = nullptr)
   {
     ExchangePlan *P = op->plan.get();
     if (!P)
@@ -475,7 +478,13 @@ namespace
                                P->count.data(), P->send.data(), P->recv.data()) != 0)
           return fail(MGX_ERR_HIP, "exchange callback failed");
       }
-    if (P->fused)
+    if (P->fused && post && post_done)
+      {
+        launch_unpack_ordered_cheb(s, num, P->recv.data(), (int)P->rank.size(), vec, P->shared_dev, P->csr_start_dev,
+                                   P->csr_k_dev, P->csr_pos_dev, P->n_shared, *post);
+        *post_done = true;
+      }
+    else if (P->fused)
       launch_unpack_ordered(s, num, P->recv.data(), (int)P->rank.size(), vec, P->shared_dev, P->csr_start_dev,
                             P->csr_k_dev, P->csr_pos_dev, P->n_shared);
     else
@@ -554,9 +563,10 @@ namespace
   // Finish(stream, first, count) (colour-free schedule only, `free_schedule`): completes the DoFs
   // [first, first + count) of the operator's list of brick-surface DoFs (launch_surf_finish); the
   // first n_surf_shared of them are the rank-interface DoFs, whose sums go to the carrier.
+  // post / post_done: the fix as the post-operation of the unpack launch where the exchange plan allows (exchange_add)
   template <typename Launch, typename Fix, typename Finish>
   int brick_loop_with_exchange(mgx_operator_t op, int form, void *carrier, Launch launch, Fix fix, bool free_schedule,
-                               Finish finish)
+                               Finish finish, const ChebList *post = nullptr, bool *post_done = nullptr)
   {
     mgx_context_t    ctx = op->ctx;
     hipStream_t      s   = ctx->stream;
@@ -573,8 +583,12 @@ namespace
         }
         if (op->plan)
           {
-            MGX_TRY(exchange_add(op, carrier));
-            fix(s);
+            bool done = false;
+            MGX_TRY(exchange_add(op, carrier, nullptr, post, post ? &done : nullptr));
+            if (!done)
+              fix(s);
+            if (post_done)
+              *post_done = done;
           }
         return MGX_OK;
       }
@@ -589,8 +603,14 @@ namespace
       if (free_schedule)
         finish(s, n_sh, n_all - n_sh);
     }
-    MGX_TRY(exchange_add(op, carrier, ctx->side));
-    fix(ctx->side);
+    {
+      bool done = false;
+      MGX_TRY(exchange_add(op, carrier, ctx->side, post, post ? &done : nullptr));
+      if (!done)
+        fix(ctx->side);
+      if (post_done)
+        *post_done = done;
+    }
     MGX_HIP(hipEventRecord(ctx->ev_side, ctx->side));
     MGX_HIP(hipStreamWaitEvent(s, ctx->ev_side, 0));
     return MGX_OK;
@@ -2212,6 +2232,9 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
   const bool fr = op->d.bricks.fr.available() && mode >= 2 && mode <= 6;
   // (reduced-colour schedule on one rank: the update of the constrained rows rides on the finish kernel)
   const bool folded = fr && !op->plan;
+  // decomposed: interface DoFs and constrained rows are updated by the unpack launch of the exchange
+  const ChebList post{mode, cur, b, op->d.inv_diag, old, out, f1, f2, f0, op->d.constrained, op->d.n_constrained};
+  bool           post_done = false;
   MGX_TRY(brick_loop_with_exchange(
     op, mode, sm->tmp,
     [&](hipStream_t st, int g0, int g1) {
@@ -2231,8 +2254,9 @@ static int cheb_fused_iteration(mgx_smoother_t sm, int mode, const void *cur, co
       // one rank: one call for the whole surface list, which takes the constrained rows along
       launch_surf_finish(st, op->d, mode, first, count, sm->tmp, cur, out, b, op->d.inv_diag, old, f1, f2, f0,
                          folded ? op->d.constrained : nullptr, folded ? op->d.n_constrained : 0u);
-    }));
-  if (!folded)
+    },
+    (op->plan && mode != 9 && !op->ctx->tun.exchange_unfused) ? &post : nullptr, &post_done));
+  if (!folded && !post_done)
     launch_cheb_constrained(s, op->d.number, mode, cur, out, b, op->d.inv_diag, f1, f2, op->d.constrained,
                             op->d.n_constrained, nullptr, old, f0);
   MGX_HIP(hipGetLastError());

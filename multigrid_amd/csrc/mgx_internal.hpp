@@ -344,6 +344,20 @@ namespace mgx
   void launch_unpack_ordered(hipStream_t s, int number, void *const *recv, int n_neighbors, void *v,
                              const uint32_t *shared, const uint32_t *csr_start, const uint8_t *csr_k,
                              const uint32_t *csr_pos, uint32_t n_shared);
+  // Chebyshev post-operation of the interface DoFs folded into the ordered unpack (one launch instead of two, and the
+  // constrained rows -- A x = x -- ride along): what launch_cheb_constrained would do with ax = the completed sums
+  struct ChebList
+  {
+    int             mode;
+    const void     *x, *b, *dinv, *old;
+    void           *out;
+    double          f1, f2, f0;
+    const uint32_t *constrained;
+    uint32_t        n_constrained;
+  };
+  void launch_unpack_ordered_cheb(hipStream_t s, int number, void *const *recv, int n_neighbors, void *v,
+                                  const uint32_t *shared, const uint32_t *csr_start, const uint8_t *csr_k,
+                                  const uint32_t *csr_pos, uint32_t n_shared, const ChebList &post);
   void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count);
   void launch_list_residual(hipStream_t s, int number, void *res, const void *rhs, const uint32_t *list,
                             uint32_t count); // res[i] = rhs[i] - res[i]

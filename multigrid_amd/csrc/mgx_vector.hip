@@ -313,6 +313,42 @@ namespace mgx
     }
   }
 
+  // the same with the Chebyshev update of the fused brick forms applied to the completed sums (k_cheb_constrained
+  // with ax = v), and to the constrained rows behind them (entries n_shared ... n_shared + n_c: A x = x)
+  template <typename T>
+  __global__ void __launch_bounds__(256)
+    k_unpack_ordered_cheb(ExchangePtrs p, T *__restrict__ v, const uint32_t *__restrict__ shared,
+                          const uint32_t *__restrict__ csr_start, const uint8_t *__restrict__ csr_k,
+                          const uint32_t *__restrict__ csr_pos, uint32_t n_shared, int mode, const T *x, T *out,
+                          const T *__restrict__ b, const T *__restrict__ dinv, const T *old, T f1, T f2, T f0,
+                          const uint32_t *__restrict__ clist, uint32_t n_c)
+  {
+    GRID_STRIDE(j, n_shared + n_c)
+    {
+      const bool     ident = j >= n_shared;
+      const uint32_t dof   = ident ? clist[j - n_shared] : shared[j];
+      T              sum   = T(0);
+      if (!ident)
+        {
+          for (uint32_t c = csr_start[j]; c < csr_start[j + 1]; ++c)
+            {
+              const uint32_t k = csr_k[c];
+              sum += k == 255u ? v[dof] : ((const T *)p.buf[k])[csr_pos[c]];
+            }
+          v[dof] = sum;
+        }
+      const T xi = mode == 5 ? f0 * dinv[dof] * b[dof] : x[dof];
+      T       xn = xi + f2 * dinv[dof] * (b[dof] - (ident ? xi : sum));
+      if (mode == 2)
+        xn += f1 * (xi - old[dof]);
+      else if (mode == 6)
+        xn += f1 * (xi - f0 * dinv[dof] * b[dof]);
+      else if (mode == 4 || mode == 5)
+        xn += f1 * xi;
+      out[dof] = xn;
+    }
+  }
+
   template <typename T>
   __global__ void __launch_bounds__(256)
     k_unpack_add(T *__restrict__ v, const T *__restrict__ buf, const uint32_t *__restrict__ list, uint32_t count)
@@ -743,6 +779,22 @@ namespace mgx
       p.buf[k] = recv[k];
     BY_NUMBER(number, hipLaunchKernelGGL((k_unpack_ordered<T>), stream_grid(n_shared), dim3(256), 0, s, p, (T *)v,
                                          shared, csr_start, csr_k, csr_pos, n_shared));
+  }
+
+  void launch_unpack_ordered_cheb(hipStream_t s, int number, void *const *recv, int n_neighbors, void *v,
+                                  const uint32_t *shared, const uint32_t *csr_start, const uint8_t *csr_k,
+                                  const uint32_t *csr_pos, uint32_t n_shared, const ChebList &c)
+  {
+    if (n_shared + c.n_constrained == 0)
+      return;
+    ExchangePtrs p{};
+    for (int k = 0; k < n_neighbors; ++k)
+      p.buf[k] = recv[k];
+    const void *old = c.old ? c.old : c.out, *x = c.x ? c.x : c.b; // mode 5 never reads x
+    BY_NUMBER(number, hipLaunchKernelGGL((k_unpack_ordered_cheb<T>), stream_grid((size_t)n_shared + c.n_constrained), dim3(256), 0,
+                                         s, p, (T *)v, shared, csr_start, csr_k, csr_pos, n_shared, c.mode, (const T *)x,
+                                         (T *)c.out, (const T *)c.b, (const T *)c.dinv, (const T *)old, (T)c.f1, (T)c.f2,
+                                         (T)c.f0, c.constrained, c.n_constrained));
   }
 
   void launch_unpack_add(hipStream_t s, int number, void *v, const void *buf, const uint32_t *list, uint32_t count)
