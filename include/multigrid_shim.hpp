@@ -2,7 +2,11 @@
 // of the C ABI of mgx.h, so that driver code written against
 //     multigrid::LaplaceOperator<dim,fe_degree,number>          common/laplace_operator.h:56-164
 //     multigrid::MultigridSolver<dim,fe_degree,Number,Number2>  common/multigrid_solver.h:96-782
-// keeps its call sites (vmult, vmult_residual, compute_diagonal, solve, solve_cg, do_matvec,
+//     multigrid::LaplaceOperatorCompactCombine<dim,fe_degree,Number,type> + JacobiTransformed
+//                                                                common/laplace_operator_dg.h:350-2256
+//     multigrid::MultigridSolverDG<dim,fe_degree,Number,Number2> common/multigrid_solver_dg.h:55-747
+// keeps its call sites (vmult, vmult_residual, vmult_with_cg_update, compute_residual, evaluate_coefficient,
+// compute_diagonal, get_matrix_diagonal_inverse, solve, solve_cg, vmult_with_residual_update, do_matvec,
 // compute_l2_error, get_solution, print_wall_times ...).  Non-zero C status codes become
 // exceptions, as deal.II's AssertThrow would (SURVEY.md 8b "Errors").
 //
@@ -15,10 +19,13 @@
 
 #include "mgx.h"
 #include "mgx_cube.h"
+#include "mgx_dg.h"
 
 #include <array>
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -231,6 +238,9 @@ namespace multigrid
       check(mgx_cube_operator_desc(disc.handle(), (int)level, number_id<number>::value, &d));
       check(mgx_operator_create(ctx.handle(), &d, &h_));
       owned_ = true;
+      desc_  = d; // (the tables stay owned by the discretisation)
+      disc_  = &disc;
+      level_ = (int)level;
     }
     void attach(const Context &ctx, mgx_operator_t h)
     {
@@ -252,13 +262,70 @@ namespace multigrid
     {
       check(mgx_vmult_residual(h_, rhs.begin(), lhs.begin(), residual.begin()));
     }
+    // vmult_with_cg_update(alpha, beta, r, q, p, x) (laplace_operator.h:638-719): x += alpha p, p = beta p + q
+    // (alpha == 0: p = q), q = A p in one pass of the cell loop; returns {q.p, r.r, q.r, q.q}
+    std::array<number, 4> vmult_with_cg_update(const number alpha, const number beta, const Vector<number> &r, Vector<number> &q,
+                                               Vector<number> &p, Vector<number> &x) const
+    {
+      double sums[4];
+      check(mgx_vmult_with_cg_update(h_, (double)alpha, (double)beta, r.begin(), q.begin(), p.begin(), x.begin(), nullptr, sums));
+      return {{(number)sums[0], (number)sums[1], (number)sums[2], (number)sums[3]}};
+    }
+    // compute_residual(dst, src, rhs_function) (laplace_operator.h:804-845): dst = (f, phi) - (grad phi, K grad u_bc) with
+    // the boundary values in the constrained entries of src.  The reference evaluates a Function at the quadrature
+    // points; here the values f(x_q) JxW_q arrive as a device vector [cell][(p+1)^3] (rhs_at_quadrature_points() gives
+    // those of the discretisation's problem)
+    void compute_residual(Vector<number> &dst, Vector<number> &src, const Vector<number> &rhs_q) const
+    {
+      check(mgx_compute_residual(h_, dst.begin(), src.begin(), rhs_q.begin()));
+    }
+    Vector<number> rhs_at_quadrature_points() const
+    {
+      const std::size_t   n = (std::size_t)mgx_cube_n_cells(disc_->handle(), level_) * (fe_degree + 1) * (fe_degree + 1) * (fe_degree + 1);
+      std::vector<double> host(n);
+      check(mgx_cube_rhs_quadrature(disc_->handle(), level_, host.data()));
+      std::vector<number> cast(host.begin(), host.end());
+      Vector<number>      v(*ctx_, n);
+      v.upload(cast);
+      return v;
+    }
+    // evaluate_coefficient(coefficient_function) (laplace_operator.h:357-432): the merged coefficient det J J^-1 a J^-T
+    // per cell and quadrature point, six entries each ([cell][6][(p+1)^3], host; the reference evaluates a Function and
+    // the mapping, here the caller or the discretisation supplies the values).  An empty vector restores the constant
+    // Cartesian coefficient of the discretisation.
+    void evaluate_coefficient(const std::vector<number> &merged_coefficient)
+    {
+      if (!owned_)
+        throw MgxError(MGX_ERR_UNSUPPORTED, "evaluate_coefficient: operator is borrowed from a solver");
+      mgx_operator_desc d = desc_;
+      if (!merged_coefficient.empty())
+        {
+          if (merged_coefficient.size() != (std::size_t)d.n_cells * 6 * (fe_degree + 1) * (fe_degree + 1) * (fe_degree + 1))
+            throw MgxError(MGX_ERR_INVALID_ARGUMENT, "evaluate_coefficient: expected [cell][6][(p+1)^3] values");
+          d.coef_q = merged_coefficient.data();
+        }
+      mgx_operator_t fresh = nullptr;
+      check(mgx_operator_create(ctx_->handle(), &d, &fresh));
+      mgx_operator_destroy(h_);
+      h_ = fresh;
+    }
     void compute_diagonal() { check(mgx_compute_diagonal(h_)); }
+    // Base::get_matrix_diagonal_inverse()->get_vector() (filled by compute_diagonal, laplace_operator.h:745-800): borrowed
+    Vector<number> get_matrix_diagonal_inverse() const
+    {
+      const void *dptr = nullptr;
+      check(mgx_get_inverse_diagonal(h_, &dptr));
+      return Vector<number>(*ctx_, static_cast<number *>(const_cast<void *>(dptr)), m());
+    }
     mgx_operator_t handle() const { return h_; }
 
   private:
-    const Context *ctx_   = nullptr;
-    mgx_operator_t h_     = nullptr;
-    bool           owned_ = false;
+    const Context            *ctx_   = nullptr;
+    const CubeDiscretization *disc_  = nullptr;
+    mgx_operator_desc         desc_{};
+    int                       level_ = 0;
+    mgx_operator_t            h_     = nullptr;
+    bool                      owned_ = false;
   };
 
   // multigrid::MultigridSolver (multigrid_solver.h:96-782)
@@ -328,6 +395,27 @@ namespace multigrid
     }
     // preconditioner interface (:498-510)
     void vmult(Vector<Number2> &dst, const Vector<Number2> &src) const { check(mgx_solver_vmult(s_.solver, dst.begin(), src.begin())); }
+    // vmult_with_residual_update(residual, update, factor) (:516-619): the V-cycle as preconditioner with the residual
+    // update of the PCG step merged into its two precision casts; returns {z.residual, z.(factor update)}
+    std::array<Number2, 2> vmult_with_residual_update(Vector<Number2> &residual, Vector<Number2> &update, const Number2 factor) const
+    {
+      double out[2];
+      check(mgx_solver_vmult_with_residual_update(s_.solver, residual.begin(), update.begin(), (double)factor, out));
+      return {{(Number2)out[0], (Number2)out[1]}};
+    }
+    // the operator of a level in the V-cycle number type / in fp64 (matrix[level], matrix_dp[level]); borrowed
+    void get_operator(const unsigned int level, LaplaceOperator<dim, fe_degree, Number> &op) const
+    {
+      mgx_operator_t h = nullptr;
+      check(mgx_solver_get_operator(s_.solver, (int)level, 0, &h));
+      op.attach(ctx_, h);
+    }
+    void get_operator_dp(const unsigned int level, LaplaceOperator<dim, fe_degree, Number2> &op) const
+    {
+      mgx_operator_t h = nullptr;
+      check(mgx_solver_get_operator(s_.solver, (int)level, 1, &h));
+      op.attach(ctx_, h);
+    }
     void do_matvec() { check(mgx_solver_do_matvec(s_.solver)); }                   // :624-628
     void do_matvec_smoother() { check(mgx_solver_do_matvec_smoother(s_.solver)); } // :633-637
     // L2 errors {start, end} per level of the last solve(true) (:420-424, 468-472)
@@ -373,5 +461,168 @@ namespace multigrid
     const CubeDiscretization &disc_;
     mgx_cube_solver           s_{};
     int                       maxlevel_ = 0;
+  };
+  // multigrid::LaplaceOperatorCompactCombine<dim,fe_degree,Number,type> (laplace_operator_dg.h:350-2025) on an affine mesh:
+  // type 0 FE_DGQHermite, 1 FE_DGQ on Gauss-Lobatto points, 2 FE_DGQ on Gauss points.  The reference's reinit takes a
+  // MatrixFree; here the mesh arrives as the neighbour table of its cells and the one cell Jacobian (the reference asserts
+  // a single Jacobian as well, :749-750).
+  template <int dim, int fe_degree, typename Number, int type = 0>
+  class LaplaceOperatorCompactCombine
+  {
+    static_assert(dim == 3, "the MI355X path implements dim = 3");
+    static_assert(type >= 0 && type <= 2, "Only types=0,1,2 implemented");
+
+  public:
+    typedef Number value_type;
+    LaplaceOperatorCompactCombine() = default;
+    ~LaplaceOperatorCompactCombine() { clear(); }
+    LaplaceOperatorCompactCombine(const LaplaceOperatorCompactCombine &) = delete;
+    LaplaceOperatorCompactCombine &operator=(const LaplaceOperatorCompactCombine &) = delete;
+    // neighbours: [n_cells][6] cell behind face 2d + s or MGX_DG_BOUNDARY; jacobian: dx/dxi, row-major
+    void reinit(const Context &ctx, const std::vector<std::int32_t> &neighbours, const double (&jacobian)[9])
+    {
+      clear();
+      ctx_ = &ctx;
+      mgx_dg_operator_desc d{};
+      d.degree     = fe_degree;
+      d.basis      = type;
+      d.number     = number_id<Number>::value;
+      d.n_cells    = (std::uint32_t)(neighbours.size() / 6);
+      d.neighbours = neighbours.data();
+      for (int i = 0; i < 9; ++i)
+        d.jacobian[i] = jacobian[i];
+      check(mgx_dg_operator_create(ctx.handle(), &d, &h_));
+    }
+    // the Cartesian mesh of a cube discretisation: the cells of its finest level in the provider's order, all outer
+    // faces Dirichlet
+    void reinit(const Context &ctx, const CubeDiscretization &disc)
+    {
+      const int            l  = disc.n_levels() - 1;
+      const std::uint32_t  nc = mgx_cube_n_cells(disc.handle(), l), N = mgx_cube_cells_per_dim(disc.handle(), l);
+      const std::uint32_t *xyz = mgx_cube_cell_coords(disc.handle(), l);
+      std::vector<std::int32_t> at((std::size_t)N * N * N, MGX_DG_BOUNDARY), nb((std::size_t)nc * 6);
+      for (std::uint32_t c = 0; c < nc; ++c)
+        at[((std::size_t)xyz[3 * c + 2] * N + xyz[3 * c + 1]) * N + xyz[3 * c]] = (std::int32_t)c;
+      for (std::uint32_t c = 0; c < nc; ++c)
+        for (int d = 0; d < 3; ++d)
+          for (int s = 0; s < 2; ++s)
+            {
+              std::int64_t p[3] = {xyz[3 * c], xyz[3 * c + 1], xyz[3 * c + 2]};
+              p[d] += s ? 1 : -1;
+              nb[6 * (std::size_t)c + 2 * d + s] =
+                (p[d] < 0 || p[d] >= (std::int64_t)N) ? MGX_DG_BOUNDARY : at[((std::size_t)p[2] * N + p[1]) * N + p[0]];
+            }
+      const double h      = mgx_cube_cell_size(disc.handle(), l);
+      const double jac[9] = {h, 0, 0, 0, h, 0, 0, 0, h};
+      reinit(ctx, nb, jac);
+    }
+    void clear()
+    {
+      if (h_)
+        mgx_dg_operator_destroy(h_);
+      h_ = nullptr;
+    }
+    std::size_t m() const { return (std::size_t)mgx_dg_operator_n_dofs(h_); }
+    void        initialize_dof_vector(Vector<Number> &v) const { v.reinit(*ctx_, (std::size_t)mgx_dg_operator_vector_size(h_)); }
+    double      get_penalty(const unsigned int /*cell*/, const unsigned int face) const
+    {
+      double pen[3];
+      check(mgx_dg_operator_info(h_, nullptr, pen, nullptr));
+      return pen[face / 2];
+    }
+    void vmult(Vector<Number> &dst, const Vector<Number> &src) const { check(mgx_dg_vmult(h_, dst.begin(), src.begin())); }
+    void vmult_residual(const Vector<Number> &rhs, const Vector<Number> &lhs, Vector<Number> &residual) const
+    {
+      check(mgx_dg_vmult_residual(h_, residual.begin(), rhs.begin(), lhs.begin()));
+    }
+    // :863-908
+    std::array<Number, 4> vmult_with_cg_update(const Number alpha, const Number beta, const Vector<Number> &r, Vector<Number> &q,
+                                               Vector<Number> &p, Vector<Number> &x) const
+    {
+      double sums[4];
+      check(mgx_dg_vmult_with_cg_update(h_, (double)alpha, (double)beta, r.begin(), q.begin(), p.begin(), x.begin(), sums));
+      return {{(Number)sums[0], (Number)sums[1], (Number)sums[2], (Number)sums[3]}};
+    }
+    // :910-955; the two vectors trade their storage for iteration_index >= 1, as the reference's swap does (:931)
+    void vmult_with_chebyshev_update(const Vector<Number> &rhs, const unsigned int iteration_index, const Number factor1,
+                                     const Number factor2, Vector<Number> &solution, Vector<Number> &solution_old) const
+    {
+      check(mgx_dg_vmult_with_chebyshev_update(h_, rhs.begin(), iteration_index, (double)factor1, (double)factor2,
+                                               solution.begin(), solution_old.begin()));
+      if (iteration_index > 0)
+        solution.swap(solution_old);
+    }
+    mgx_dg_operator_t handle() const { return h_; }
+    const Context    &context() const { return *ctx_; }
+
+  private:
+    const Context    *ctx_ = nullptr;
+    mgx_dg_operator_t h_   = nullptr;
+  };
+
+  // multigrid::JacobiTransformed (laplace_operator_dg.h:2028-2256): block Jacobi in the eigenvector basis of the cell
+  template <int dim, int fe_degree, typename Number, int type = 0>
+  class JacobiTransformed
+  {
+  public:
+    explicit JacobiTransformed(const LaplaceOperatorCompactCombine<dim, fe_degree, Number, type> &laplace)
+      : laplace_(laplace)
+    {}
+    std::size_t m() const { return laplace_.m(); }
+    void        vmult(Vector<Number> &dst, const Vector<Number> &src) const
+    {
+      check(mgx_dg_jacobi_vmult(laplace_.handle(), dst.begin(), src.begin()));
+    }
+
+  private:
+    const LaplaceOperatorCompactCombine<dim, fe_degree, Number, type> &laplace_;
+  };
+
+  // multigrid::MultigridSolverDG<dim,fe_degree,Number,Number2> (multigrid_solver_dg.h:55-747): the DG level on top of the
+  // FE_Q(fe_degree) hierarchy of the same mesh
+  template <int dim, int fe_degree, typename Number, typename Number2, int type = 0>
+  class MultigridSolverDG
+  {
+    static_assert(std::is_same<Number2, double>::value, "the outer iteration is fp64");
+
+  public:
+    MultigridSolverDG(const Context &ctx, const CubeDiscretization &disc, const unsigned int degree_pre)
+      : cfe_(ctx, disc, degree_pre, degree_pre, 1)
+    {
+      matrix_dg.reinit(ctx, disc);
+      matrix_dg_dp.reinit(ctx, disc);
+      mgx_dg_solver_desc d{};
+      d.matrix_dg    = matrix_dg.handle();
+      d.matrix_dg_dp = matrix_dg_dp.handle();
+      d.cfe          = cfe_.handle();
+      d.degree_pre   = (int)degree_pre;
+      check(mgx_dg_solver_create(ctx.handle(), &d, &h_));
+    }
+    ~MultigridSolverDG() { mgx_dg_solver_destroy(h_); }
+    MultigridSolverDG(const MultigridSolverDG &) = delete;
+    MultigridSolverDG &operator=(const MultigridSolverDG &) = delete;
+    // vmult (:429-440): one DG V-cycle
+    void vmult(Vector<Number2> &dst, const Vector<Number2> &src) const { check(mgx_dg_solver_vmult(h_, dst.begin(), src.begin())); }
+    // solve_cg(tolerance) (:410-424) on a given right-hand side: (iterations, reduction per iteration)
+    std::pair<unsigned int, double> solve_cg(const Vector<Number2> &rhs, Vector<Number2> &solution, const double tolerance = 1e-9)
+    {
+      unsigned int its = 0;
+      double       red = 1.;
+      check(mgx_dg_solver_solve_cg(h_, tolerance, rhs.begin(), solution.begin(), &its, &red));
+      return std::make_pair(its, red);
+    }
+    mgx_smoother_info smoother_info() const
+    {
+      mgx_smoother_info i{};
+      check(mgx_dg_solver_smoother_info(h_, &i));
+      return i;
+    }
+    LaplaceOperatorCompactCombine<dim, fe_degree, Number, type>  matrix_dg;    // :700
+    LaplaceOperatorCompactCombine<dim, fe_degree, Number2, type> matrix_dg_dp; // :703
+    mgx_dg_solver_t handle() const { return h_; }
+
+  private:
+    MultigridSolver<dim, fe_degree, Number, Number2> cfe_; // FE_Q hierarchy, re-configured by the DG solver (:271-291)
+    mgx_dg_solver_t                                  h_ = nullptr;
   };
 } // namespace multigrid

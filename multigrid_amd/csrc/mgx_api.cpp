@@ -138,6 +138,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
 #endif
     {"macro_wg_per_cu_x16", nullptr, &macro_wg_x16},
     {"no_diag_table", &no_diag_table, nullptr},
+    {"no_macro_v2", &no_macro_v2, nullptr},
     {"no_fused_init", &no_fused_init, nullptr},
     {"no_fused_restrict", &no_fused_restrict, nullptr},
     {"no_fused_prolong", &no_fused_prolong, nullptr},
@@ -1260,6 +1261,7 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
   d.cells_form       = tun.cells_form;
   d.wide_max         = tun.wide_max;
   d.macro_wg_x16     = tun.macro_wg_x16;
+  d.macro_v2         = !tun.no_macro_v2;
   for (int a = 0; a < n && d.separable; ++a)
     for (int bb = 0; bb < n; ++bb)
       if (std::fabs(M1[a * n + bb] - M1[(n - 1 - a) * n + n - 1 - bb]) > 1e-12 ||
@@ -1427,6 +1429,13 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
               build_item_map(p, map);
               MGX_HIP(hipMalloc((void **)&b.item_map, sizeof(uint32_t) * map.size()));
               MGX_HIP(hipMemcpy(b.item_map, map.data(), sizeof(uint32_t) * map.size(), hipMemcpyHostToDevice));
+              {
+                // ... and of its second pipeline (mgx_macro2.hip): interior of the brick first
+                std::vector<uint32_t> map2;
+                build_item_map2(p, map2);
+                MGX_HIP(hipMalloc((void **)&b.item_map2, sizeof(uint32_t) * map2.size()));
+                MGX_HIP(hipMemcpy(b.item_map2, map2.data(), sizeof(uint32_t) * map2.size(), hipMemcpyHostToDevice));
+              }
               // Reduced-colour schedule of the plain / residual / Chebyshev forms (mgx_macro.hip, FREE): one
               // class (one launch per level) on levels with at most free_one_max bricks, two classes up to
               // free_max_bricks
@@ -1724,6 +1733,7 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.bricks.ent_base);
   (void)hipFree(op->d.bricks.ent_flags);
   (void)hipFree(op->d.bricks.item_map);
+  (void)hipFree(op->d.bricks.item_map2);
   (void)hipFree(op->d.bricks.fr.ent);
   (void)hipFree(op->d.bricks.fr.surf_off);
   (void)hipFree(op->d.bricks.fr.priv);
@@ -1914,14 +1924,29 @@ int mgx_compute_residual(mgx_operator_t op, void *dst, const void *src, const vo
 {
   MGX_REQUIRE(op && dst, "mgx_compute_residual: null argument");
   MGX_REQUIRE(dst != src, "mgx_compute_residual: dst and src must not alias");
+  // (the boundary values are gathered through the table that also names the constrained DoFs)
+  MGX_REQUIRE(op->d.idx27_plain, "mgx_compute_residual: the operator was created without idx27_plain");
   hipStream_t  s     = op->ctx->stream;
   const size_t bytes = number_size(op->d.number) * op->d.n_dofs;
-  void        *zero  = nullptr;
+  // temporaries of this call, released on every path out of it (after the stream has drained)
+  struct Scratch
+  {
+    hipStream_t s;
+    void       *zero      = nullptr;
+    uint32_t   *lists_dev = nullptr;
+    ~Scratch()
+    {
+      if (zero || lists_dev)
+        (void)hipStreamSynchronize(s);
+      (void)hipFree(zero);
+      (void)hipFree(lists_dev);
+    }
+  } tmp{s};
   if (!src) // homogeneous boundary values
     {
-      MGX_HIP(hipMalloc(&zero, bytes));
-      MGX_HIP(hipMemsetAsync(zero, 0, bytes, s));
-      src = zero;
+      MGX_HIP(hipMalloc(&tmp.zero, bytes));
+      MGX_HIP(hipMemsetAsync(tmp.zero, 0, bytes, s));
+      src = tmp.zero;
     }
   MGX_HIP(hipMemsetAsync(dst, 0, bytes, s));
   // assembly without atomics, as for the diagonal (mgx_compute_diagonal)
@@ -1929,23 +1954,16 @@ int mgx_compute_residual(mgx_operator_t op, void *dst, const void *src, const vo
     {
       std::vector<uint32_t> lists, list_start;
       brick_cell_lists(op, lists, list_start);
-      uint32_t *lists_dev = nullptr;
-      MGX_HIP(hipMalloc((void **)&lists_dev, sizeof(uint32_t) * (lists.size() + 1)));
-      MGX_HIP(hipMemcpyAsync(lists_dev, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice, s));
-      launch_cell_residual(s, op->d, dst, src, rhs_q, lists_dev, list_start.data(), (int)list_start.size() - 1);
-      MGX_HIP(hipStreamSynchronize(s));
-      MGX_HIP(hipFree(lists_dev));
+      MGX_HIP(hipMalloc((void **)&tmp.lists_dev, sizeof(uint32_t) * (lists.size() + 1)));
+      MGX_HIP(hipMemcpyAsync(tmp.lists_dev, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice, s));
+      launch_cell_residual(s, op->d, dst, src, rhs_q, tmp.lists_dev, list_start.data(), (int)list_start.size() - 1);
+      MGX_HIP(hipStreamSynchronize(s)); // (`lists` is pageable host memory in flight until here)
     }
   else if (op->d.cell_order && !op->d.asm_start)
     launch_cell_residual(s, op->d, dst, src, rhs_q, op->d.cell_order, op->d.cell_colour_start, op->d.n_cell_colours);
   else
     launch_cell_residual(s, op->d, dst, src, rhs_q);
   MGX_HIP(hipGetLastError());
-  if (zero)
-    {
-      MGX_HIP(hipStreamSynchronize(s));
-      MGX_HIP(hipFree(zero));
-    }
   return exchange_add(op, dst); // dst.compress(add), laplace_operator.h:843
 }
 
@@ -3156,8 +3174,15 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
           std::copy(tmp.begin(), tmp.end(), S->agg_host.begin());
         }
       MGX_HIP(hipStreamSynchronize(s));
-      if (!ctx->comm.allreduce_sum || ctx->comm.allreduce_sum(ctx->comm.user, S->agg_host.data(), (int)ng) != 0)
+      // (the callback counts in int: pieces of at most 2^30 values, so that no count is ever narrowed)
+      if (!ctx->comm.allreduce_sum)
         return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+      for (size_t first = 0; first < (size_t)ng; first += (size_t)1 << 30)
+        {
+          const size_t piece = std::min<size_t>((size_t)ng - first, (size_t)1 << 30);
+          if (ctx->comm.allreduce_sum(ctx->comm.user, S->agg_host.data() + first, (int)piece) != 0)
+            return fail(MGX_ERR_HIP, "allreduce_sum callback failed");
+        }
       if (num == MGX_F64)
         {
           // pageable staging buffer, rewritten by the next cycle: the copy must have left it before we return
@@ -3200,7 +3225,6 @@ int mgx_solver_set_agglomeration(mgx_solver_t S, int level, mgx_solver_t coarse,
               "mgx_solver_set_agglomeration: the coarse solver lives on a context of its own without a communicator");
   MGX_REQUIRE(n_local == S->matrix[level]->d.n_dofs, "mgx_solver_set_agglomeration: map length is not the level size");
   const uint32_t ng = coarse->matrix[level]->d.n_dofs;
-  MGX_REQUIRE(ng <= 0x7FFFFFFFu, "mgx_solver_set_agglomeration: the agglomerated level exceeds the count of one allreduce");
   for (uint32_t i = 0; i < n_local; ++i)
     if (local_to_global[i] >= ng)
       return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_solver_set_agglomeration: map entry out of range");

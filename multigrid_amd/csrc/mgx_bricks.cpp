@@ -493,77 +493,108 @@ namespace mgx
     return true;
   }
 
-  void build_item_map(int p, std::vector<uint32_t> &map)
+  namespace
   {
-    const int NB = p <= 4 ? 4 : 2, G = NB * p + 1, E1 = 2 * NB + 1;
-    auto word = [](int slot, int pnt, int off) { return (uint32_t)slot | ((uint32_t)pnt << 10) | ((uint32_t)off << 23); };
-    // the entities in write-out order with the brick point of each of their DoFs
-    struct Ent
+    // the entities of a brick in the write-out order of build_item_map with the brick point of each of their DoFs
+    struct ItemEntity
     {
       int              slot;
       std::vector<int> pnt; // brick point of DoF k of the entity
     };
-    std::vector<Ent> ents;
-    // part A: per cell (Morton order) the entities on its high side / in its interior
-    for (int m = 0; m < NB * NB * NB; ++m)
-      {
-        const int bx = compact3(m), by = compact3(m >> 1), bz = compact3(m >> 2);
-        for (int j = 0; j < 8; ++j)
-          {
-            const int cx = 1 + (j & 1), cy = 1 + ((j >> 1) & 1), cz = 1 + (j >> 2);
-            const int nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
-            Ent       e;
-            e.slot = ((2 * bz + cz) * E1 + 2 * by + cy) * E1 + 2 * bx + cx;
-            for (int kl = 0; kl < nx * ny * nz; ++kl)
-              {
-                const int ox = kl % nx, oy = (kl / nx) % ny, oz = kl / (nx * ny);
-                const int lx = cx == 1 ? 1 + ox : p, ly = cy == 1 ? 1 + oy : p, lz = cz == 1 ? 1 + oz : p;
-                e.pnt.push_back(((bz * p + lz) * G + by * p + ly) * G + bx * p + lx);
-              }
-            if (!e.pnt.empty())
-              ents.push_back(e);
-          }
-      }
-    // part B: the entities on the three low faces of the brick (their DoFs belong to the cell
-    // blocks of neighbouring bricks), plane by plane
-    for (int ez = 0; ez < E1; ++ez)
-      for (int ey = 0; ey < E1; ++ey)
-        for (int ex = 0; ex < E1; ++ex)
-          {
-            if (ex != 0 && ey != 0 && ez != 0)
-              continue;
-            const int nx = (ex & 1) ? p - 1 : 1, ny = (ey & 1) ? p - 1 : 1, nz = (ez & 1) ? p - 1 : 1;
-            Ent       e;
-            e.slot = (ez * E1 + ey) * E1 + ex;
-            for (int kl = 0; kl < nx * ny * nz; ++kl)
-              {
-                const int ox = kl % nx, oy = (kl / nx) % ny, oz = kl / (nx * ny);
-                const int gx = (ex / 2) * p + ((ex & 1) ? 1 + ox : 0), gy = (ey / 2) * p + ((ey & 1) ? 1 + oy : 0),
-                          gz = (ez / 2) * p + ((ez & 1) ? 1 + oz : 0);
-                e.pnt.push_back((gz * G + gy) * G + gx);
-              }
-            if (!e.pnt.empty())
-              ents.push_back(e);
-          }
+    inline uint32_t item_word(int slot, int pnt, int off)
+    {
+      return (uint32_t)slot | ((uint32_t)pnt << 10) | ((uint32_t)off << 23);
+    }
+    void enumerate_item_entities(int p, std::vector<ItemEntity> &ents)
+    {
+      const int NB = p <= 4 ? 4 : 2, G = NB * p + 1, E1 = 2 * NB + 1;
+      ents.clear();
+      // part A: per cell (Morton order) the entities on its high side / in its interior
+      for (int m = 0; m < NB * NB * NB; ++m)
+        {
+          const int bx = compact3(m), by = compact3(m >> 1), bz = compact3(m >> 2);
+          for (int j = 0; j < 8; ++j)
+            {
+              const int  cx = 1 + (j & 1), cy = 1 + ((j >> 1) & 1), cz = 1 + (j >> 2);
+              const int  nx = cx == 1 ? p - 1 : 1, ny = cy == 1 ? p - 1 : 1, nz = cz == 1 ? p - 1 : 1;
+              ItemEntity e;
+              e.slot = ((2 * bz + cz) * E1 + 2 * by + cy) * E1 + 2 * bx + cx;
+              for (int kl = 0; kl < nx * ny * nz; ++kl)
+                {
+                  const int ox = kl % nx, oy = (kl / nx) % ny, oz = kl / (nx * ny);
+                  const int lx = cx == 1 ? 1 + ox : p, ly = cy == 1 ? 1 + oy : p, lz = cz == 1 ? 1 + oz : p;
+                  e.pnt.push_back(((bz * p + lz) * G + by * p + ly) * G + bx * p + lx);
+                }
+              if (!e.pnt.empty())
+                ents.push_back(e);
+            }
+        }
+      // part B: the entities on the three low faces of the brick (their DoFs belong to the cell
+      // blocks of neighbouring bricks), plane by plane
+      for (int ez = 0; ez < E1; ++ez)
+        for (int ey = 0; ey < E1; ++ey)
+          for (int ex = 0; ex < E1; ++ex)
+            {
+              if (ex != 0 && ey != 0 && ez != 0)
+                continue;
+              const int  nx = (ex & 1) ? p - 1 : 1, ny = (ey & 1) ? p - 1 : 1, nz = (ez & 1) ? p - 1 : 1;
+              ItemEntity e;
+              e.slot = (ez * E1 + ey) * E1 + ex;
+              for (int kl = 0; kl < nx * ny * nz; ++kl)
+                {
+                  const int ox = kl % nx, oy = (kl / nx) % ny, oz = kl / (nx * ny);
+                  const int gx = (ex / 2) * p + ((ex & 1) ? 1 + ox : 0), gy = (ey / 2) * p + ((ey & 1) ? 1 + oy : 0),
+                            gz = (ez / 2) * p + ((ez & 1) ? 1 + oz : 0);
+                  e.pnt.push_back((gz * G + gy) * G + gx);
+                }
+              if (!e.pnt.empty())
+                ents.push_back(e);
+            }
+    }
+  } // namespace
+
+  void build_item_map(int p, std::vector<uint32_t> &map)
+  {
+    const int               NB = p <= 4 ? 4 : 2, G = NB * p + 1;
+    std::vector<ItemEntity> ents;
+    enumerate_item_entities(p, ents);
     // pairs first (DoFs 2k, 2k+1 of one entity: adjacent in memory by the entity-contiguity
     // contract, whatever the numbering), then the odd DoF left over in every entity of odd size
     map.clear();
     map.reserve((size_t)G * G * G);
     if (MGX_MACRO_PAIRS)
       {
-        for (const Ent &e : ents)
+        for (const ItemEntity &e : ents)
           for (size_t k = 0; k + 1 < e.pnt.size(); k += 2)
             {
-              map.push_back(word(e.slot, e.pnt[k], (int)k));
-              map.push_back(word(e.slot, e.pnt[k + 1], (int)k + 1));
+              map.push_back(item_word(e.slot, e.pnt[k], (int)k));
+              map.push_back(item_word(e.slot, e.pnt[k + 1], (int)k + 1));
             }
-        for (const Ent &e : ents)
+        for (const ItemEntity &e : ents)
           if (e.pnt.size() % 2)
-            map.push_back(word(e.slot, e.pnt.back(), (int)e.pnt.size() - 1));
+            map.push_back(item_word(e.slot, e.pnt.back(), (int)e.pnt.size() - 1));
       }
     else
-      for (const Ent &e : ents)
+      for (const ItemEntity &e : ents)
         for (size_t k = 0; k < e.pnt.size(); ++k)
-          map.push_back(word(e.slot, e.pnt[k], (int)k));
+          map.push_back(item_word(e.slot, e.pnt[k], (int)k));
+  }
+
+  void build_item_map2(int p, std::vector<uint32_t> &map)
+  {
+    const int               NB = p <= 4 ? 4 : 2, G = NB * p + 1, E1 = 2 * NB + 1;
+    std::vector<ItemEntity> ents;
+    enumerate_item_entities(p, ents);
+    auto on_surface = [&](int slot) {
+      const int ex = slot % E1, ey = (slot / E1) % E1, ez = slot / (E1 * E1);
+      return ex == 0 || ex == E1 - 1 || ey == 0 || ey == E1 - 1 || ez == 0 || ez == E1 - 1;
+    };
+    map.clear();
+    map.reserve((size_t)G * G * G);
+    for (int pass = 0; pass < 2; ++pass)
+      for (const ItemEntity &e : ents)
+        if ((int)on_surface(e.slot) == pass)
+          for (size_t k = 0; k < e.pnt.size(); ++k)
+            map.push_back(item_word(e.slot, e.pnt[k], (int)k));
   }
 } // namespace mgx

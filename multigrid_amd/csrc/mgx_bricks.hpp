@@ -62,4 +62,10 @@ namespace mgx
 #define MGX_MACRO_PAIRS 0
 #endif
   void build_item_map(int p, std::vector<uint32_t> &map);
+  // Item table of the second pipeline of the macro-element kernel (mgx_macro2.hip): the same words, but the
+  // (G - 2)^3 points in the interior of the brick first (in the order above), then the points on its surface.  Only
+  // the surface points carry partial sums between the colour launches, can be constrained or lie on a rank
+  // interface: the first (G - 2)^3 / threads value slots of every thread then need neither flags nor carrier accesses,
+  // and the partial sums of the remaining few can be requested ahead of the sweeps.
+  void build_item_map2(int p, std::vector<uint32_t> &map);
 } // namespace mgx

@@ -39,6 +39,7 @@ namespace mgx
     bool     dg_unmerged_restrict = false; // DG V-cycle: residual and DG -> FE_Q restriction as two kernels instead of the merged action 1
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
     bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
+    bool     no_macro_v2      = false; // first pipeline of the macro-element kernel (gather after the sweeps) for every form; A/B of mgx_macro2.hip
     bool     no_fused_init    = false; // MGX_NO_FUSED_INIT    store the first Chebyshev iterate
     bool     no_fused_restrict = false; // MGX_NO_FUSED_RESTRICT  separate residual and restriction kernels
     bool     no_fused_prolong = false; // MGX_NO_FUSED_PROLONG prolongation as a kernel of its own
@@ -116,6 +117,7 @@ namespace mgx
     uint32_t *ent_base  = nullptr; // device [n_bricks * 729]
     uint8_t  *ent_flags = nullptr; // device [n_bricks * 729]  bit0 FIRST, bit1 LAST
     uint32_t *item_map  = nullptr; // device [(NB p + 1)^3]: write-out order of the macro-element kernel
+    uint32_t *item_map2 = nullptr; // device: the same items, interior of the brick first (second pipeline, mgx_macro2.hip)
     std::vector<uint32_t> order; // host: colour-sorted position -> brick index in cell order
     bool      available() const { return n_bricks > 0; }
     FreeSchedule fr; // reduced-colour schedule of the plain / residual / Chebyshev forms (may be absent)
@@ -161,6 +163,7 @@ namespace mgx
     // every brick (uniform mesh), else nullptr: the macro-element kernel then reads it from
     // registers instead of streaming inv_diag (mgx_macro.hip, DTAB)
     void     *diag_items    = nullptr;
+    bool      macro_v2      = true;    // !Tunables::no_macro_v2
   };
 
   struct TransferData
@@ -287,6 +290,11 @@ namespace mgx
   void launch_reduce4(hipStream_t s, const double *partials, uint32_t n, const double *extra, double *sums);
   void macro_diag_table_f64(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   void macro_diag_table_f32(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
+  // second pipeline (mgx_macro2.hip: plain and residual form); false: form / degree not covered, use the first
+  bool launch_macro2_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a, void *out,
+                              void *partial, int group_begin, int group_end);
+  bool launch_macro2_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a, void *out,
+                              void *partial, int group_begin, int group_end);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)

@@ -74,3 +74,37 @@ def test_schedules_against_oracle_and_each_other(monkeypatch, p, ns, nr, number)
             assert rel(a, e) < 10 * tol_op
     cube.close()
     orc.close()
+
+
+@pytest.mark.parametrize("p,ns,nr,number", [(1, 1, 4, "f64"), (2, 1, 4, "f64"), (3, 3, 2, "f64"), (4, 1, 3, "f64"), (4, 3, 2, "f64"),
+                                            (5, 1, 3, "f64"), (6, 1, 2, "f64"), (7, 3, 1, "f64"), (8, 1, 2, "f64"), (9, 1, 2, "f64"),
+                                            (4, 1, 3, "f32"), (8, 1, 2, "f32")])
+def test_second_pipeline_of_the_plain_and_residual_forms(p, ns, nr, number):
+    """mgx_macro2.hip (interior points first, partial sums requested before the sweeps) runs the plain and the residual
+    form of the eight-colour schedule: against the oracle and BITWISE against the first pipeline (mgx_macro.hip, option
+    no_macro_v2) -- same sweeps, same order of every sum."""
+    vnum = mg.F32 if number == "f32" else mg.F64
+    tol = 2e-5 if number == "f32" else 1e-12
+    cube = mg.Cube(p, ns, nr)
+    orc = oracle_for(cube, p, ns, nr)
+    l = cube.max_level
+    x, b = cube.seeded_vector(l, 31), cube.seeded_vector(l, 32)
+    if number == "f32":
+        x, b = x.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    results = []
+    for opts in ({"free_max_bricks": 0}, {"free_max_bricks": 0, "no_macro_v2": 1}):
+        c = mg.Context(0, options=opts)
+        op = mg.LaplaceOperator.from_cube(c, cube, l, number=vnum)
+        src, rhs, dst = c.vector(x.size, vnum, x), c.vector(x.size, vnum, b), c.vector(x.size, vnum)
+        op.vmult(dst, src)
+        y = dst.download()
+        assert rel(y.astype(np.float64), orc.vmult(l, x)) < tol
+        op.vmult_residual(rhs, src, dst)
+        r = dst.download()
+        assert rel(r.astype(np.float64), orc.vmult_residual(l, b, x)) < tol
+        results.append((y, r))
+        op.clear()
+        c.close()
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    cube.close()
+    orc.close()

@@ -2,7 +2,7 @@
 usage: [MGX_LIB_PATH=...] python tools/bench_forms.py [bench.py arguments]"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-verify"] + sys.argv[1:],
+out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-verify", "--no-secondary"] + sys.argv[1:],
                      capture_output=True, cwd=root)
 d = json.loads(out.stdout.decode().strip().splitlines()[-1])
 forms = {"kCheb": d["roofline"], "kPlain": d["roofline_matvec"], **d["roofline_forms"]}

@@ -34,7 +34,13 @@ ctx.sync()
 lib = mg._lib.load()
 nb = 4096
 buf = np.zeros((nb, 16), np.uint64)
-rc = lib.mgx_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), nb)
+# the second pipeline (mgx_macro2.hip) keeps stamps of its own: use them where it ran (MGX_STAMPS_V1=1: first pipeline)
+v2 = hasattr(lib, "mgx_debug_read_stamps2") and not os.environ.get("MGX_STAMPS_V1")
+if v2:
+    rc = lib.mgx_debug_read_stamps2(buf.ctypes.data_as(ctypes.c_void_p), nb)
+    v2 = rc == 0 and (buf[:, 0] != 0).any()
+if not v2:
+    rc = lib.mgx_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), nb)
 assert rc == 0, rc
 live = buf[:, 0] != 0
 t = buf[live].astype(np.int64)
@@ -51,13 +57,26 @@ rep("prologue: table", t[:, 1] - t[:, 0])
 rep("prologue: gather + land", t[:, 2] - t[:, 1])
 # fourth brick of each workgroup (steady state): 3 loop top, 4 x, 5 y, 6 z, 7 tables parked + next gather
 # issued, 8 write-out done, 9 next gather landed in U, 10 barrier, 11 next loop top
-rep("brick 4: x sweep", t[:, 4] - t[:, 3])
-rep("brick 4: y sweep", t[:, 5] - t[:, 4])
-rep("brick 4: z sweep", t[:, 6] - t[:, 5])
-rep("brick 4: park tables, issue gather", t[:, 7] - t[:, 6])
-rep("brick 4: write-out", t[:, 8] - t[:, 7])
-rep("brick 4: barrier + land gather", t[:, 9] - t[:, 8])
-rep("brick 4: barrier", t[:, 10] - t[:, 9])
+if v2:
+    # second pipeline: 3 loop top, 4 requests issued + barrier, 5 x done, 6 y done, 7 z done, 8 write-out done, 9 barrier,
+    # 10 gather landed + tables stored, 11 next loop top
+    print("(second pipeline)")
+    rep("brick 4: issue gather / partials", t[:, 4] - t[:, 3])
+    rep("brick 4: x sweep", t[:, 5] - t[:, 4])
+    rep("brick 4: y sweep", t[:, 6] - t[:, 5])
+    rep("brick 4: z sweep", t[:, 7] - t[:, 6])
+    rep("brick 4: write-out", t[:, 8] - t[:, 7])
+    rep("brick 4: barrier", t[:, 9] - t[:, 8])
+    rep("brick 4: land gather, store tables", t[:, 10] - t[:, 9])
+    rep("brick 4: barrier", t[:, 11] - t[:, 10])
+else:
+    rep("brick 4: x sweep", t[:, 4] - t[:, 3])
+    rep("brick 4: y sweep", t[:, 5] - t[:, 4])
+    rep("brick 4: z sweep", t[:, 6] - t[:, 5])
+    rep("brick 4: park tables, issue gather", t[:, 7] - t[:, 6])
+    rep("brick 4: write-out", t[:, 8] - t[:, 7])
+    rep("brick 4: barrier + land gather", t[:, 9] - t[:, 8])
+    rep("brick 4: barrier", t[:, 10] - t[:, 9])
 rep("brick 4: whole iteration", t[:, 11] - t[:, 3])
 rep("whole workgroup", t[:, 14] - t[:, 0])
 rt = t[:, 13] - t[:, 15]

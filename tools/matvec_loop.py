@@ -13,7 +13,11 @@ while ns % 2 == 0 and ns > 1:
 # every launch of the fused transfer forms (and every 512-block launch of the eight-colour kernels) in the trace
 # belongs to the finest level
 # (no_restrict_scratch: otherwise the fused residual + restriction would run there as well, as one launch)
-ctx = mg.Context(0, options={"free_one_max": 8192, "no_restrict_scratch": 1} if mode == "all" else None)
+opts = {"free_one_max": 8192, "no_restrict_scratch": 1} if mode == "all" else {}
+# MATVEC_OPTS="name=value,...": further context options (A/B of code paths under the profiler)
+for kv in filter(None, os.environ.get("MATVEC_OPTS", "").split(",")):
+    opts[kv.split("=")[0]] = float(kv.split("=")[1])
+ctx = mg.Context(0, options=opts or None)
 cube = mg.Cube(deg, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Times the finest-level brick kernels of several library variants (tools/build_variant.sh) on the GPU box.
+# Times the finest-level brick kernels of several library variants (tools/build_variant_of.sh) on the GPU box.
 # usage: tools/run_variants.sh <cells> <mode> tag1 tag2 ...   (tag "prod" = the production library)
 cells=$1; mode=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
