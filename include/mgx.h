@@ -145,6 +145,14 @@ typedef struct
  * poisson_cube/program.cc:281-296,347-354; here: HIP events on the context's stream around every
  * launch of the cell-loop kernel of the operators flagged with mgx_operator_set_profiled) ---- */
 int mgx_profile_enable(mgx_context_t ctx, int enable);
+/* Profiler ranges (roctx, bound at run time; no-ops unless the context option "roctx" is set): the driver's LIKWID
+ * regions of the reference -- LIKWID_MARKER_START / STOP("fmg_solver" | "cg_solver" | "matvec" | "matvec_sp"),
+ * poisson_cube/program.cc:282-295, 309-321, 348-354, 369-375.  With the option set the library itself brackets the
+ * phases of every V-cycle level: vmult_cheby_<level> (laplace_operator.h:732-739), mg_mv_<level>, restrict_<level>,
+ * prolongate_<level>, mg_vec_<level>, inhomBC_<level>, coarse_solver_0 (the columns of print_wall_times,
+ * multigrid_solver.h:348-371).  rocprofv3 --marker-trace shows them. */
+int mgx_range_push(mgx_context_t ctx, const char *name);
+int mgx_range_pop(mgx_context_t ctx);
 /* Synchronises and returns, for one form of the cell loop, the number of bracketed kernel launches
  * and their summed duration; resets that form's record.  form: 0 plain vmult (16 B/DoF
  * algorithmic: src read + dst write), 1 residual (24 B/DoF), 2 fused Chebyshev iteration

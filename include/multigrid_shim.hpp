@@ -72,6 +72,11 @@ namespace multigrid
     Context &operator=(const Context &) = delete;
     mgx_context_t handle() const { return h_; }
     void          sync() const { check(mgx_sync(h_)); }
+    // options of mgx_context_set_option (before the first object is created on the context)
+    void set_option(const char *name, double value) { check(mgx_context_set_option(h_, name, value)); }
+    // LIKWID_MARKER_START / STOP of the reference's drivers as profiler ranges (no-ops unless the option "roctx" is set)
+    void marker_start(const char *name) const { check(mgx_range_push(h_, name)); }
+    void marker_stop(const char * /*name*/) const { check(mgx_range_pop(h_)); }
     // device memory in use on the context's GPU (all processes), in MB
     double device_memory_used_mb() const
     {

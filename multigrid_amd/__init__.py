@@ -291,6 +291,21 @@ class Context:
     def profile_enable(self, on=True):
         check(self.lib.mgx_profile_enable(self.h, int(on)))
 
+    def range(self, name):
+        """context manager: a profiler range (roctx) with one of the reference's LIKWID region names --
+        "fmg_solver", "cg_solver", "matvec", "matvec_sp" (poisson_cube/program.cc:282-375); no-op unless the
+        context option "roctx" is set"""
+        ctx = self
+
+        class _Range:
+            def __enter__(self):
+                check(ctx.lib.mgx_range_push(ctx.h, name.encode()))
+
+            def __exit__(self, *exc):
+                check(ctx.lib.mgx_range_pop(ctx.h))
+                return False
+        return _Range()
+
     def profile_read(self, form):
         """(kernel launches, summed duration in ms) of one form of the profiled cell loop:
         0 plain vmult, 1 residual, 2 fused Chebyshev iteration, 3 first step, 4 zero x_old; resets"""

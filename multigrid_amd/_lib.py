@@ -108,6 +108,8 @@ SIGNATURES = {
     "mgx_operator_exchange_buffers": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(C.c_int)]),
     "mgx_exchange_add": (C.c_int, [vp, vp]),
     "mgx_profile_enable": (C.c_int, [vp, C.c_int]),
+    "mgx_range_push": (C.c_int, [vp, C.c_char_p]),
+    "mgx_range_pop": (C.c_int, [vp]),
     "mgx_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64), f64p]),
     "mgx_operator_set_profiled": (C.c_int, [vp, C.c_int]),
     "mgx_malloc": (C.c_int, [vp, C.POINTER(vp), C.c_size_t]),

@@ -139,6 +139,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"macro_wg_per_cu_x16", nullptr, &macro_wg_x16},
     {"no_diag_table", &no_diag_table, nullptr},
     {"no_macro_v2", &no_macro_v2, nullptr},
+    {"roctx", &roctx, nullptr},
     {"no_fused_init", &no_fused_init, nullptr},
     {"no_fused_restrict", &no_fused_restrict, nullptr},
     {"no_fused_prolong", &no_fused_prolong, nullptr},
@@ -669,6 +670,44 @@ namespace
     return exchange_add(op, dst); // no-op on a single rank
   }
 
+  // Profiler ranges (context option "roctx"): the reference brackets its phases with LIKWID markers -- fmg_solver,
+  // cg_solver, matvec, matvec_sp in the driver (poisson_cube/program.cc:282,309,348,369) and vmult_cheby_<level> around
+  // the smoother's operator applications (laplace_operator.h:732-739); the same names go to roctx here, so that a
+  // rocprofv3 --marker-trace of a run can be cut by level and phase.  The library is bound at run time.
+  struct Roctx
+  {
+    int (*push)(const char *) = nullptr;
+    int (*pop)()              = nullptr;
+    Roctx()
+    {
+      for (const char *n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+        if (void *lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))
+          {
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+            pop  = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            if (push && pop)
+              return;
+          }
+      push = nullptr;
+      pop  = nullptr;
+    }
+  };
+  Roctx &roctx()
+  {
+    static Roctx r;
+    return r;
+  }
+  inline void range_push(mgx_context_t ctx, const char *name)
+  {
+    if (ctx->tun.roctx && roctx().push)
+      (void)roctx().push(name);
+  }
+  inline void range_pop(mgx_context_t ctx)
+  {
+    if (ctx->tun.roctx && roctx().pop)
+      (void)roctx().pop();
+  }
+
   struct Stopwatch
   {
     mgx_solver_t s;
@@ -679,6 +718,15 @@ namespace
       , level(level)
       , slot(slot)
     {
+      if (s->ctx->tun.roctx)
+        {
+          // the phases print_wall_times() reports (multigrid_solver.h:348-371), the smoother under the reference's
+          // marker name
+          static const char *const names[6] = {"mg_mv", "restrict", "prolongate", "inhomBC", "mg_vec", "vmult_cheby"};
+          char                     buf[48];
+          std::snprintf(buf, sizeof(buf), "%s_%d", (level == 0 && slot == 0) ? "coarse_solver" : names[slot], level);
+          range_push(s->ctx, buf);
+        }
       if (s->timing)
         {
           (void)hipStreamSynchronize(s->ctx->stream);
@@ -693,6 +741,7 @@ namespace
           s->timings[6 * level + slot] +=
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
+      range_pop(s->ctx);
     }
   };
 
@@ -958,6 +1007,20 @@ int mgx_copy_device(mgx_context_t ctx, void *dst, const void *src, size_t bytes)
       MGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
       MGX_HIP(hipStreamSynchronize(ctx->stream));
     }
+  return MGX_OK;
+}
+
+int mgx_range_push(mgx_context_t ctx, const char *name)
+{
+  MGX_REQUIRE(ctx && name, "mgx_range_push: null argument");
+  range_push(ctx, name);
+  return MGX_OK;
+}
+
+int mgx_range_pop(mgx_context_t ctx)
+{
+  MGX_REQUIRE(ctx, "mgx_range_pop: null context");
+  range_pop(ctx);
   return MGX_OK;
 }
 
@@ -3257,7 +3320,16 @@ static int v_cycle(mgx_solver_t S, int level, int my_n_cycles)
   hipStream_t s = S->ctx->stream;
   if (S->graph_exec)
     {
-      MGX_HIP(hipGraphLaunch(S->graph_exec, s));
+      // (the levels inside the replayed graph cannot be cut by host ranges: one range for the whole coarse part)
+      if (S->ctx->tun.roctx)
+        {
+          char buf[48];
+          std::snprintf(buf, sizeof(buf), "v_cycle_graph_levels_0_to_%d", level);
+          range_push(S->ctx, buf);
+        }
+      const hipError_t e = hipGraphLaunch(S->graph_exec, s);
+      range_pop(S->ctx);
+      MGX_HIP(e);
       return MGX_OK;
     }
   if (S->graph_calls++ == 0)

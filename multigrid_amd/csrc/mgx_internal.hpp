@@ -39,6 +39,7 @@ namespace mgx
     bool     dg_unmerged_restrict = false; // DG V-cycle: residual and DG -> FE_Q restriction as two kernels instead of the merged action 1
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
     bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
+    bool     roctx            = false; // profiler ranges with the reference's LIKWID region names (mgx_range_push/pop, per-level phases of the V-cycle)
     bool     no_macro_v2      = false; // first pipeline of the macro-element kernel (gather after the sweeps) for every form; A/B of mgx_macro2.hip
     bool     no_fused_init    = false; // MGX_NO_FUSED_INIT    store the first Chebyshev iterate
     bool     no_fused_restrict = false; // MGX_NO_FUSED_RESTRICT  separate residual and restriction kernels

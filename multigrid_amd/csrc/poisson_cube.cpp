@@ -61,6 +61,7 @@ namespace
                 << ctx.device_memory_used_mb() << std::endl;
     }
     double best_time = 1e10, tot_time = 0;
+    ctx.marker_start("fmg_solver"); // program.cc:282
     for (unsigned int i = 0; i < 7; ++i) // program.cc:285-293
       {
         auto t0 = clock_type::now();
@@ -71,6 +72,7 @@ namespace
         tot_time += t;
         std::cout << "Time solve                 " << t << "\n";
       }
+    ctx.marker_stop("fmg_solver"); // :295
     solver.enable_timings(true);
     const double vcycl_reduction = solver.solve(true); // :297
     std::cout << "All solver time " << tot_time << std::endl;
@@ -81,6 +83,7 @@ namespace
     std::cout << "Solution l2 norm = " << solver.get_solution().l2_norm() << " error = " << l2_error << std::endl;
     double                          time_cg = 1e10;
     std::pair<unsigned int, double> cg_details;
+    ctx.marker_start("cg_solver"); // :309
     for (unsigned int i = 0; i < 10; ++i) // :313-319
       {
         auto t0    = clock_type::now();
@@ -90,6 +93,7 @@ namespace
         time_cg        = std::min(t, time_cg);
         std::cout << "Time solve CG              " << t << "\n";
       }
+    ctx.marker_stop("cg_solver"); // :321
     const double l2_error_cg = solver.compute_l2_error(maxlevel); // :323
     const std::size_t n_dofs = disc.n_dofs();
     double            best_mv = 1e10;
@@ -98,8 +102,10 @@ namespace
         const unsigned int n_mv = n_dofs < 10000000 ? 200 : 50;
         ctx.sync();
         auto t0 = clock_type::now();
+        ctx.marker_start("matvec"); // :348
         for (unsigned int j = 0; j < n_mv; ++j)
           solver.do_matvec();
+        ctx.marker_stop("matvec"); // :354
         ctx.sync();
         const double t = seconds_since(t0) / n_mv;
         best_mv        = std::min(best_mv, t);
@@ -111,8 +117,10 @@ namespace
         const unsigned int n_mv = n_dofs < 10000000 ? 200 : 50;
         ctx.sync();
         auto t0 = clock_type::now();
+        ctx.marker_start("matvec_sp"); // :369
         for (unsigned int j = 0; j < n_mv; ++j)
           solver.do_matvec_smoother();
+        ctx.marker_stop("matvec_sp"); // :375
         ctx.sync();
         best_mvs = std::min(best_mvs, seconds_since(t0) / n_mv);
       }
@@ -129,6 +137,8 @@ namespace
   {
     std::cout << "Testing FE_Q<3>(" << degree << ")" << std::endl;
     multigrid::Context ctx(0);
+    if (std::getenv("MGX_ROCTX")) // profiler ranges in place of the reference's LIKWID build (-DLIKWID_PERFMON)
+      ctx.set_option("roctx", 1.);
     const unsigned int sizes[] = {1,   2,   3,   4,   5,   6,   7,   8,   10,  12,  14,   16,   20,
                                   24,  28,  32,  40,  48,  56,  64,  80,  96,  112, 128,  160,  192,
                                   224, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536}; // :498-500
