@@ -294,8 +294,8 @@ namespace multigrid
       v.upload(cast);
       return v;
     }
-    // evaluate_coefficient(coefficient_function) (laplace_operator.h:357-432): the merged coefficient det J J^-1 a J^-T
-    // per cell and quadrature point, six entries each ([cell][6][(p+1)^3], host; the reference evaluates a Function and
+    // evaluate_coefficient(coefficient_function) (laplace_operator.h:357-432): the merged coefficient JxW J^-1 a J^-T
+    // (quadrature weight folded in, :388-430) per cell and quadrature point, six entries each ([cell][6][(p+1)^3], host; the reference evaluates a Function and
     // the mapping, here the caller or the discretisation supplies the values).  An empty vector restores the constant
     // Cartesian coefficient of the discretisation.
     void evaluate_coefficient(const std::vector<number> &merged_coefficient)
@@ -601,6 +601,15 @@ namespace multigrid
       d.matrix_dg_dp = matrix_dg_dp.handle();
       d.cfe          = cfe_.handle();
       d.degree_pre   = (int)degree_pre;
+      // decomposition-independent cell ids (lexicographic position in the mesh): the start vector of the smoother's
+      // eigenvalue estimate is tied to them, as deal.II ties it to the global DoF index
+      const int                  l   = disc.n_levels() - 1;
+      const std::uint32_t        nc  = mgx_cube_n_cells(disc.handle(), l), N = mgx_cube_cells_per_dim(disc.handle(), l);
+      const std::uint32_t       *xyz = mgx_cube_cell_coords(disc.handle(), l);
+      std::vector<std::uint32_t> gid(nc);
+      for (std::uint32_t c = 0; c < nc; ++c)
+        gid[c] = xyz[3 * c] + N * (xyz[3 * c + 1] + N * xyz[3 * c + 2]);
+      d.cell_global_id = gid.data();
       check(mgx_dg_solver_create(ctx.handle(), &d, &h_));
     }
     ~MultigridSolverDG() { mgx_dg_solver_destroy(h_); }

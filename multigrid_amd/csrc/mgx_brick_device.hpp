@@ -295,7 +295,7 @@ namespace mgx
               acc[l * G + pb * P + j] = o[j];
           }
       });
-    __syncthreads();
+    lds_barrier(); // LDS only: the gathered source values of the next brick stay in flight
     // y: lines (x < CN, z)
     sweep(
       CN * G, [&](int l) { return (l / CN) * G * G + l % CN; }, G,
@@ -308,7 +308,7 @@ namespace mgx
               acc[(z * G + pb * P + j) * G + x] = o[j];
           }
       });
-    __syncthreads();
+    lds_barrier();
     // z: lines (x, y) with x, y < CN; the results are added to the coarse vector (values requested above;
     // all stores behind all loads: a load behind a store to the same vector would wait for it)
     {

@@ -291,11 +291,11 @@ namespace mgx
   void launch_reduce4(hipStream_t s, const double *partials, uint32_t n, const double *extra, double *sums);
   void macro_diag_table_f64(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
   void macro_diag_table_f32(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
-  // second pipeline (mgx_macro2.hip: plain and residual form); false: form / degree not covered, use the first
+  // second pipeline (mgx_macro2.hip: plain, residual, residual + restriction); false: form / degree not covered, use the first
   bool launch_macro2_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a, void *out,
-                              void *partial, int group_begin, int group_end);
+                              void *partial, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
   bool launch_macro2_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a, void *out,
-                              void *partial, int group_begin, int group_end);
+                              void *partial, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)

@@ -1046,9 +1046,9 @@ namespace mgx
     const bool fr = free_schedule && op.bricks.fr.available() && mode <= kChebOldInit && !MGX_MACRO_PAIRS;
     if (free_schedule && !fr)
       return false;
-    // the forms the second pipeline covers (mgx_macro2.hip: plain, residual) on the eight-colour schedule
+    // the forms the second pipeline covers (mgx_macro2.hip: plain, residual, residual + restriction) on the eight-colour schedule
     if (!free_schedule && op.macro_v2 && !MGX_MACRO_PAIRS &&
-        MGX_CAT(launch_macro2_loop_, MGX_MACRO_SUFFIX)(s, op, mode, src, a, out, partial, g0, g1))
+        MGX_CAT(launch_macro2_loop_, MGX_MACRO_SUFFIX)(s, op, mode, src, a, out, partial, coarse, coarse_blocks, g0, g1))
       return true;
     if (mode < kPlain || (mode > kResidualRestrict && mode != kChebFirstProlong) || MGX_MACRO_PAIRS * (mode == kChebFirstProlong) ||
         (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)

@@ -247,7 +247,12 @@ namespace mgx
       }
   }
 
-  __host__ __device__ constexpr bool macro2_covers(int mode) { return mode == kPlain || mode == kResidual; }
+  // (residual + restriction at p >= 5, where a brick is the 8 children of one parent: the 40 registers of the right-hand
+  // side in flight across the sweeps cost more than the wait they remove -- 274 against 257 us per colour launch at p = 8)
+  __host__ __device__ constexpr bool macro2_covers(int mode, int p = 4)
+  {
+    return mode == kPlain || mode == kResidual || (mode == kResidualRestrict && p <= 4);
+  }
 
   template <int P, typename T, int MODE>
   __global__ void __launch_bounds__((M2Cfg<P, T>::THREADS), (M2Cfg<P, T>::MINW))
@@ -255,7 +260,7 @@ namespace mgx
                         const uint32_t *__restrict__ ent_base, const uint32_t *__restrict__ item_map,
                         const Basis1D<T> *__restrict__ B, T c0, T c1, T c2, BrickPost<T> post, uint32_t vec_bytes)
   {
-    static_assert(macro2_covers(MODE), "form not covered by this pipeline");
+    static_assert(macro2_covers(MODE, MODE == kResidualRestrict ? 4 : P), "form not covered by this pipeline");
     using C            = M2Cfg<P, T>;
     constexpr int NT   = C::THREADS, IT = C::IT, JINT = C::JINT, JSURF = C::JSURF, NE = C::NE;
     constexpr int NEW  = (NE + NT - 1) / NT; // entity words per thread
@@ -317,19 +322,40 @@ namespace mgx
         if (live(j))
           U[item_point(mw[j])] = g[j];
     };
-    // partial sums of the surface slots of the current brick (not FIRST: an earlier colour launch left a sum)
-    T    pp[JSURF];
-    auto partial_issue = [&]() {
+    // partial sums of the surface slots of the current brick (not FIRST: an earlier colour launch left a sum).  The
+    // residual + restriction form hands nothing over between the bricks (linear form, see post_finish in
+    // mgx_macro_device.hpp)
+    constexpr bool kCarrier = MODE != kResidualRestrict;
+    T              pp[JSURF];
+    auto           partial_issue = [&]() {
 #pragma unroll
       for (int j = JINT; j < IT; ++j)
         {
           pp[j - JINT] = T(0);
+          if (!kCarrier)
+            continue;
 #ifndef MGX_MACRO_NOCARRIER // diagnostic build (wrong results): what the launches cost without the carrier traffic
           const uint32_t w    = live(j) ? E[item_slot(mw[j])] : kInvalid;
           const bool     need = w != kInvalid && !(w & 0x40000000u);
           if (__builtin_amdgcn_ballot_w64(need) != 0) // whole waves of FIRST items skip the load
             pp[j - JINT] = buf_ld(r_partial, need ? unit_offset(w, mw[j]) : kOob, T());
 #endif
+        }
+    };
+
+    // right-hand side at the DoFs the current brick completes (residual forms), requested before the sweeps as well
+    constexpr bool kRhs = MODE != kPlain;
+    T              av[kRhs ? IT : 1];
+    auto           rhs_issue = [&]() {
+      if (kRhs)
+        {
+#pragma unroll
+          for (int j = 0; j < IT; ++j)
+            {
+              const uint32_t w    = live(j) ? E[item_slot(mw[j])] : kInvalid;
+              const bool     last = w != kInvalid && (j < JINT || (w >> 31));
+              av[kRhs ? j : 0]    = buf_ld(r_a, last ? unit_offset(w, mw[j]) : kOob, T());
+            }
         }
     };
 
@@ -358,6 +384,7 @@ namespace mgx
           MGX_STAMP(11);
 #endif
         partial_issue(); // in flight during the sweeps
+        rhs_issue();
         // keep what is derived from the item words (LDS addresses, offsets) out of the registers that live across
         // the sweeps: the compiler must not hoist it out of the brick loop
 #pragma unroll
@@ -379,10 +406,10 @@ namespace mgx
         MGX_STAMP_IT(8);
 
         // ---- write-out: assembled value (+ partial sum) -> result where the brick completes the DoF (LAST), else
-        //      -> carrier; the residual form loads its right-hand side for all slots at once ----
+        //      -> carrier.  Every operand is in registers: nothing here waits for memory.  Residual + restriction: the
+        //      brick's share of the residual stays in W (rows of constrained DoFs: zero) and is restricted below ----
         {
-          uint32_t w[IT], off[IT];
-          T        av[MODE == kResidual ? IT : 1];
+          uint32_t w[IT];
 #pragma unroll
           for (int j = 0; j < IT; ++j)
             w[j] = live(j) ? E[item_slot(mw[j])] : kInvalid;
@@ -392,31 +419,43 @@ namespace mgx
               // interior of the brick: complete after this brick, whatever the schedule says
               if (j < JINT && w[j] != kInvalid)
                 w[j] |= 0xC0000000u;
-              off[j] = unit_offset(w[j], mw[j]);
-              if (MODE == kResidual)
-                av[MODE == kResidual ? j : 0] = buf_ld(r_a, (w[j] != kInvalid && (w[j] >> 31)) ? off[j] : kOob, T());
-            }
-#pragma unroll
-          for (int j = 0; j < IT; ++j)
-            {
-              const bool vld = w[j] != kInvalid, last = vld && (w[j] >> 31);
-              T          val = live(j) ? W[item_point(mw[j])] : T(0);
-              if (j >= JINT)
+              const bool     vld = w[j] != kInvalid, last = vld && (w[j] >> 31);
+              const uint32_t off = unit_offset(w[j], mw[j]);
+              T              val = live(j) ? W[item_point(mw[j])] : T(0);
+              if (j >= JINT && kCarrier)
                 val += pp[j >= JINT ? j - JINT : 0]; // (out-of-range loads returned zero)
+              if (MODE == kResidualRestrict)
+                {
+                  // linear form: b on the points the brick completes minus its own share of A x on all its points
+                  if (live(j))
+                    W[item_point(mw[j])] = vld ? (last ? av[kRhs ? j : 0] : T(0)) - val : T(0);
+                  continue;
+                }
               if (MODE == kResidual && last)
-                val = av[MODE == kResidual ? j : 0] - val;
+                val = av[kRhs ? j : 0] - val;
               if (j < JINT)
-                buf_st<kAuxNt>(r_out, off[j], val);
+                buf_st<kAuxNt>(r_out, off, val);
               else
                 {
-                  buf_st<kAuxNt>(r_out, last ? off[j] : kOob, val);
+                  buf_st<kAuxNt>(r_out, last ? off : kOob, val);
 #ifndef MGX_MACRO_NOCARRIER
                   if (__builtin_amdgcn_ballot_w64(vld && !last) != 0) // whole waves of completed items skip the store
-                    buf_st(r_partial, last ? kOob : off[j], val);
+                    buf_st(r_partial, last ? kOob : off, val);
 #endif
                 }
             }
         }
+        if (MODE == kResidualRestrict)
+          {
+            constexpr int CE1 = C::NB + 1, CNP = (C::NB / 2) * P + 1; // coarse entities / points per direction of the parents
+            lds_barrier();
+            const uint32_t *ctab = post.coarse_blocks + (size_t)(brick_first + b) * (CE1 * CE1 * CE1);
+            if (post.coarse_scratch) // uniform
+              restrict_brick<P, T, NT, true>(tid, W, B->P1, nullptr, ctab,
+                                             post.coarse_scratch + (size_t)(brick_first + b) * (CNP * CNP * CNP));
+            else
+              restrict_brick<P, T, NT, false>(tid, W, B->P1, post.coarse, ctab);
+          }
         MGX_STAMP_IT(9);
         if (!has_next)
           break;
@@ -456,9 +495,18 @@ namespace mgx
   {
     using C             = M2Cfg<P, T>;
     const BrickData &bd = op.bricks;
+    // kResidualRestrict with a coarse scratch array: the bricks hand nothing to each other and write disjoint
+    // addresses -- one launch for all of them
+    const bool one_launch = MODE == kResidualRestrict && post.coarse_scratch != nullptr;
     for (int c = g0; c < g1; ++c)
       {
-        const uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
+        uint32_t first = bd.colour_start[c], count = bd.colour_start[c + 1] - first;
+        if (one_launch)
+          {
+            if (c != g0)
+              break;
+            count = bd.colour_start[g1] - first;
+          }
         if (count == 0)
           continue;
         // persistent workgroups: as many as are resident at once (WGS per CU)
@@ -474,23 +522,31 @@ namespace mgx
   {
     if (mode == kPlain)
       macro2_launch<P, T, kPlain>(s, op, src, post, g0, g1);
-    else
+    else if (mode == kResidual)
       macro2_launch<P, T, kResidual>(s, op, src, post, g0, g1);
+    else if constexpr (P <= 4)
+      macro2_launch<P, T, kResidualRestrict>(s, op, src, post, g0, g1);
   }
 
 #define MGX_CAT2(a, b) a##b
 #define MGX_CAT(a, b) MGX_CAT2(a, b)
   // false: form / degree / vector size not covered by this pipeline (the caller uses the first one)
+  // kResidualRestrict: `partial` names the per-brick scratch array of the restricted values (or nullptr: added into
+  // `coarse` colour by colour), coarse_blocks the coarse entity table of the bricks' parents
   bool MGX_CAT(launch_macro2_loop_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
-                                                      void *out, void *partial, int g0, int g1)
+                                                      void *out, void *partial, void *coarse, const uint32_t *coarse_blocks, int g0,
+                                                      int g1)
   {
     using T = MGX_MACRO_T;
-    if (!macro2_covers(mode) || !op.bricks.item_map2 || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
+    if (!macro2_covers(mode, op.p) || !op.bricks.item_map2 || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
       return false;
     BrickPost<T> post{};
-    post.a       = (const T *)a;
-    post.out     = (T *)out;
-    post.partial = (T *)partial;
+    post.a              = (const T *)a;
+    post.out            = (T *)out;
+    post.partial        = (T *)partial;
+    post.coarse         = (T *)coarse;
+    post.coarse_blocks  = coarse_blocks;
+    post.coarse_scratch = mode == kResidualRestrict ? (T *)partial : nullptr;
     switch (op.p)
       {
 #ifdef MGX_MACRO_ONLY_P

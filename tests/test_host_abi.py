@@ -163,3 +163,34 @@ def test_invalid_arguments(lib):
     assert lib.mgx_cube_create(0, 1, 1, C.byref(h)) == -1
     assert lib.mgx_cube_create(4, 1, 12, C.byref(h)) != 0
     assert lib.mgx_cube_create(9, 3, 8, C.byref(h)) == -4  # 32-bit DoF index overflow refused
+
+
+def test_shim_declares_the_reference_interface_and_compiles(tmp_path):
+    """include/multigrid_shim.hpp mirrors the public members of the reference classes on the hot path:
+    every one of them is declared, and a translation unit that calls all of them (tests/shim_check.cpp) compiles."""
+    import re
+    import subprocess
+    src = open(os.path.join(ROOT, "include", "multigrid_shim.hpp")).read()
+
+    def members(cls):
+        body = src[src.index("  class " + cls):]
+        body = body[:body.index("\n  };")]
+        return set(re.findall(r"\b([a-z_0-9]+)\(", body))
+    need = {
+        # common/laplace_operator.h:60-124
+        "LaplaceOperator": {"initialize", "clear", "vmult", "vmult_residual", "vmult_with_cg_update", "compute_residual",
+                            "evaluate_coefficient", "compute_diagonal", "get_matrix_diagonal_inverse", "m",
+                            "initialize_dof_vector"},
+        # common/multigrid_solver.h:100-637
+        "MultigridSolver": {"solve", "solve_cg", "vmult", "vmult_with_residual_update", "do_matvec", "do_matvec_smoother",
+                            "compute_l2_error", "get_solution", "print_wall_times"},
+        # common/laplace_operator_dg.h:350-2025, 2028-2256; common/multigrid_solver_dg.h:55-747
+        "LaplaceOperatorCompactCombine": {"reinit", "m", "initialize_dof_vector", "get_penalty", "vmult", "vmult_residual",
+                                          "vmult_with_cg_update", "vmult_with_chebyshev_update"},
+        "JacobiTransformed": {"m", "vmult"},
+        "MultigridSolverDG": {"vmult", "solve_cg"},
+    }
+    for cls, names in need.items():
+        assert names <= members(cls), (cls, names - members(cls))
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "shim_check.cpp")], check=True)
