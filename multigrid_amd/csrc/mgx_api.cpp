@@ -1804,6 +1804,7 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.bricks.fr.surf_start);
   (void)hipFree(op->d.bricks.fr.surf_pos);
   (void)hipFree(op->d.diag_items);
+  (void)hipFree(op->d.diag_items2);
   (void)hipFree(op->cg_partials);
   (void)hipFree(op->cg_result);
   (void)hipFree(op->cg_carrier);
@@ -2079,13 +2080,17 @@ int mgx_compute_diagonal(mgx_operator_t op)
   op->has_diag = true;
   // Is the diagonal the same for every brick (uniform mesh)?  Then the macro-element kernel keeps
   // it in registers instead of streaming it (mgx_macro.hip, DTAB).  MGX_NO_DIAG_TABLE=1: A/B timing.
-  if (op->d.diag_items)
+  for (int which = 0; which < 2; ++which) // the table in the item order of either pipeline of the macro-element kernel
     {
-      MGX_HIP(hipFree(op->d.diag_items));
-      op->d.diag_items = nullptr;
-    }
-  if (op->d.bricks.item_map && op->d.separable && !op->ctx->tun.no_diag_table)
-    {
+      void          *&slot = which == 0 ? op->d.diag_items : op->d.diag_items2;
+      const uint32_t *map  = which == 0 ? op->d.bricks.item_map : op->d.bricks.item_map2;
+      if (slot)
+        {
+          MGX_HIP(hipFree(slot));
+          slot = nullptr;
+        }
+      if (!map || !op->d.separable || op->ctx->tun.no_diag_table)
+        continue;
       const uint32_t nb = op->d.p <= 4 ? 4 : 2, g = nb * op->d.p + 1, npts = g * g * g;
       void          *table = nullptr;
       uint32_t      *flag  = nullptr, mismatch = 1;
@@ -2094,17 +2099,18 @@ int mgx_compute_diagonal(mgx_operator_t op)
       MGX_HIP(hipMemsetAsync(table, 0, number_size(op->d.number) * npts, s));
       MGX_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
       if (op->d.number == MGX_F64)
-        macro_diag_table_f64(s, op->d, table, flag);
+        macro_diag_table_f64(s, op->d, map, table, flag);
       else
-        macro_diag_table_f32(s, op->d, table, flag);
+        macro_diag_table_f32(s, op->d, map, table, flag);
       MGX_HIP(hipMemcpyAsync(&mismatch, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       MGX_HIP(hipStreamSynchronize(s));
       MGX_HIP(hipFree(flag));
       if (mismatch == 0)
-        op->d.diag_items = table;
+        slot = table;
       else
         MGX_HIP(hipFree(table));
-      MGX_TRACE("compute_diagonal: diagonal %s per brick item", mismatch == 0 ? "uniform" : "not uniform");
+      if (which == 0)
+        MGX_TRACE("compute_diagonal: diagonal %s per brick item", mismatch == 0 ? "uniform" : "not uniform");
     }
   return MGX_OK;
 }

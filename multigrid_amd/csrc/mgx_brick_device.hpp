@@ -202,6 +202,14 @@ namespace mgx
   __device__ __forceinline__ void restrict_half(const T *__restrict__ p1, const T (&r)[2 * P + 1], T (&o)[P + 1])
   {
     constexpr int N = P + 1, M = 2 * P + 1;
+    // The M x N coefficients are scalar operands (wave-uniform loads): in slices of a few outputs, so that no more than
+    // ~40 doubles of them are live at a time.  All 153 of p = 8 at once overflow the scalar register file and the compiler
+    // spills them lane by lane into vector registers -- round 4 found 5240 v_readlane + 1670 v_writelane among the 9500
+    // vector instructions per brick of the p = 8 residual + restriction kernel, three per multiply-add; with the slices
+    // 274 -> 174 us per colour launch (prolongation form 223 -> 201 us).  (The same fences inside the operator sweeps,
+    // whose two even-odd matrices overflow the file at p = 8 as well -- ~600 lane moves per brick -- cost more in lost
+    // scheduling freedom than the moves: plain form 106 -> 115 us; not kept.)
+    constexpr int JC = (40 / M) < 1 ? 1 : 40 / M;
 #pragma unroll
     for (int j = 0; j < N; ++j)
       {
@@ -210,6 +218,11 @@ namespace mgx
         for (int a = 1; a < M; ++a)
           s = fma(p1[a * N + j], r[a], s);
         o[j] = s;
+        if (M * N > 48 && (j + 1) % JC == 0)
+          {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
       }
   }
 
@@ -356,6 +369,7 @@ namespace mgx
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
       {
+        constexpr int AC = (40 / N) < 1 ? 1 : 40 / N; // rows of the embedding per slice of scalar operands, as above
 #pragma unroll
         for (int a = (pb == 0 ? 0 : 1); a < M; ++a)
           {
@@ -364,6 +378,11 @@ namespace mgx
             for (int i = 1; i < N; ++i)
               s = fma(p1[a * N + i], c[pb * P + i], s);
             f[pb * 2 * P + a] = s;
+            if (M * N > 48 && (a + 1) % AC == 0)
+              {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+              }
           }
       }
   }

@@ -164,6 +164,7 @@ namespace mgx
     // every brick (uniform mesh), else nullptr: the macro-element kernel then reads it from
     // registers instead of streaming inv_diag (mgx_macro.hip, DTAB)
     void     *diag_items    = nullptr;
+    void     *diag_items2   = nullptr; // ... in the order of bricks.item_map2 (second pipeline)
     bool      macro_v2      = true;    // !Tunables::no_macro_v2
   };
 
@@ -289,13 +290,15 @@ namespace mgx
                                   void *p, void *x, void *carrier, double *partials, uint32_t capacity,
                                   uint32_t *n_partials);
   void launch_reduce4(hipStream_t s, const double *partials, uint32_t n, const double *extra, double *sums);
-  void macro_diag_table_f64(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
-  void macro_diag_table_f32(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev);
+  void macro_diag_table_f64(hipStream_t s, const OperatorData &op, const uint32_t *item_map, void *table, uint32_t *flag_dev);
+  void macro_diag_table_f32(hipStream_t s, const OperatorData &op, const uint32_t *item_map, void *table, uint32_t *flag_dev);
   // second pipeline (mgx_macro2.hip: plain, residual, residual + restriction); false: form / degree not covered, use the first
   bool launch_macro2_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a, void *out,
-                              void *partial, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
+                              void *partial, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end,
+                              double f1, double f2, double f0, const void *old);
   bool launch_macro2_loop_f32(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a, void *out,
-                              void *partial, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end);
+                              void *partial, void *coarse, const uint32_t *coarse_blocks, int group_begin, int group_end,
+                              double f1, double f2, double f0, const void *old);
   // true: the brick loop evaluates the separable form (7 sweeps); false: the general
   // quadrature-point form of laplace_operator.h:436-523 (12 sweeps)
   // diag += diagonal of the cell matrices (local_compute_diagonal, laplace_operator.h:770-800)

@@ -951,15 +951,16 @@ namespace mgx
 #define MGX_CAT(a, b) MGX_CAT2(a, b)
   // builds the table into `table` (device, (NB p + 1)^3 values, zero-initialised by the caller);
   // *flag_dev (device, zero-initialised) is nonzero afterwards if the diagonal is not periodic
-  void MGX_CAT(macro_diag_table_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, void *table, uint32_t *flag_dev)
+  void MGX_CAT(macro_diag_table_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, const uint32_t *item_map, void *table,
+                                                    uint32_t *flag_dev)
   {
     using T             = MGX_MACRO_T;
     const BrickData &bd = op.bricks;
     const uint32_t   nb = op.p <= 4 ? 4 : 2, g = nb * op.p + 1, npts = g * g * g, e1 = 2 * nb + 1, ne = e1 * e1 * e1;
     hipLaunchKernelGGL((diag_table_kernel<T, false>), dim3(bd.n_bricks), dim3(256), 0, s, (const T *)op.inv_diag,
-                       bd.ent_base, bd.item_map, ne, npts, (T *)table, flag_dev);
+                       bd.ent_base, item_map, ne, npts, (T *)table, flag_dev);
     hipLaunchKernelGGL((diag_table_kernel<T, true>), dim3(bd.n_bricks), dim3(256), 0, s, (const T *)op.inv_diag,
-                       bd.ent_base, bd.item_map, ne, npts, (T *)table, flag_dev);
+                       bd.ent_base, item_map, ne, npts, (T *)table, flag_dev);
   }
 
   // vmult_with_cg_update on a brick-scheduled level of one rank (mgx_api.cpp handles the rest):
@@ -1046,9 +1047,9 @@ namespace mgx
     const bool fr = free_schedule && op.bricks.fr.available() && mode <= kChebOldInit && !MGX_MACRO_PAIRS;
     if (free_schedule && !fr)
       return false;
-    // the forms the second pipeline covers (mgx_macro2.hip: plain, residual, residual + restriction) on the eight-colour schedule
+    // the forms the second pipeline covers (mgx_macro2.hip) on the eight-colour schedule
     if (!free_schedule && op.macro_v2 && !MGX_MACRO_PAIRS &&
-        MGX_CAT(launch_macro2_loop_, MGX_MACRO_SUFFIX)(s, op, mode, src, a, out, partial, coarse, coarse_blocks, g0, g1))
+        MGX_CAT(launch_macro2_loop_, MGX_MACRO_SUFFIX)(s, op, mode, src, a, out, partial, coarse, coarse_blocks, g0, g1, f1, f2, f0, old))
       return true;
     if (mode < kPlain || (mode > kResidualRestrict && mode != kChebFirstProlong) || MGX_MACRO_PAIRS * (mode == kChebFirstProlong) ||
         (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)

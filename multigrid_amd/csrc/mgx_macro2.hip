@@ -36,6 +36,11 @@
 #ifndef MGX_MACRO_T
 #define MGX_MACRO_T double
 #endif
+// value slots per chunk of the write-out of the Chebyshev forms (operands of chunk c + 1 requested before chunk c is
+// computed and stored)
+#ifndef MGX_MACRO2_CHUNK
+#define MGX_MACRO2_CHUNK 3
+#endif
 
 #ifdef MGX_MACRO_STAMPS
 // Diagnostic build only (make stamps): thread 0 of every workgroup records s_memtime at the phase boundaries of its
@@ -249,9 +254,14 @@ namespace mgx
 
   // (residual + restriction at p >= 5, where a brick is the 8 children of one parent: the 40 registers of the right-hand
   // side in flight across the sweeps cost more than the wait they remove -- 274 against 257 us per colour launch at p = 8)
+  // Of the Chebyshev forms the two that never store the first iterate (kChebInit, kChebOldInit) run here, with the inverse
+  // diagonal taken from the per-item table (uniform meshes; where it has to be streamed they stay on the first
+  // pipeline): 119 -> 116 and 133 -> 126 us per colour launch.  The general iteration (kCheb: 144 -> 148 us) and its
+  // two special cases gain nothing from the earlier partial sums -- their write-out waits for b and x_old either way --
+  // and stay on the first pipeline.
   __host__ __device__ constexpr bool macro2_covers(int mode, int p = 4)
   {
-    return mode == kPlain || mode == kResidual || (mode == kResidualRestrict && p <= 4);
+    return mode == kPlain || mode == kResidual || (mode == kResidualRestrict && p <= 4) || mode == kChebInit || mode == kChebOldInit;
   }
 
   template <int P, typename T, int MODE>
@@ -283,8 +293,18 @@ namespace mgx
     for (int j = 0; j < IT; ++j)
       mw[j] = item_map[live(j) ? tid + j * NT : 0];
     const rsrc_t rsrc = make_rsrc(src, vec_bytes), r_a = make_rsrc(post.a, vec_bytes), r_out = make_rsrc(post.out, vec_bytes),
-                 r_partial = make_rsrc(post.partial, vec_bytes);
+                 r_partial = make_rsrc(post.partial, vec_bytes), r_old = make_rsrc(post.old, vec_bytes);
     const EOMat<T> &M = B->mass, &K = B->lapl;
+    // the fused Chebyshev forms keep the source value of every item for the update and the inverse diagonal of the
+    // thread's items (post.b = the per-item table in the order of this pipeline's item map) for all bricks
+    constexpr bool kKeepX = is_cheb_mode(MODE);
+    T              dv[kKeepX ? IT : 1];
+    if (kKeepX)
+      {
+#pragma unroll
+        for (int j = 0; j < IT; ++j)
+          dv[kKeepX ? j : 0] = post.b[live(j) ? tid + j * NT : 0];
+      }
 
     uint32_t en[NEW] = {}; // entity table words of the next brick
     auto     table_load = [&](uint32_t brick, uint32_t(&e)[NEW]) {
@@ -312,15 +332,23 @@ namespace mgx
       for (int j = 0; j < IT; ++j)
         {
           g[j] = T(0);
-          if (live(j))
-            g[j] = buf_ld(rsrc, unit_offset(tab[item_slot(mw[j])], mw[j]), T());
+          if (live(j)) // (kChebInit gathers the right-hand side: x_1 = f0 D^-1 b is formed while landing)
+            g[j] = buf_ld(MODE == kChebInit ? r_a : rsrc, unit_offset(tab[item_slot(mw[j])], mw[j]), T());
         }
     };
+    T    xs[kKeepX ? IT : 1];
     auto gather_land = [&]() {
 #pragma unroll
       for (int j = 0; j < IT; ++j)
-        if (live(j))
-          U[item_point(mw[j])] = g[j];
+        {
+          T v = g[j];
+          if (MODE == kChebInit)
+            v = post.f0 * dv[kKeepX ? j : 0] * g[j];
+          if (live(j))
+            U[item_point(mw[j])] = v;
+          if (kKeepX)
+            xs[kKeepX ? j : 0] = v;
+        }
     };
     // partial sums of the surface slots of the current brick (not FIRST: an earlier colour launch left a sum).  The
     // residual + restriction form hands nothing over between the bricks (linear form, see post_finish in
@@ -344,7 +372,7 @@ namespace mgx
     };
 
     // right-hand side at the DoFs the current brick completes (residual forms), requested before the sweeps as well
-    constexpr bool kRhs = MODE != kPlain;
+    constexpr bool kRhs = MODE == kResidual || MODE == kResidualRestrict;
     T              av[kRhs ? IT : 1];
     auto           rhs_issue = [&]() {
       if (kRhs)
@@ -390,6 +418,12 @@ namespace mgx
 #pragma unroll
         for (int j = 0; j < IT; ++j)
           asm volatile("" : "+v"(mw[j]));
+        if (MODE == kChebInit || MODE == kChebOldInit) // likewise f0 * dv
+          {
+#pragma unroll
+            for (int j = 0; j < IT; ++j)
+              asm volatile("" : "+v"(dv[kKeepX ? j : 0]));
+          }
         MGX_STAMP_IT(4);
 #ifndef MGX_MACRO_NOSWEEP // diagnostic build without the sweeps (wrong results): memory phases alone
         brick_sweeps<P, T>(tid, U, W, M, K, c0, c1, c2, [&](int k) { MGX_STAMP_IT(5 + k); });
@@ -405,46 +439,122 @@ namespace mgx
           }
         MGX_STAMP_IT(8);
 
-        // ---- write-out: assembled value (+ partial sum) -> result where the brick completes the DoF (LAST), else
-        //      -> carrier.  Every operand is in registers: nothing here waits for memory.  Residual + restriction: the
-        //      brick's share of the residual stays in W (rows of constrained DoFs: zero) and is restricted below ----
-        {
-          uint32_t w[IT];
-#pragma unroll
-          for (int j = 0; j < IT; ++j)
-            w[j] = live(j) ? E[item_slot(mw[j])] : kInvalid;
-#pragma unroll
-          for (int j = 0; j < IT; ++j)
+        if constexpr (kKeepX)
+          {
+            // ---- write-out of the Chebyshev forms: x_new = x + f2 D^-1 (b - A x) [+ f1 (x - x_old)] where the brick
+            //      completes the DoF, the partial sum to the carrier elsewhere.  The operands b (and x_old) are requested
+            //      in chunks, one chunk ahead of the stores; the partial sums are in registers already ----
+            constexpr int kChunk = MGX_MACRO2_CHUNK < IT ? MGX_MACRO2_CHUNK : IT, NCH = (IT + kChunk - 1) / kChunk;
+            struct Ops
             {
-              // interior of the brick: complete after this brick, whatever the schedule says
-              if (j < JINT && w[j] != kInvalid)
-                w[j] |= 0xC0000000u;
-              const bool     vld = w[j] != kInvalid, last = vld && (w[j] >> 31);
-              const uint32_t off = unit_offset(w[j], mw[j]);
-              T              val = live(j) ? W[item_point(mw[j])] : T(0);
-              if (j >= JINT && kCarrier)
-                val += pp[j >= JINT ? j - JINT : 0]; // (out-of-range loads returned zero)
-              if (MODE == kResidualRestrict)
+              T        av, ov;
+              uint32_t w, off;
+            };
+            Ops  ops[2][kChunk];
+            auto issue = [&](int c, Ops(&o)[kChunk]) {
+#pragma unroll
+              for (int k = 0; k < kChunk; ++k)
                 {
-                  // linear form: b on the points the brick completes minus its own share of A x on all its points
-                  if (live(j))
-                    W[item_point(mw[j])] = vld ? (last ? av[kRhs ? j : 0] : T(0)) - val : T(0);
-                  continue;
+                  const int j = c * kChunk + k;
+                  if (j < IT)
+                    o[k].w = live(j) ? E[item_slot(mw[j])] : kInvalid;
                 }
-              if (MODE == kResidual && last)
-                val = av[kRhs ? j : 0] - val;
-              if (j < JINT)
-                buf_st<kAuxNt>(r_out, off, val);
-              else
+#pragma unroll
+              for (int k = 0; k < kChunk; ++k)
                 {
-                  buf_st<kAuxNt>(r_out, last ? off : kOob, val);
+                  const int j = c * kChunk + k;
+                  if (j >= IT)
+                    continue;
+                  if (j < JINT && o[k].w != kInvalid)
+                    o[k].w |= 0xC0000000u;
+                  const bool last  = o[k].w != kInvalid && (o[k].w >> 31);
+                  o[k].off         = unit_offset(o[k].w, mw[j]);
+                  const uint32_t ol = last ? o[k].off : kOob;
+                  o[k].av          = buf_ld(r_a, ol, T());
+                  o[k].ov          = MODE == kCheb ? buf_ld(r_old, ol, T()) : T(0);
+                }
+            };
+            issue(0, ops[0]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+              {
+                if (c + 1 < NCH)
+                  issue(c + 1, ops[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                T val[kChunk];
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k)
+                  {
+                    const int j = c * kChunk + k;
+                    val[k]      = (j < IT && live(j)) ? W[item_point(mw[j])] : T(0);
+                  }
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k)
+                  {
+                    const int j = c * kChunk + k;
+                    if (j >= IT)
+                      continue;
+                    const Ops &o   = ops[c & 1][k];
+                    const bool vld = o.w != kInvalid, last = vld && (o.w >> 31);
+                    const T    res = post_finish<T, MODE>(post, j >= JINT ? pp[j >= JINT ? j - JINT : 0] : T(0), o.av, o.ov,
+                                                          dv[kKeepX ? j : 0], last, val[k], xs[kKeepX ? j : 0]);
+                    if (j < JINT)
+                      buf_st(r_out, o.off, res);
+                    else
+                      {
+                        buf_st(r_out, last ? o.off : kOob, res);
 #ifndef MGX_MACRO_NOCARRIER
-                  if (__builtin_amdgcn_ballot_w64(vld && !last) != 0) // whole waves of completed items skip the store
-                    buf_st(r_partial, last ? kOob : off, val);
+                        if (__builtin_amdgcn_ballot_w64(vld && !last) != 0)
+                          buf_st(r_partial, last ? kOob : o.off, res);
 #endif
-                }
-            }
-        }
+                      }
+                  }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+        else
+          {
+          // ---- write-out: assembled value (+ partial sum) -> result where the brick completes the DoF (LAST), else
+          //      -> carrier.  Every operand is in registers: nothing here waits for memory.  Residual + restriction: the
+          //      brick's share of the residual stays in W (rows of constrained DoFs: zero) and is restricted below ----
+          {
+            uint32_t w[IT];
+  #pragma unroll
+            for (int j = 0; j < IT; ++j)
+              w[j] = live(j) ? E[item_slot(mw[j])] : kInvalid;
+  #pragma unroll
+            for (int j = 0; j < IT; ++j)
+              {
+                // interior of the brick: complete after this brick, whatever the schedule says
+                if (j < JINT && w[j] != kInvalid)
+                  w[j] |= 0xC0000000u;
+                const bool     vld = w[j] != kInvalid, last = vld && (w[j] >> 31);
+                const uint32_t off = unit_offset(w[j], mw[j]);
+                T              val = live(j) ? W[item_point(mw[j])] : T(0);
+                if (j >= JINT && kCarrier)
+                  val += pp[j >= JINT ? j - JINT : 0]; // (out-of-range loads returned zero)
+                if (MODE == kResidualRestrict)
+                  {
+                    // linear form: b on the points the brick completes minus its own share of A x on all its points
+                    if (live(j))
+                      W[item_point(mw[j])] = vld ? (last ? av[kRhs ? j : 0] : T(0)) - val : T(0);
+                    continue;
+                  }
+                if (MODE == kResidual && last)
+                  val = av[kRhs ? j : 0] - val;
+                if (j < JINT)
+                  buf_st<kAuxNt>(r_out, off, val);
+                else
+                  {
+                    buf_st<kAuxNt>(r_out, last ? off : kOob, val);
+  #ifndef MGX_MACRO_NOCARRIER
+                    if (__builtin_amdgcn_ballot_w64(vld && !last) != 0) // whole waves of completed items skip the store
+                      buf_st(r_partial, last ? kOob : off, val);
+  #endif
+                  }
+              }
+          }
+          }
         if (MODE == kResidualRestrict)
           {
             constexpr int CE1 = C::NB + 1, CNP = (C::NB / 2) * P + 1; // coarse entities / points per direction of the parents
@@ -520,12 +630,18 @@ namespace mgx
   template <int P, typename T>
   static void macro2_modes(hipStream_t s, const OperatorData &op, int mode, const T *src, const BrickPost<T> &post, int g0, int g1)
   {
-    if (mode == kPlain)
-      macro2_launch<P, T, kPlain>(s, op, src, post, g0, g1);
-    else if (mode == kResidual)
-      macro2_launch<P, T, kResidual>(s, op, src, post, g0, g1);
-    else if constexpr (P <= 4)
-      macro2_launch<P, T, kResidualRestrict>(s, op, src, post, g0, g1);
+    switch (mode)
+      {
+        case kPlain: macro2_launch<P, T, kPlain>(s, op, src, post, g0, g1); break;
+        case kResidual: macro2_launch<P, T, kResidual>(s, op, src, post, g0, g1); break;
+        case kChebInit: macro2_launch<P, T, kChebInit>(s, op, src, post, g0, g1); break;
+        case kChebOldInit: macro2_launch<P, T, kChebOldInit>(s, op, src, post, g0, g1); break;
+        case kResidualRestrict:
+          if constexpr (P <= 4)
+            macro2_launch<P, T, kResidualRestrict>(s, op, src, post, g0, g1);
+          break;
+        default: break;
+      }
   }
 
 #define MGX_CAT2(a, b) a##b
@@ -535,12 +651,19 @@ namespace mgx
   // `coarse` colour by colour), coarse_blocks the coarse entity table of the bricks' parents
   bool MGX_CAT(launch_macro2_loop_, MGX_MACRO_SUFFIX)(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,
                                                       void *out, void *partial, void *coarse, const uint32_t *coarse_blocks, int g0,
-                                                      int g1)
+                                                      int g1, double f1, double f2, double f0, const void *old)
   {
     using T = MGX_MACRO_T;
     if (!macro2_covers(mode, op.p) || !op.bricks.item_map2 || (uint64_t)op.n_dofs * sizeof(T) >= 0xFFFFFFF0ull)
       return false;
+    if (is_cheb_mode(mode) && !op.diag_items2) // inverse diagonal not uniform per item: streamed by the first pipeline
+      return false;
     BrickPost<T> post{};
+    post.b   = (const T *)op.diag_items2;
+    post.old = (const T *)old;
+    post.f1  = (T)f1;
+    post.f2  = (T)f2;
+    post.f0  = (T)f0;
     post.a              = (const T *)a;
     post.out            = (T *)out;
     post.partial        = (T *)partial;

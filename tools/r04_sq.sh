@@ -2,6 +2,7 @@
 # SQ / TA / TCP / TCC counters of the macro-element kernels, one rocprofv3 --pmc pass per counter set (no trace domains
 # next to --pmc).  usage: tools/r04_sq.sh <tag> <match> <matvec_loop.py arguments...>     -> gpurun_out/r04/sq_<tag>.txt
 # MGX_LIB_PATH / MATVEC_OPTS select the library variant / context options.
+# (a pass with TA_* counters aborted rocprofv3 on this pool and is left out)
 tag=$1; match=$2; shift; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04/sq_$tag; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -12,7 +13,6 @@ sets=(
  "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_IFETCH"
  "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
  "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TOTAL_CACHE_ACCESSES_sum"
- "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_TOTAL_CYCLES_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_STALL_sum"
  "GRBM_GUI_ACTIVE GRBM_TA_BUSY"
 )
@@ -20,7 +20,8 @@ files=""
 i=0
 for set in "${sets[@]}"; do
   i=$((i + 1)); rm -rf $O/p$i
-  if rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o t -- python3 $R/tools/matvec_loop.py "$@" > $O/p$i.log 2>&1; then
+  echo "pass $i: $set"
+  if timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o t -- python3 $R/tools/matvec_loop.py "$@" > $O/p$i.log 2>&1; then
     f=$(find $O/p$i -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && files="$files $f"
   else
