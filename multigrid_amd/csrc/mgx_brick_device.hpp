@@ -197,19 +197,32 @@ namespace mgx
   // coarse vector through the coarse entity table of the brick.  Bricks of one colour launch are
   // not adjacent, so their parents share no coarse DoF: plain read-modify-write.
   // ------------------------------------------------------------------------------------------
+  // Scalar operands of a transfer line product in slices: called after row / column k of an M x N block of the embedding
+  // whose rows (columns) hold ROW coefficients, it keeps the loads of the next slice behind the products of this one, so
+  // that no more than ~40 doubles of coefficients are live at a time.  Without it the compiler loads the whole block
+  // ahead, overflows the scalar register file (~100 registers, two per double) and spills it lane by lane into vector
+  // registers: round 4 found three v_readlane per multiply-add in the p = 8 kernels (5240 + 1670 lane moves among the
+  // 9500 vector instructions per brick of the residual + restriction form).  Blocks of up to 48 coefficients fit.
+  template <int ROW, int TOTAL>
+  __device__ __forceinline__ void scalar_operand_slice(int k)
+  {
+    constexpr int C = (40 / ROW) < 1 ? 1 : 40 / ROW;
+    if (TOTAL > 48 && (k + 1) % C == 0)
+      {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+
   // one parent's part of a line: o[j] = sum_a P1[a][j] r[a], a over the 2p+1 fine points of parent pb
   template <int P, typename T>
   __device__ __forceinline__ void restrict_half(const T *__restrict__ p1, const T (&r)[2 * P + 1], T (&o)[P + 1])
   {
     constexpr int N = P + 1, M = 2 * P + 1;
-    // The M x N coefficients are scalar operands (wave-uniform loads): in slices of a few outputs, so that no more than
-    // ~40 doubles of them are live at a time.  All 153 of p = 8 at once overflow the scalar register file and the compiler
-    // spills them lane by lane into vector registers -- round 4 found 5240 v_readlane + 1670 v_writelane among the 9500
-    // vector instructions per brick of the p = 8 residual + restriction kernel, three per multiply-add; with the slices
-    // 274 -> 174 us per colour launch (prolongation form 223 -> 201 us).  (The same fences inside the operator sweeps,
-    // whose two even-odd matrices overflow the file at p = 8 as well -- ~600 lane moves per brick -- cost more in lost
-    // scheduling freedom than the moves: plain form 106 -> 115 us; not kept.)
-    constexpr int JC = (40 / M) < 1 ? 1 : 40 / M;
+    // (scalar_operand_slice: with the slices 274 -> 174 us per colour launch of the p = 8 residual + restriction form,
+    // prolongation form 223 -> 201 us.  The same fences inside the operator sweeps, whose two even-odd matrices overflow
+    // the scalar file at p = 8 as well -- ~600 lane moves per brick -- cost more in lost scheduling freedom than the
+    // moves: plain form 106 -> 115 us; not kept.)
 #pragma unroll
     for (int j = 0; j < N; ++j)
       {
@@ -218,11 +231,7 @@ namespace mgx
         for (int a = 1; a < M; ++a)
           s = fma(p1[a * N + j], r[a], s);
         o[j] = s;
-        if (M * N > 48 && (j + 1) % JC == 0)
-          {
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-          }
+        scalar_operand_slice<M, M * N>(j);
       }
   }
 
@@ -369,7 +378,6 @@ namespace mgx
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
       {
-        constexpr int AC = (40 / N) < 1 ? 1 : 40 / N; // rows of the embedding per slice of scalar operands, as above
 #pragma unroll
         for (int a = (pb == 0 ? 0 : 1); a < M; ++a)
           {
@@ -378,11 +386,7 @@ namespace mgx
             for (int i = 1; i < N; ++i)
               s = fma(p1[a * N + i], c[pb * P + i], s);
             f[pb * 2 * P + a] = s;
-            if (M * N > 48 && (a + 1) % AC == 0)
-              {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-              }
+            scalar_operand_slice<N, M * N>(a);
           }
       }
   }
