@@ -35,7 +35,7 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (datasheet); tools/microbenc
 # executed by the macro-element brick kernel at p = 4: 289 lines x 628 fp64 instructions (ISA count of
 # the three sweeps: 158 + 279 + 191, ~80 % of them FMA = 2 flop) per 4096-DoF brick (dense 12-sweep form: 270)
 FLOP_PER_DOF_P4 = 80.0
-TRAFFIC_FILES = {(4, 128): "r03_pmc_traffic_128cube_p4.json", (8, 64): "r03_pmc_traffic_64cube_p8.json"}
+TRAFFIC_FILES = {(4, 128): "r04_pmc_traffic_128cube_p4.json", (8, 64): "r04_pmc_traffic_64cube_p8.json"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
 
 
@@ -308,17 +308,18 @@ def spawn(args):
     """`python bench.py --gpus N` outside a launcher: start N fresh child processes (this parent never
     touches the GPU and never replaces itself), give each its rank environment, relay rank 0's JSON
     line, fail if any rank fails."""
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    import tempfile
+    # The ranks meet through a file (torch.distributed "file://" rendezvous, MGX_BENCH_INIT_FILE): no port is picked by
+    # a process that does not keep it (a socket bound and closed here could be taken by someone else before rank 0 binds
+    # it).  MASTER_ADDR / MASTER_PORT are set for code that looks at them, but nothing listens there.
+    rendezvous = os.path.join(tempfile.mkdtemp(prefix="mgx_bench_"), "rendezvous")
     one_gpu = os.environ.get("MGX_BENCH_BACKEND", "nccl") != "nccl" or args.dry_run
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29500", MGX_BENCH_INIT_FILE=rendezvous)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # host-side table construction is OpenMP code: every rank gets its share of the cores
         env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // args.gpus))))
@@ -352,6 +353,8 @@ def spawn(args):
                     p.kill()
             break
     codes = [p.wait() for p in procs]
+    import shutil
+    shutil.rmtree(os.path.dirname(rendezvous), ignore_errors=True)
     if out is None:
         out, _ = procs[0].communicate()
     sys.stdout.write(out.decode())
@@ -421,10 +424,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under "
                          "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     dist = None
+    # started by spawn(): file rendezvous; under torch.distributed.run: the launcher's environment
+    init_file = os.environ.get("MGX_BENCH_INIT_FILE")
+    init_kw = dict(init_method="file://" + init_file, rank=rank, world_size=world) if init_file else {}
     if args.dry_run:
         if world > 1:
             import torch.distributed as dist
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **init_kw)
         dry_run(args, rank, world, dist)
         if dist is not None:
             dist.destroy_process_group()
@@ -435,10 +441,10 @@ def main():
         backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")  # "gloo": functional test on one GPU
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **init_kw)
         else:
             local_rank = 0
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **init_kw)
 
     import numpy as np
 

@@ -87,6 +87,26 @@ def test_cell_by_cell_brick_kernel(monkeypatch, p, ns, nr, wide_max):
     ctx.close()
 
 
+def test_cell_by_cell_brick_kernel_in_the_crosscheck_library():
+    """The six cases above need the cell-by-cell kernels, which the production library does not carry: they run here
+    against multigrid_amd/libmgx_crosscheck.so (built by __graft_entry__.build(): make crosscheck) in ONE child process
+    (a process loads one build of the library)."""
+    import os
+    import subprocess
+    import sys
+    if mg._lib.load().mgx_has_cells_form():
+        pytest.skip("this process already runs the cross-check library")
+    lib = os.path.join(os.path.dirname(mg._lib.LIB_PATH), "libmgx_crosscheck.so")
+    if not os.path.exists(lib):
+        pytest.skip("libmgx_crosscheck.so not built (make -C multigrid_amd/csrc crosscheck)")
+    env = dict(os.environ, MGX_LIB_PATH=lib)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k",
+                          "test_cell_by_cell_brick_kernel and not crosscheck", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, timeout=900)
+    tail = out.stdout.decode()[-600:]
+    assert out.returncode == 0 and "6 passed" in tail, tail
+
+
 @pytest.mark.parametrize("p,nr", [(4, 2), (4, 3), (2, 4)])
 def test_operator_from_foreign_tables(ctx, p, nr):
     """Drop-in scenario: tables come from the caller (here: the oracle's own arrays), not from

@@ -23,7 +23,15 @@ l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
 x = ctx.vector(cube.n_dofs(l), data=cube.seeded_vector(l, 42))
 y = ctx.vector(cube.n_dofs(l))
-if mode == "vmult":
+if mode == "calib":
+    # streaming kernels with known byte counts on finest-level vectors only: the calibration of the traffic counters
+    # (tools/make_traffic_json.py)
+    lib, nd = ctx.lib, cube.n_dofs(l)
+    for _ in range(n):
+        mg.check(lib.mgx_copy_cast(ctx.h, y.ptr, mg.F64, x.ptr, mg.F64, nd))
+        mg.check(lib.mgx_sadd(ctx.h, mg.F64, y.ptr, 0.5, 0.25, x.ptr, nd))
+        ctx.dot(x, y)
+elif mode == "vmult":
     for _ in range(n):
         op.vmult(y, x)
 elif mode == "all":
