@@ -409,7 +409,14 @@ int mgx_solver_vmult(mgx_solver_t solver, double *dst, const double *src);
  * communicator).  Per V-cycle the defect of `level` is summed over the ranks into coarse's defect
  * (each DoF by its owner: owned[i] != 0), coarse runs its V-cycle, and every rank reads back the
  * correction of its DoFs through local_to_global[i] (the DoF of coarse's level `level` that local
- * DoF i is).  The finest level always stays decomposed.  The arrays are host memory, copied. */
+ * DoF i is).  The finest level always stays decomposed.  The arrays are host memory, copied.
+ * `coarse` may have MORE levels than level + 1: its finest level is the seam, i.e. level `level` of `solver` (a hierarchy
+ * whose level 0 is level k of the whole mesh, mgx_cube_level_offset: the k coarsest levels then exist on `coarse` only,
+ * and mgx_solver_solve starts from coarse's own full multigrid cycle, whose right-hand sides must be those of the same
+ * problem).
+ * Ownership: `coarse` and its context stay the caller's, but from this call on the coarse context runs on `solver`'s
+ * stream (its own stream is destroyed): it must not host other solvers, must be used only through `solver`, and
+ * must be destroyed BEFORE solver's context (the Python binding closes them in that order). */
 int mgx_solver_set_agglomeration(mgx_solver_t solver, int level, mgx_solver_t coarse, const uint32_t *local_to_global,
                                  const uint8_t *owned, uint32_t n_local);
 /* MultigridSolver::vmult_with_residual_update(residual, update, factor) :516-619: the V-cycle

@@ -91,12 +91,18 @@ int mgx_cube_create_box(const mgx_cube_box_desc *desc, mgx_cube_t *cube);
  * The multiplicities of the transfer are not powers of two where three blocks meet: levels carry no
  * weight_shift, mgx_transfer_create derives owner weights. */
 int mgx_cube_create_shell(int degree, int n_coarse, int n_refine, int problem, mgx_cube_t *cube);
-/* The same distributed over n_ranks <= n_coarse ranks (equal shares where n_ranks divides n_coarse, else one cell more
- * on some ranks -- 12 cells on 8 ranks: 1, 2, 1, 2, ...): rank r owns the coarse cells
- * [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks) with everything refined from them; DoFs on faces between
- * coarse cells of different ranks are duplicated and exchanged like the interface DoFs of the block-split cube
- * (mgx_cube_exchange_desc). */
+/* The same distributed over ranks (the reference partitions the refined mesh cell by cell,
+ * poisson_shell/program.cc:249,274).  Where n_ranks divides n_coarse, rank r owns the coarse cells
+ * [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks) with everything refined from them.  Otherwise, where the mesh is
+ * refined at least once and n_ranks divides 8 n_coarse (8 ranks: 6 of the 48 / 12 of the 96 cells of level 1 each), the
+ * cells of LEVEL 1 are dealt out the same way: level i of the object is then level i + 1 of the whole mesh
+ * (mgx_cube_level_offset() == 1, mgx_cube_n_levels() == n_refine), and the coarse cells exist only on the undecomposed
+ * copy of the coarse levels every rank keeps (mgx_solver_set_agglomeration, mgx_solver_set_coarse_start).  Neither:
+ * uneven shares of coarse cells (n_ranks <= n_coarse).  DoFs on faces between cells of different ranks are duplicated
+ * and exchanged like the interface DoFs of the block-split cube (mgx_cube_exchange_desc). */
 int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int problem, int n_ranks, int rank, mgx_cube_t *cube);
+/* level of the whole mesh that level 0 of this object is (0 except for the level-1 partition above) */
+int mgx_cube_level_offset(mgx_cube_t cube);
 /* multi-block meshes: the physical Gauss-Lobatto points of every cell of a level,
  * out[cell][3][(p+1)^3], and the number of cells around each of the 27 entities of every cell
  * (what deal.II's mesh would tell a caller) */

@@ -417,7 +417,11 @@ class Cube:
             self.degree = degree
             self.n_levels = self.lib.mgx_cube_n_levels(h)
             self.max_level = self.n_levels - 1
+            # level i of this object is level i + level_offset of the whole mesh (1 where the cells of level 1 are
+            # dealt out to the ranks: 8 ranks hold 6 of 48 / 12 of 96 cells each)
+            self.level_offset = self.lib.mgx_cube_level_offset(h)
             return
+        self.level_offset = 0
         self.box_desc = None if box is None else dict(box=tuple(box), origin=origin, h0=h0, geometry=geometry,
                                                         problem=problem, numbering=numbering)
         if box is None:
@@ -726,8 +730,8 @@ class MultigridSolver:
         self.max_level = self.n_levels - 1
         self.h = C.c_void_p(self.s.solver)
         self.coarse = None
-        if cube.size > 1 and (cube.box_desc is not None or cube.shell is not None) and agglomerate and \
-                os.environ.get("MGX_AGGLOMERATE", "1") != "0":
+        if cube.size > 1 and (cube.box_desc is not None or cube.shell is not None) and \
+                ((agglomerate and os.environ.get("MGX_AGGLOMERATE", "1") != "0") or cube.level_offset > 0):
             # the set-up is local; whether to use it is decided by all ranks together (a rank that
             # could not build its copy must not leave the others waiting in the allreduce)
             prepared = None
@@ -759,17 +763,22 @@ class MultigridSolver:
         native = bool(getattr(self.comm, "native_ready", False)) or not hasattr(self.comm, "native_ready")
         cube, limit = self.cube, int(os.environ.get("MGX_AGGLOMERATE_MAX_DOFS", "3000000" if native else "600000"))
         level = -1
+        # level i of a shell whose level-1 cells are dealt out to the ranks is level i + off of the whole mesh: the
+        # coarse cells exist on the undecomposed copy only, which is therefore not optional there
+        off = cube.level_offset
         for l in range(self.max_level):
             if cube.shell is not None:   # (cells x p^3 + the DoFs of two spherical boundary layers: an upper bound will do)
-                size = cube.shell_desc["shell"] * 8 ** l * (cube.degree + 1) ** 3
+                size = cube.shell_desc["shell"] * 8 ** (l + off) * (cube.degree + 1) ** 3
             else:
                 size = int((np.array(cube.cells_per_dim3(l)[1], dtype=np.int64) * cube.degree + 1).prod())
             if size <= limit:
                 level = l
+        if level < 0 and off > 0:
+            level = 0   # (a mesh refined once: the rank's hierarchy is its finest level alone, the seam is that level)
         if level < 0:
             return None
         if cube.shell is not None:
-            whole = Cube(cube.degree, n_refine=level, shell=cube.shell_desc["shell"], problem=cube.shell_desc["problem"])
+            whole = Cube(cube.degree, n_refine=level + off, shell=cube.shell_desc["shell"], problem=cube.shell_desc["problem"])
         else:
             d = cube.box_desc
             whole = Cube(cube.degree, n_refine=level, box=d["box"], procs=(1, 1, 1), rank=0, numbering=d["numbering"],
@@ -777,7 +786,7 @@ class MultigridSolver:
         ctx2 = Context(self.ctx.device)
         coarse = MultigridSolver(ctx2, whole, degree, degree, n_cycles, vnumber, device_rhs=True)  # its rhs is never used
         # local DoF -> DoF of the whole level through the run-independent id of a DoF
-        gg = whole.dof_grid(level)
+        gg = whole.dof_grid(level + off)
         order = np.argsort(gg)
         at = np.searchsorted(gg[order], cube.dof_grid(level))
         assert np.array_equal(gg[order][at], cube.dof_grid(level))

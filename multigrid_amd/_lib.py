@@ -165,6 +165,7 @@ SIGNATURES = {
     "mgx_cube_create_box": (C.c_int, [C.POINTER(CubeBoxDesc), C.POINTER(vp)]),
     "mgx_cube_create_shell": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "mgx_cube_create_shell_ranks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "mgx_cube_level_offset": (C.c_int, [vp]),
     "mgx_cube_cell_nodes": (C.c_int, [vp, C.c_int, f64p]),
     "mgx_cube_entity_multiplicity": (C.POINTER(C.c_uint8), [vp, C.c_int]),
     "mgx_cube_rank": (C.c_int, [vp]),

@@ -352,6 +352,7 @@ struct mgx_solver_s
   // every rank holds on a context of its own (no exchange, graph replay)
   mgx_solver_t    agg_solver = nullptr;
   int             agg_level  = -1;
+  int             agg_offset = 0;       // level agg_level of this solver is level agg_level + agg_offset of agg_solver (its finest)
   uint32_t       *agg_map    = nullptr; // device [n_dofs(agg_level)]: local DoF -> DoF of agg_solver's level
   uint8_t        *agg_owned  = nullptr; // device: 1 where this rank owns the DoF
   hipEvent_t      agg_in = nullptr, agg_out = nullptr;
@@ -3216,17 +3217,17 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
 {
   mgx_solver_t  G   = S->agg_solver;
   mgx_context_t ctx = S->ctx;
-  const int     L   = S->agg_level;
+  const int     L   = S->agg_level, Lg = L + S->agg_offset; // the seam level in the numbering of either solver
   hipStream_t   s = ctx->stream, sg = G->ctx->stream;
   const int     num = S->vnumber;
-  const size_t  ng = G->matrix[L]->d.n_dofs, nl = S->matrix[L]->d.n_dofs;
+  const size_t  ng = G->matrix[Lg]->d.n_dofs, nl = S->matrix[L]->d.n_dofs;
   Stopwatch     sw(S, L, 5);
-  MGX_HIP(hipMemsetAsync(G->defect[L], 0, number_size(num) * ng, s));
-  launch_scatter_map(s, num, G->defect[L], S->defect[L], S->agg_map, S->agg_owned, (uint32_t)nl);
+  MGX_HIP(hipMemsetAsync(G->defect[Lg], 0, number_size(num) * ng, s));
+  launch_scatter_map(s, num, G->defect[Lg], S->defect[L], S->agg_map, S->agg_owned, (uint32_t)nl);
   if (ctx->use_rccl)
     {
       RcclApi &R = rccl_api();
-      if (R.AllReduce(G->defect[L], G->defect[L], ng, num == MGX_F64 ? ncclDouble : ncclFloat, ncclSum, ctx->nccl, s) !=
+      if (R.AllReduce(G->defect[Lg], G->defect[Lg], ng, num == MGX_F64 ? ncclDouble : ncclFloat, ncclSum, ctx->nccl, s) !=
           ncclSuccess)
         return fail(MGX_ERR_HIP, "ncclAllReduce of the agglomerated defect failed");
     }
@@ -3234,11 +3235,11 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
     {
       S->agg_host.resize(ng);
       if (num == MGX_F64)
-        MGX_HIP(hipMemcpyAsync(S->agg_host.data(), G->defect[L], 8 * ng, hipMemcpyDeviceToHost, s));
+        MGX_HIP(hipMemcpyAsync(S->agg_host.data(), G->defect[Lg], 8 * ng, hipMemcpyDeviceToHost, s));
       else
         {
           std::vector<float> tmp(ng);
-          MGX_HIP(hipMemcpyAsync(tmp.data(), G->defect[L], 4 * ng, hipMemcpyDeviceToHost, s));
+          MGX_HIP(hipMemcpyAsync(tmp.data(), G->defect[Lg], 4 * ng, hipMemcpyDeviceToHost, s));
           MGX_HIP(hipStreamSynchronize(s));
           std::copy(tmp.begin(), tmp.end(), S->agg_host.begin());
         }
@@ -3255,13 +3256,13 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
       if (num == MGX_F64)
         {
           // pageable staging buffer, rewritten by the next cycle: the copy must have left it before we return
-          MGX_HIP(hipMemcpyAsync(G->defect[L], S->agg_host.data(), 8 * ng, hipMemcpyHostToDevice, s));
+          MGX_HIP(hipMemcpyAsync(G->defect[Lg], S->agg_host.data(), 8 * ng, hipMemcpyHostToDevice, s));
           MGX_HIP(hipStreamSynchronize(s));
         }
       else
         {
           std::vector<float> tmp(S->agg_host.begin(), S->agg_host.end());
-          MGX_HIP(hipMemcpyAsync(G->defect[L], tmp.data(), 4 * ng, hipMemcpyHostToDevice, s));
+          MGX_HIP(hipMemcpyAsync(G->defect[Lg], tmp.data(), 4 * ng, hipMemcpyHostToDevice, s));
           MGX_HIP(hipStreamSynchronize(s));
         }
     }
@@ -3270,13 +3271,13 @@ static int agglomerated_cycle(mgx_solver_t S, int my_n_cycles)
       MGX_HIP(hipEventRecord(S->agg_in, s));
       MGX_HIP(hipStreamWaitEvent(sg, S->agg_in, 0));
     }
-  MGX_TRY(v_cycle(G, L, my_n_cycles));
+  MGX_TRY(v_cycle(G, Lg, my_n_cycles));
   if (sg != s)
     {
       MGX_HIP(hipEventRecord(S->agg_out, sg));
       MGX_HIP(hipStreamWaitEvent(s, S->agg_out, 0));
     }
-  launch_pack(s, num, S->solution_update[L], G->solution_update[L], S->agg_map, (uint32_t)nl);
+  launch_pack(s, num, S->solution_update[L], G->solution_update[Lg], S->agg_map, (uint32_t)nl);
   MGX_HIP(hipGetLastError());
   return MGX_OK;
 }
@@ -3286,14 +3287,20 @@ int mgx_solver_set_agglomeration(mgx_solver_t S, int level, mgx_solver_t coarse,
 {
   MGX_REQUIRE(S && coarse && local_to_global && owned, "mgx_solver_set_agglomeration: null argument");
   MGX_REQUIRE(S->agg_solver == nullptr, "mgx_solver_set_agglomeration: already set");
-  MGX_REQUIRE(level >= 0 && level < S->n_levels - 1, "mgx_solver_set_agglomeration: the finest level stays decomposed");
-  MGX_REQUIRE(coarse->n_levels == level + 1, "mgx_solver_set_agglomeration: the coarse solver must end at `level`");
+  // (a hierarchy that lacks the coarsest levels of the whole mesh may consist of its finest level alone: the seam is then
+  // that level, the only one that exists on both sides)
+  MGX_REQUIRE(level >= 0 && (level < S->n_levels - 1 || (level == S->n_levels - 1 && coarse->n_levels > level + 1)),
+              "mgx_solver_set_agglomeration: the finest level stays decomposed");
+  // (a hierarchy whose level 0 is level k of the whole mesh -- mgx_cube_level_offset -- meets a coarse solver with k more
+  // levels: its finest level is the seam either way)
+  MGX_REQUIRE(coarse->n_levels >= level + 1, "mgx_solver_set_agglomeration: the coarse solver must end at `level`");
+  const int offset = coarse->n_levels - 1 - level;
   MGX_REQUIRE(coarse->vnumber == S->vnumber && coarse->degree == S->degree,
               "mgx_solver_set_agglomeration: number type or smoother degree differ");
   MGX_REQUIRE(coarse->ctx != S->ctx && !coarse->ctx->has_comm,
               "mgx_solver_set_agglomeration: the coarse solver lives on a context of its own without a communicator");
   MGX_REQUIRE(n_local == S->matrix[level]->d.n_dofs, "mgx_solver_set_agglomeration: map length is not the level size");
-  const uint32_t ng = coarse->matrix[level]->d.n_dofs;
+  const uint32_t ng = coarse->matrix[level + offset]->d.n_dofs;
   for (uint32_t i = 0; i < n_local; ++i)
     if (local_to_global[i] >= ng)
       return fail(MGX_ERR_INVALID_ARGUMENT, "mgx_solver_set_agglomeration: map entry out of range");
@@ -3313,6 +3320,7 @@ int mgx_solver_set_agglomeration(mgx_solver_t S, int level, mgx_solver_t coarse,
     }
   S->agg_solver = coarse;
   S->agg_level  = level;
+  S->agg_offset = offset;
   return MGX_OK;
 }
 
@@ -3484,6 +3492,26 @@ int mgx_solver_solve_hooked(mgx_solver_t S, int do_analyze, double *reduction_ra
   MGX_REQUIRE(S, "mgx_solver_solve: null solver");
   hipStream_t s    = S->ctx->stream;
   double      rate = 1.;
+  int         first_level = 1;
+  if (S->agg_solver && S->agg_offset > 0)
+    {
+      // The levels of the whole mesh below level 0 of this hierarchy exist on the undecomposed copy only (cells of level
+      // 1 dealt out to the ranks, mgx_cube_create_shell_ranks): the copy -- the same problem on every rank -- runs the
+      // full multigrid cycle up to the seam, every rank takes the solution of its DoFs from there and goes on above it.
+      mgx_solver_t        G  = S->agg_solver;
+      const int           L  = S->agg_level, Lg = L + S->agg_offset;
+      std::vector<double> gt(2 * (size_t)G->n_levels, 0.);
+      MGX_TRY(mgx_solver_solve_hooked(G, do_analyze, &rate, gt.data(), nullptr, nullptr));
+      launch_pack(s, MGX_F64, S->solution[L], G->solution[Lg], S->agg_map, (uint32_t)S->matrix[L]->d.n_dofs);
+      if (trace)
+        for (int l = 0; l <= L; ++l)
+          {
+            trace[2 * l]     = gt[2 * (size_t)(l + S->agg_offset)];
+            trace[2 * l + 1] = gt[2 * (size_t)(l + S->agg_offset) + 1];
+          }
+      first_level = L + 1;
+    }
+  else
   {
     // coarse solver invoked twice (multigrid_solver.h:397-402)
     Stopwatch    sw(S, 0, 0);
@@ -3494,7 +3522,7 @@ int mgx_solver_solve_hooked(mgx_solver_t S, int do_analyze, double *reduction_ra
     launch_copy_cast(s, S->solution[0], MGX_F64, S->t[0], S->vnumber, n0);
     S->timings[1] += 2;
   }
-  for (int level = 1; level < S->n_levels; ++level)
+  for (int level = first_level; level < S->n_levels; ++level)
     {
       const size_t n = S->matrix[level]->d.n_dofs;
       {

@@ -165,6 +165,7 @@ namespace
     // quadrature point the merged coefficient, component-major [cell][6][n_q] with the weight
     // folded in, det(J) w_q and the physical quadrature point; empty on the Cartesian
     // constant-coefficient mesh
+    uint32_t              cell_offset = 0; // multi-block meshes over ranks: index of local cell 0 among the cells of the whole level
     std::vector<double>   coef_q, jxw, xq;
     // multi-block meshes (hyper_shell): number of cells around each of the 27 entities of every cell
     // (the multiplicities of the transfer where they are not products of 1 and 2 per direction)
@@ -278,7 +279,9 @@ struct mgx_cube_s
   Basis              basis;
   std::vector<Level> levels;
   std::vector<ShellBlock> shell; // MGX_CUBE_GEOMETRY_HYPER_SHELL: the coarse cells of the whole mesh
-  int                shell_block0 = 0; // ... the first one this rank owns
+  // ... over ranks: level i of this object is level i + level_offset of the whole mesh (1 where cells of level 1, not
+  // coarse cells, are dealt out to the ranks: the coarser levels then exist on the undecomposed copy only)
+  int                level_offset = 0;
 };
 
 namespace
@@ -1009,10 +1012,18 @@ int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int prob
     return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: unknown problem");
   if ((uint64_t)n_coarse << (3 * n_refine) >= 0x10000000ull)
     return mgx::report_error(MGX_ERR_UNSUPPORTED, "mgx_cube_create_shell: too many cells");
-  // rank r holds the coarse cells [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks): equal shares where n_ranks divides
-  // them, otherwise one more on some ranks (12 cells on 8 ranks: 1, 2, 1, 2, ...)
-  if (n_ranks < 1 || n_ranks > n_coarse || rank < 0 || rank >= n_ranks)
-    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: at most one rank per coarse cell");
+  // What is dealt out: the coarse cells in contiguous shares where n_ranks divides them (rank r holds cells
+  // [r n_coarse / n_ranks, (r + 1) n_coarse / n_ranks)); otherwise the cells of level 1 -- 48 or 96 of them, equal shares
+  // for 8 (and 16, 24, 32) ranks -- where the mesh is refined at least once: the reference partitions the refined mesh
+  // cell by cell as well (poisson_shell/program.cc:249,274).  Level i of the object is then level i + 1 of the whole
+  // mesh (mgx_cube_level_offset); the coarse cells exist on the undecomposed copy of the coarse levels only
+  // (mgx_solver_set_agglomeration).  Neither: uneven shares of coarse cells (12 cells on 8 ranks: 1, 2, 1, 2, ...).
+  int granularity = 0;
+  if (n_ranks > 1 && n_coarse % n_ranks != 0 && n_refine >= 1 && (8 * n_coarse) % n_ranks == 0 && n_ranks <= 32)
+    granularity = 1;
+  if (n_ranks < 1 || n_ranks > (n_coarse << (3 * granularity)) || rank < 0 || rank >= n_ranks)
+    return mgx::report_error(MGX_ERR_INVALID_ARGUMENT, "mgx_cube_create_shell: at most one rank per coarse cell (or per cell of "
+                                                       "level 1 where those can be dealt out evenly)");
   omp_set_num_threads(effective_threads());
   auto C        = std::make_unique<mgx_cube_s>();
   C->p          = degree;
@@ -1024,36 +1035,38 @@ int mgx_cube_create_shell_ranks(int degree, int n_coarse, int n_refine, int prob
   C->shell      = shell_blocks(n_coarse);
   C->rank       = rank;
   C->size       = n_ranks;
-  C->shell_block0 = (rank * n_coarse) / n_ranks;
-  const int my_blocks = ((rank + 1) * n_coarse) / n_ranks - C->shell_block0;
+  C->level_offset = granularity;
   make_basis(C->basis, degree);
-  C->levels.resize(n_refine + 1);
-  for (int l = 0; l <= n_refine; ++l)
+  C->levels.resize(n_refine + 1 - granularity);
+  for (int l = granularity; l <= n_refine; ++l)
     {
       std::string why;
+      Level      &mine = C->levels[l - granularity];
       if (n_ranks == 1)
         {
-          if (!build_shell_level(*C, C->levels[l], l, why))
+          if (!build_shell_level(*C, mine, l, why))
             return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
         }
       else
         {
           // the tables of the whole mesh (every rank builds them; they are small next to the per-point
-          // coefficients), then this rank's blocks of it
+          // coefficients), then this rank's share of it
           Level      whole;
-          const int  b0 = C->shell_block0;
-          C->shell_block0 = 0;
           const bool ok = build_shell_level(*C, whole, l, why);
-          C->shell_block0 = b0;
           if (!ok)
             return mgx::report_error(MGX_ERR_UNSUPPORTED, ("mgx_cube_create_shell: " + why).c_str());
-          localise_shell_level(*C, whole, C->levels[l], my_blocks);
+          localise_shell_level(*C, whole, mine, granularity);
         }
-      build_geometry(*C, C->levels[l]);
-      build_bc(*C, C->levels[l]);
+      build_geometry(*C, mine);
+      build_bc(*C, mine);
     }
   *out = C.release();
   return MGX_OK;
+}
+
+int mgx_cube_level_offset(mgx_cube_t c)
+{
+  return c ? c->level_offset : 0;
 }
 
 int mgx_cube_cell_nodes(mgx_cube_t c, int l, double *out)

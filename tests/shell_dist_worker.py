@@ -32,10 +32,14 @@ def run(mode, n_coarse, p, nr, problem, dist, rank, world, say=print):
     whole = mg.Cube(p, n_refine=nr, shell=n_coarse, problem=problem)
     cube = mg.Cube(p, n_refine=nr, shell=n_coarse, problem=problem, procs=(world, 1, 1), rank=rank)
     orc = Oracle(p, degree=3, n_cycles=1, mesh=whole, problem=problem)
+    # level i of the rank's mesh is level i + off of the whole mesh (off = 1 where the cells of level 1 are dealt out:
+    # 8 ranks on either shell, 4 ranks on the six-cell one)
+    off = cube.level_offset
+    assert cube.n_levels + off == whole.n_levels
     # local DoF -> DoF of the whole mesh through the run-independent id of a DoF
     l2g = []
     for lev in range(cube.n_levels):
-        gid = whole.dof_grid(lev)
+        gid = whole.dof_grid(lev + off)
         order = np.argsort(gid)
         pos = np.searchsorted(gid[order], cube.dof_grid(lev))
         assert np.array_equal(gid[order][pos], cube.dof_grid(lev))
@@ -65,19 +69,22 @@ def run(mode, n_coarse, p, nr, problem, dist, rank, world, say=print):
     if mode == "host":
         for lev in range(cube.n_levels):
             nc = torch.tensor([float(cube.n_cells(lev))])
-            dist.all_reduce(nc)   # shares may differ by one coarse cell (12 cells on 8 ranks)
-            assert int(nc.item()) == whole.n_cells(lev)
+            dist.all_reduce(nc)
+            assert int(nc.item()) == whole.n_cells(lev + off)
+            units = n_coarse * 8 ** off           # what is dealt out: coarse cells, or the cells of level 1
+            if units % world == 0:                # ... in equal shares wherever that is possible
+                assert cube.n_cells(lev) * world == whole.n_cells(lev + off)
             rhs = exchange_add_host(lev, cube.rhs(lev).copy())
-            ref = orc.rhs(lev)[l2g[lev]]
+            ref = orc.rhs(lev + off)[l2g[lev]]
             assert np.abs(rhs - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-30), (lev, np.abs(rhs - ref).max())
             owned = np.ones(cube.n_dofs(lev))
             owned[cube.not_owned(lev)] = 0
             t = torch.tensor([owned.sum()])
             dist.all_reduce(t)
-            assert int(t.item()) == whole.n_dofs(lev), (int(t.item()), whole.n_dofs(lev))
+            assert int(t.item()) == whole.n_dofs(lev + off), (int(t.item()), whole.n_dofs(lev + off))
             # the local index tables address the same DoFs of the whole mesh as the whole mesh's own tables
-            c0 = (rank * n_coarse) // world * (whole.n_cells(lev) // n_coarse)   # first cell of this rank's first block
-            gi, li = whole.idx27(lev)[c0:c0 + cube.n_cells(lev)], cube.idx27(lev)
+            c0 = (rank * units) // world * (whole.n_cells(lev + off) // units)   # first cell of this rank's first unit
+            gi, li = whole.idx27(lev + off)[c0:c0 + cube.n_cells(lev)], cube.idx27(lev)
             ok = li != 0xFFFFFFFF
             assert np.array_equal(ok, gi != 0xFFFFFFFF) and np.array_equal(l2g[lev][li[ok]], gi[ok])
         say("rank %d host ok" % rank, flush=True)
@@ -102,21 +109,23 @@ def run(mode, n_coarse, p, nr, problem, dist, rank, world, say=print):
             m = l2g[lev]
             A = solver.matrix_dp(lev)
             x, b = cube.seeded_vector(lev, 1), cube.seeded_vector(lev, 2)
-            xg, bg = whole.seeded_vector(lev, 1), whole.seeded_vector(lev, 2)
+            xg, bg = whole.seeded_vector(lev + off, 1), whole.seeded_vector(lev + off, 2)
             assert np.array_equal(x, xg[m])
             src, rhs, dst = ctx.vector(x.size, data=x), ctx.vector(x.size, data=b), ctx.vector(x.size)
             A.vmult(dst, src)
-            assert rel(dst.download(), orc.vmult(lev, xg)[m]) < 1e-12, ("vmult", lev)
+            assert rel(dst.download(), orc.vmult(lev + off, xg)[m]) < 1e-12, ("vmult", lev)
             A.vmult_residual(rhs, src, dst)
-            assert rel(dst.download(), orc.vmult_residual(lev, bg, xg)[m]) < 1e-12, ("residual", lev)
-            assert rel(A.get_matrix_diagonal_inverse().download(), orc.inv_diag(lev)[m]) < 1e-12, ("diagonal", lev)
+            assert rel(dst.download(), orc.vmult_residual(lev + off, bg, xg)[m]) < 1e-12, ("residual", lev)
+            assert rel(A.get_matrix_diagonal_inverse().download(), orc.inv_diag(lev + off)[m]) < 1e-12, ("diagonal", lev)
             assert abs(ctx.l2_norm(src) - np.linalg.norm(xg)) < 1e-12 * np.linalg.norm(xg)
-            gi, oi = solver.smoother(lev).info(), orc.cheb_info(lev)
-            assert gi["degree"] == oi["degree"] and abs(gi["cg_its"] - oi["cg_its"]) <= (2 if lev == 0 else 0), (lev, gi, oi)
+            if off > 0 and lev == 0:
+                continue  # (level 0 of the rank's hierarchy is a smoothed level of the whole mesh: it runs on the undecomposed copy)
+            gi, oi = solver.smoother(lev).info(), orc.cheb_info(lev + off)
+            assert gi["degree"] == oi["degree"] and abs(gi["cg_its"] - oi["cg_its"]) <= (2 if lev + off == 0 else 0), (lev, gi, oi)
             assert abs(gi["lambda_max"] - oi["lambda_max"]) < 1e-8 * oi["lambda_max"], (lev, gi, oi)
         l = cube.max_level
         m = l2g[l]
-        x, xg = cube.seeded_vector(l, 5), whole.seeded_vector(l, 5)
+        x, xg = cube.seeded_vector(l, 5), whole.seeded_vector(l + off, 5)
         src, dst = ctx.vector(x.size, data=x), ctx.vector(x.size)
         for _ in range(2):
             solver.vmult(dst, src)

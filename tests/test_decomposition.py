@@ -129,11 +129,13 @@ def test_gloo_exchange_protocol_shell_sector():
     assert all("host ok" in o for o in outs), outs
 
 
-@pytest.mark.parametrize("world,n_coarse,p,nr", [(2, 6, 2, 2), (3, 6, 3, 1), (4, 12, 2, 1), (2, 12, 4, 1), (8, 12, 2, 1), (4, 6, 2, 1)])
+@pytest.mark.parametrize("world,n_coarse,p,nr", [(2, 6, 2, 2), (3, 6, 3, 1), (4, 12, 2, 1), (2, 12, 4, 1), (8, 12, 2, 1), (4, 6, 2, 1),
+                                                  (8, 6, 2, 2), (8, 6, 3, 1), (8, 12, 2, 2), (5, 6, 2, 1)])
 def test_gloo_exchange_protocol_hyper_shell(world, n_coarse, p, nr):
-    """the coarse cells of hyper_shell(6 | 12) dealt out to 2, 3, 4 and 8 ranks (8 ranks on 12 cells, 4 on 6: uneven
-    shares): local index tables address the same
-    DoFs as the whole mesh's, the right-hand side summed over the block interfaces equals the single-domain one,
+    """hyper_shell(6 | 12) over 2, 3, 4, 5 and 8 ranks: the coarse cells in equal shares where the rank count divides
+    them, else the cells of level 1 (8 ranks: 6 of 48 / 12 of 96 each; 4 ranks on the six-cell shell: 12 of 48), else
+    (5 ranks) uneven shares of coarse cells: equal cell counts wherever possible, local index tables address the same
+    DoFs as the whole mesh's, the right-hand side summed over the rank interfaces equals the single-domain one,
     every DoF is owned exactly once"""
     outs = launch("", world, 0, 0, extra=("host", str(n_coarse), str(p), str(nr)), worker="shell_dist_worker.py")
     assert all("host ok" in o for o in outs), outs

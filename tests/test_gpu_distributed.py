@@ -94,8 +94,8 @@ def test_poisson_shell_harness_on_ranks():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
 
-    def table(extra):
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "poisson_shell.py"), "2", "40000", "--cycles", "2:6"] + extra,
+    def table(extra, cycles="2:6"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "poisson_shell.py"), "2", "40000", "--cycles", cycles] + extra,
                              cwd=root, env=env, capture_output=True, timeout=600)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = out.stdout.decode().strip().splitlines()
@@ -105,6 +105,13 @@ def test_poisson_shell_harness_on_ranks():
     one, three = table([]), table(["--gpus", "3"])
     assert len(one) == len(three) == 4
     for a, b in zip(one, three):
+        assert a[:2] == b[:2] and a[5] == b[5]
+        assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(a[2:5] + a[6:], b[2:5] + b[6:])), (a, b)
+    # no cycle is skipped on a rank count that does not divide the coarse cells: four ranks take the unrefined six-cell
+    # shell as a whole, the cells of level 1 of the refined one (12 of 48 each), the coarse cells of the twelve-cell shell
+    one, four = table([], "0:6"), table(["--gpus", "4"], "0:6")
+    assert len(one) == len(four) == 6
+    for a, b in zip(one, four):
         assert a[:2] == b[:2] and a[5] == b[5]
         assert all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(a[2:5] + a[6:], b[2:5] + b[6:])), (a, b)
 
@@ -164,7 +171,8 @@ def test_callback_device_transport_takes_library_owned_buffers():
     assert out.returncode == 0 and b"callback transport ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("world,n_coarse,p,nr,problem", [(2, 6, 4, 2, "shell"), (3, 6, 2, 2, "shell"), (4, 12, 3, 1, "cube")])
+@pytest.mark.parametrize("world,n_coarse,p,nr,problem", [(2, 6, 4, 2, "shell"), (3, 6, 2, 2, "shell"), (4, 12, 3, 1, "cube"),
+                                                          (4, 6, 2, 2, "shell")])
 def test_decomposed_hyper_shell_matches_oracle(world, n_coarse, p, nr, problem):
     """BASELINE config 4 on its own mesh on several ranks: the coarse cells of hyper_shell(6 | 12) dealt out to the
     ranks, interface DoFs on the block faces exchanged; operator, diagonal, smoother parameters, V-cycle, FMG and

@@ -86,9 +86,14 @@ def test_eight_ranks_benchmark_problem_64_cubed():
     assert all(abs(r[1] / 1.327e-8 - 1) < 5e-3 for r in res), res
 
 
-def test_eight_ranks_hyper_shell():
-    """BASELINE config 4 on eight ranks: the 12 coarse cells of hyper_shell(12) dealt out 1, 2, 1, 2, ... (the run of
-    poisson_shell on 8 GPUs), variable coefficient with the 1e6 contrast, against the single-domain oracle"""
+@pytest.mark.parametrize("n_coarse,p,nr", [(12, 3, 1), (6, 2, 2), (12, 2, 2), (6, 4, 1)])
+def test_eight_ranks_hyper_shell(n_coarse, p, nr):
+    """BASELINE config 4 on eight ranks in EQUAL shares (the run of poisson_shell on 8 GPUs): the cells of level 1 of
+    hyper_shell(6 | 12) dealt out, 6 of 48 / 12 of 96 per rank (the reference partitions the refined mesh cell by cell,
+    poisson_shell/program.cc:249,274); the coarse cells live on the undecomposed copy of the coarse levels, from which
+    the full multigrid cycle starts.  Variable coefficient with the 1e6 contrast; operator, diagonal, smoother parameters,
+    V-cycle, FMG and PCG against the single-domain oracle on the whole shell."""
     lines = []
-    run_ranks(8, lambda dist, r: shell_dist_worker.run("gpu", 12, 3, 1, "shell", dist, r, 8, say=lambda *a, **k: lines.append(a[0])))
+    run_ranks(8, lambda dist, r: shell_dist_worker.run("gpu", n_coarse, p, nr, "shell", dist, r, 8,
+                                                      say=lambda *a, **k: lines.append(a[0])))
     assert len(lines) == 8 and all("gpu ok" in s and "agglomerated" in s for s in lines), lines

@@ -81,8 +81,9 @@ def _main(a, print, dist, rank, world, local_rank):  # noqa: A002 (rank 0 prints
     print("Number of post-smoother iters:  %d" % a.n_post_smooth)
     print()
     print("Testing FE_Q<3>(%d)" % a.degree)
-    ctx = mg.Context(local_rank)
-    comm = mg.Communicator(ctx, dist) if dist is not None else None
+    ctx_ranks = mg.Context(local_rank)
+    ctx_alone = None   # a context without communicator, for the meshes every rank solves as a whole
+    comm = mg.Communicator(ctx_ranks, dist) if dist is not None else None
     vnum = mg.F32 if a.vcycle == "f32" else mg.F64
     c0, c1 = (int(v) for v in a.cycles.split(":"))
     rows = []
@@ -96,14 +97,20 @@ def _main(a, print, dist, rank, world, local_rank):  # noqa: A002 (rank 0 prints
             print("Max size reached, terminating.")
             print()
             break
-        if world > n_coarse:
-            print("(fewer coarse cells than ranks: cycle skipped)")
-            print()
-            continue
+        # The ranks share the mesh in equal parts: coarse cells where the rank count divides them, else the cells of level
+        # 1 (8 ranks: 6 of 48 / 12 of 96).  An unrefined shell of 6 or 12 cells that cannot be dealt out evenly is solved
+        # by every rank as a whole (the reference's partition of such a mesh leaves ranks without cells).
+        whole = world > 1 and n_coarse % world != 0 and (n_refine == 0 or (8 * n_coarse) % world != 0)
+        if whole:
+            print("(%d cells on %d ranks: every rank solves the whole mesh)" % (n_coarse, world))
+        if whole and ctx_alone is None:
+            ctx_alone = mg.Context(local_rank)
+        ctx = ctx_alone if whole else ctx_ranks
         t0 = time.time()
-        cube = mg.Cube(a.degree, n_refine=n_refine, shell=n_coarse, problem="shell", procs=(world, 1, 1), rank=rank)
-        assert world > 1 or cube.n_dofs(cube.max_level) == n_dofs
-        solver = mg.MultigridSolver(ctx, cube, a.n_pre_smooth, a.n_post_smooth, a.n_mg_cycles, vnum, comm=comm)
+        cube = mg.Cube(a.degree, n_refine=n_refine, shell=n_coarse, problem="shell", procs=(1 if whole else world, 1, 1),
+                       rank=0 if whole else rank)
+        assert (world > 1 and not whole) or cube.n_dofs(cube.max_level) == n_dofs
+        solver = mg.MultigridSolver(ctx, cube, a.n_pre_smooth, a.n_post_smooth, a.n_mg_cycles, vnum, comm=None if whole else comm)
         print("Total setup time:      %gs" % (time.time() - t0))
         best_time, tot_time = 1e10, 0.
         for _ in range(5):                                                        # :334-343
@@ -147,7 +154,9 @@ def _main(a, print, dist, rank, world, local_rank):  # noqa: A002 (rank 0 prints
     print(" cells    dofs    mv_outer  mv_inner  reduction  fmg_L2error   fmg_time    cg_L2error    cg_time  cg_its cg_reduction")
     for r in rows:
         print("%-8d %-9d %.3e %.3e %.3e %.3e %.3e %.3e %.3e %-6d %.3e" % r)
-    ctx.close()
+    if ctx_alone is not None:
+        ctx_alone.close()
+    ctx_ranks.close()
 
 
 if __name__ == "__main__":
