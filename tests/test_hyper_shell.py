@@ -94,3 +94,56 @@ def test_convergence_order_on_the_shell(n_coarse):
         o.close()
         c.close()
     assert np.log2(errs[1] / errs[2]) > p + 0.7  # 2.86 / 2.90 measured, -> 3
+
+
+def _local_dofs(c, l, tables):
+    """[n_cells, (p+1)^3]: DoF of every Gauss-Lobatto node of every cell through the compressed index table (27 entity
+    starts per cell, lexicographic inside an entity: vector_access_reduced.h:11-505)"""
+    p, n = c.degree, c.degree + 1
+    out = np.empty((tables.shape[0], n ** 3), dtype=np.int64)
+    for e in range(27):
+        cx, cy, cz = e % 3, (e // 3) % 3, e // 9
+        rng = [([0], [1 + o for o in range(p - 1)], [p])[cc] for cc in (cx, cy, cz)]
+        k = 0
+        for iz in rng[2]:
+            for iy in rng[1]:
+                for ix in rng[0]:
+                    out[:, (iz * n + iy) * n + ix] = tables[:, e].astype(np.int64) + k
+                    k += 1
+    return out
+
+
+@pytest.mark.parametrize("n_coarse,p,nr", [(6, 2, 1), (12, 2, 1), (6, 3, 2), (12, 4, 1), (6, 1, 2)])
+def test_index_tables_glue_exactly_the_coincident_points(n_coarse, p, nr):
+    """Topology from geometry alone, independent of how the provider identified the entities of neighbouring blocks: the
+    physical Gauss-Lobatto points of all cells are enumerated on their own (points that coincide in space are one point:
+    the union of the closed cells IS the shell), and the gluing the compressed index tables imply must be exactly that --
+    a DoF has one position whatever cell looks at it, different DoFs sit at different positions, and there are as many
+    DoFs as distinct points.  With the sphere radii and the volume (above) this pins the mesh the oracle and the GPU path
+    run on without any table the two share."""
+    c = mg.Cube(p, n_refine=nr, shell=n_coarse)
+    for l in range(c.n_levels):
+        X = np.transpose(c.cell_nodes(l), (0, 2, 1)).reshape(-1, 3)       # [cell * node, xyz]
+        dof = _local_dofs(c, l, c.idx27_plain(l)).ravel()
+        # independent enumeration: distinct positions up to a tolerance far below the node spacing (h / p^2 > 1e-3)
+        key = np.round(X / 1e-9).astype(np.int64)
+        _, point = np.unique(key, axis=0, return_inverse=True)
+        point = point.ravel()
+        n_points = point.max() + 1
+        assert n_points == c.n_dofs(l)                                      # as many DoFs as points of the shell
+        # one position per DoF, one DoF per position
+        first = np.full(c.n_dofs(l), -1, dtype=np.int64)
+        first[dof] = point
+        assert (first >= 0).all() and np.array_equal(first[dof], point)
+        back = np.full(n_points, -1, dtype=np.int64)
+        back[point] = dof
+        assert np.array_equal(back[point], dof)
+        # the Dirichlet DoFs are the points on the two spheres (|x| = 0.5 and 1), and only those
+        r = np.linalg.norm(X, axis=1)
+        on_sphere = np.zeros(c.n_dofs(l), bool)
+        on_sphere[dof[(np.abs(r - 0.5) < 1e-12) | (np.abs(r - 1.0) < 1e-12)]] = True
+        cons = np.zeros(c.n_dofs(l), bool)
+        cons[c.constrained(l)] = True
+        assert np.array_equal(on_sphere, cons)
+        assert r.min() > 0.5 - 1e-12 and r.max() < 1 + 1e-12
+    c.close()
