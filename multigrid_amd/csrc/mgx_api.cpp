@@ -2804,17 +2804,50 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   // 1D prolongation matrix into the basis blocks of both operators (the transfer kernels read the
   // coarse one, the fused residual + restriction of the fine level's cell loop the fine one)
   const size_t np1 = (size_t)(2 * p + 1) * n;
+  // ... and its even-odd form for the line products of the fused forms (Basis1D::P1eo): the embedding of a parent
+  // into its two children is symmetric under reversal of both indices for every node set that is
+  std::vector<double> p1eo;
+  bool                p1_symmetric = true;
+  {
+    const double *P1 = desc->prolong_1d;
+    const int     nh = (p + 1) / 2;
+    double        scale = 0;
+    for (size_t i = 0; i < np1; ++i)
+      scale = std::max(scale, std::fabs(P1[i]));
+    for (int a = 0; a <= 2 * p; ++a)
+      for (int j = 0; j <= p; ++j)
+        if (std::fabs(P1[a * n + j] - P1[(2 * p - a) * n + (p - j)]) > 1e-12 * scale)
+          p1_symmetric = false;
+    p1eo.assign((size_t)(2 * p + 1) * nh + (p + 1), 0.);
+    for (int a = 0; a <= p; ++a)
+      for (int j = 0; j < nh; ++j)
+        {
+          p1eo[(size_t)a * nh + j] = 0.5 * (P1[a * n + j] + P1[a * n + p - j]);
+          if (a < p)
+            p1eo[(size_t)(p + 1 + a) * nh + j] = 0.5 * (P1[a * n + j] - P1[a * n + p - j]);
+        }
+    if (p % 2 == 0)
+      for (int a = 0; a <= p; ++a)
+        p1eo[(size_t)(2 * p + 1) * nh + a] = P1[a * n + p / 2];
+    if (!p1_symmetric)
+      MGX_TRACE("transfer_create: 1D embedding not symmetric under reversal, no fused transfer forms");
+  }
   for (mgx_operator_t o : {coarse, fine})
     {
       if (o->d.number == MGX_F64)
         {
           MGX_HIP(hipMemcpy((char *)o->d.basis + offsetof(Basis1D<double>, P1), desc->prolong_1d,
                             sizeof(double) * np1, hipMemcpyHostToDevice));
+          MGX_HIP(hipMemcpy((char *)o->d.basis + offsetof(Basis1D<double>, P1eo), p1eo.data(), sizeof(double) * p1eo.size(),
+                            hipMemcpyHostToDevice));
         }
       else
         {
           std::vector<float> pf(desc->prolong_1d, desc->prolong_1d + np1);
           MGX_HIP(hipMemcpy((char *)o->d.basis + offsetof(Basis1D<float>, P1), pf.data(), sizeof(float) * np1,
+                            hipMemcpyHostToDevice));
+          std::vector<float> pe(p1eo.begin(), p1eo.end());
+          MGX_HIP(hipMemcpy((char *)o->d.basis + offsetof(Basis1D<float>, P1eo), pe.data(), sizeof(float) * pe.size(),
                             hipMemcpyHostToDevice));
         }
     }
@@ -2826,7 +2859,7 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   // neither fused form runs.  (Degree 8 was in the same position while its fused forms spilled -- 13.7 / 13.3 ms in
   // round 2; since the half-line restriction sweeps and the reordered prolongation form of round 3 they fit the
   // registers: 11.13 ms fused against 11.65 ms separate.  p = 5, 6, 9 are 5-8 % faster fused.)
-  const bool fused_pays = p != 7 || coarse->ctx->tun.force_fused_transfers;
+  const bool fused_pays = p1_symmetric && (p != 7 || coarse->ctx->tun.force_fused_transfers);
   // (decomposed mesh: both levels decomposed alike -- not across an agglomeration -- and interface rows, above)
   if (fine->d.bricks.available() && fine->d.separable && (!fine->plan == !coarse->plan) && fused_pays &&
       !coarse->ctx->tun.no_fused_restrict && !(fine->plan && coarse->ctx->tun.no_fused_decomposed))

@@ -821,7 +821,7 @@ namespace mgx
       {
         constexpr int CE1 = C::NB + 1; // 2 PB + 1
         __syncthreads();
-        restrict_brick<P, T, C::THREADS>(tid, acc, B->P1, post.coarse, post.coarse_blocks + (size_t)brick * (CE1 * CE1 * CE1));
+        restrict_brick<P, T, C::THREADS>(tid, acc, B->P1eo, post.coarse, post.coarse_blocks + (size_t)brick * (CE1 * CE1 * CE1));
       }
   }
 

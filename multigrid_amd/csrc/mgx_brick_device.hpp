@@ -214,24 +214,61 @@ namespace mgx
       }
   }
 
-  // one parent's part of a line: o[j] = sum_a P1[a][j] r[a], a over the 2p+1 fine points of parent pb
+  // one parent's part of a line: o[j] = sum_a P1[a][j] r[a], a over the 2p+1 fine points of parent pb.
+  // Even-odd form (pe = Basis1D::P1eo): the sums and differences of the fine values at mirrored positions meet the
+  // symmetric and the antisymmetric half of the embedding -- (p+1) nh + p nh (+ p+1) multiply-adds instead of
+  // (2p+1)(p+1): 23 for 45 at p = 4, 77 for 153 at p = 8, and half as many scalar operands.
   template <int P, typename T>
-  __device__ __forceinline__ void restrict_half(const T *__restrict__ p1, const T (&r)[2 * P + 1], T (&o)[P + 1])
+  __device__ __forceinline__ void restrict_half(const T *__restrict__ pe, const T (&r)[2 * P + 1], T (&o)[P + 1])
   {
-    constexpr int N = P + 1, M = 2 * P + 1;
-    // (scalar_operand_slice: with the slices 274 -> 174 us per colour launch of the p = 8 residual + restriction form,
-    // prolongation form 223 -> 201 us.  The same fences inside the operator sweeps, whose two even-odd matrices overflow
-    // the scalar file at p = 8 as well -- ~600 lane moves per brick -- cost more in lost scheduling freedom than the
-    // moves: plain form 106 -> 115 us; not kept.)
+    constexpr int NH = (P + 1) / 2, TOT = (2 * P + 1) * NH + ((P % 2 == 0) ? P + 1 : 0);
+#ifdef MGX_RESTRICT_DENSE // A/B build: the dense products with P1 itself
+    {
+      constexpr int N = P + 1, M = 2 * P + 1;
+      const T *p1 = reinterpret_cast<const Basis1D<T> *>(reinterpret_cast<const char *>(pe) - offsetof(Basis1D<T>, P1eo))->P1;
 #pragma unroll
-    for (int j = 0; j < N; ++j)
+      for (int j = 0; j < N; ++j)
+        {
+          T s = p1[j] * r[0];
+#pragma unroll
+          for (int a = 1; a < M; ++a)
+            s = fma(p1[a * N + j], r[a], s);
+          o[j] = s;
+          scalar_operand_slice<M, M * N>(j);
+        }
+      return;
+    }
+#endif
+    const T      *he = pe, *ho = pe + (P + 1) * NH, *pc = pe + (2 * P + 1) * NH;
+    T             re[P + 1], ro[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
       {
-        T s = p1[j] * r[0];
+        re[a] = r[a] + r[2 * P - a];
+        ro[a] = r[a] - r[2 * P - a];
+      }
+    re[P] = r[P];
 #pragma unroll
-        for (int a = 1; a < M; ++a)
-          s = fma(p1[a * N + j], r[a], s);
-        o[j] = s;
-        scalar_operand_slice<M, M * N>(j);
+    for (int j = 0; j < NH; ++j)
+      {
+        T se = he[j] * re[0], so = ho[j] * ro[0];
+#pragma unroll
+        for (int a = 1; a <= P; ++a)
+          se = fma(he[a * NH + j], re[a], se);
+#pragma unroll
+        for (int a = 1; a < P; ++a)
+          so = fma(ho[a * NH + j], ro[a], so);
+        o[j]     = se + so;
+        o[P - j] = se - so;
+        scalar_operand_slice<2 * P + 1, TOT>(j);
+      }
+    if (P % 2 == 0)
+      {
+        T s = pc[0] * re[0];
+#pragma unroll
+        for (int a = 1; a <= P; ++a)
+          s = fma(pc[a], re[a], s);
+        o[P / 2] = s;
       }
   }
 
@@ -370,23 +407,69 @@ namespace mgx
   // acc receives P cv on the G^3 points of the brick.  Exact embedding: every fine point takes the
   // value of the coarse finite-element function (MGTransferMatrixFree::prolongate).
   // ------------------------------------------------------------------------------------------
+  // f = P1 c per parent, in the even-odd form of restrict_half (pe = Basis1D::P1eo): f[a] and f[2p-a] from the sums and
+  // differences of the coarse values at mirrored nodes
   template <int P, typename T>
-  __device__ __forceinline__ void prolong_line(const T *__restrict__ p1, const T (&c)[(BCfg<P>::NB / 2) * P + 1],
+  __device__ __forceinline__ void prolong_line(const T *__restrict__ pe, const T (&c)[(BCfg<P>::NB / 2) * P + 1],
                                                T (&f)[BCfg<P>::G])
   {
-    constexpr int N = P + 1, M = 2 * P + 1, PB = BCfg<P>::NB / 2;
+    constexpr int PB = BCfg<P>::NB / 2, NH = (P + 1) / 2, TOT = (2 * P + 1) * NH + ((P % 2 == 0) ? P + 1 : 0);
+    constexpr int ROW = 2 * NH + (P % 2 == 0 ? 1 : 0);
+#ifdef MGX_PROLONG_DENSE // A/B build: the dense products with P1 itself
+    {
+      constexpr int N = P + 1, M = 2 * P + 1;
+      const T *p1 = reinterpret_cast<const Basis1D<T> *>(reinterpret_cast<const char *>(pe) - offsetof(Basis1D<T>, P1eo))->P1;
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+        {
+#pragma unroll
+          for (int a = (pb == 0 ? 0 : 1); a < M; ++a)
+            {
+              T s = p1[a * N] * c[pb * P];
+#pragma unroll
+              for (int i = 1; i < N; ++i)
+                s = fma(p1[a * N + i], c[pb * P + i], s);
+              f[pb * 2 * P + a] = s;
+              scalar_operand_slice<N, M * N>(a);
+            }
+        }
+      return;
+    }
+#endif
+    const T      *he = pe, *ho = pe + (P + 1) * NH, *pc = pe + (2 * P + 1) * NH;
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
       {
+        T ce[NH], co[NH];
 #pragma unroll
-        for (int a = (pb == 0 ? 0 : 1); a < M; ++a)
+        for (int i = 0; i < NH; ++i)
           {
-            T s = p1[a * N] * c[pb * P];
+            ce[i] = c[pb * P + i] + c[pb * P + P - i];
+            co[i] = c[pb * P + i] - c[pb * P + P - i];
+          }
+        const T cc = c[pb * P + P / 2];
 #pragma unroll
-            for (int i = 1; i < N; ++i)
-              s = fma(p1[a * N + i], c[pb * P + i], s);
-            f[pb * 2 * P + a] = s;
-            scalar_operand_slice<N, M * N>(a);
+        for (int a = 0; a <= P; ++a)
+          {
+            T se = he[a * NH] * ce[0];
+#pragma unroll
+            for (int i = 1; i < NH; ++i)
+              se = fma(he[a * NH + i], ce[i], se);
+            if (P % 2 == 0)
+              se = fma(pc[a], cc, se);
+            if (a < P)
+              {
+                T so = ho[a * NH] * co[0];
+#pragma unroll
+                for (int i = 1; i < NH; ++i)
+                  so = fma(ho[a * NH + i], co[i], so);
+                if (pb == 0 || a > 0) // the first point of the upper parent is the last of the lower one
+                  f[pb * 2 * P + a] = se + so;
+                f[pb * 2 * P + 2 * P - a] = se - so;
+              }
+            else
+              f[pb * 2 * P + P] = se;
+            scalar_operand_slice<ROW, TOT>(a);
           }
       }
   }

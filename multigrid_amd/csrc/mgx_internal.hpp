@@ -84,6 +84,13 @@ namespace mgx
     // 1D mass and stiffness matrices of the separable (Cartesian, constant coefficient) cell
     // matrix  A_cell = sum_d c_d (M x M x K_d):  M = S^T W S,  K = S^T D^T W D S
     EOMat<T> mass, lapl;
+    // P1 in even-odd form for the line products of the fused transfer forms (restrict_half / prolong_line,
+    // mgx_brick_device.hpp).  The embedding of a parent into its two children is symmetric under reversal of both
+    // indices, P1[2p-a][p-j] = P1[a][j] (checked when the transfer is created).  With nh = (p+1)/2 pairs (j, p-j):
+    //   HE[a*nh+j] = (P1[a][j] + P1[a][p-j]) / 2, a <= p;  HO[a*nh+j] = (P1[a][j] - P1[a][p-j]) / 2, a < p;
+    //   PC[a] = P1[a][p/2], a <= p (p even: the coarse point in the middle of the parent)
+    // at offsets 0, (p+1) nh, (2p+1) nh.
+    T P1eo[2 * kMaxN * kMaxN];
   };
 
   // Reduced-colour schedule of the macro-element kernel (mgx_macro.hip, FREE; built by

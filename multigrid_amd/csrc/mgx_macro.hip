@@ -339,7 +339,7 @@ namespace mgx
       if (kProlong)
         {
           lds_barrier(); // the entity table parked in W (prologue) has been read by everyone
-          prolong_brick<P, T, NT>(tid, W, B->P1, cvv);
+          prolong_brick<P, T, NT>(tid, W, B->P1eo, cvv);
         }
     };
     auto add_correction = [&]() {
@@ -727,10 +727,10 @@ namespace mgx
             __syncthreads();
             const uint32_t *ctab = post.coarse_blocks + (size_t)(brick_first + b) * (CE1 * CE1 * CE1);
             if (post.coarse_scratch) // uniform
-              restrict_brick<P, T, NT, true>(tid, W, B->P1, nullptr, ctab,
+              restrict_brick<P, T, NT, true>(tid, W, B->P1eo, nullptr, ctab,
                                              post.coarse_scratch + (size_t)(brick_first + b) * (CNP * CNP * CNP));
             else
-              restrict_brick<P, T, NT, false>(tid, W, B->P1, post.coarse, ctab);
+              restrict_brick<P, T, NT, false>(tid, W, B->P1eo, post.coarse, ctab);
           }
         if (!has_next)
           break;

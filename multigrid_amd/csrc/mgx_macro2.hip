@@ -561,10 +561,10 @@ namespace mgx
             lds_barrier();
             const uint32_t *ctab = post.coarse_blocks + (size_t)(brick_first + b) * (CE1 * CE1 * CE1);
             if (post.coarse_scratch) // uniform
-              restrict_brick<P, T, NT, true>(tid, W, B->P1, nullptr, ctab,
+              restrict_brick<P, T, NT, true>(tid, W, B->P1eo, nullptr, ctab,
                                              post.coarse_scratch + (size_t)(brick_first + b) * (CNP * CNP * CNP));
             else
-              restrict_brick<P, T, NT, false>(tid, W, B->P1, post.coarse, ctab);
+              restrict_brick<P, T, NT, false>(tid, W, B->P1eo, post.coarse, ctab);
           }
         MGX_STAMP_IT(9);
         if (!has_next)

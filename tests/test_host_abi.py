@@ -194,3 +194,36 @@ def test_shim_declares_the_reference_interface_and_compiles(tmp_path):
         assert names <= members(cls), (cls, names - members(cls))
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "tests", "shim_check.cpp")], check=True)
+
+
+@pytest.mark.parametrize("p", range(1, 10))
+def test_embedding_is_symmetric_and_its_even_odd_form_reproduces_it(lib, p):
+    """what the fused transfer forms rely on (Basis1D::P1eo, mgx_brick_device.hpp restrict_half / prolong_line): the 1D
+    embedding of a parent into its two children is symmetric under reversal of both indices, and the half-size
+    products with the sums and differences at mirrored positions give the dense restriction and prolongation"""
+    import multigrid_amd as mg
+    c = mg.Cube(p, 1, 1)
+    P1 = c.prolong_1d()
+    c.close()
+    n, nh = p + 1, (p + 1) // 2
+    assert P1.shape == (2 * p + 1, n)
+    np.testing.assert_allclose(P1[::-1, ::-1], P1, atol=1e-14)
+    he = 0.5 * (P1[:n, :nh] + P1[:n, ::-1][:, :nh])
+    ho = 0.5 * (P1[:p, :nh] - P1[:p, ::-1][:, :nh])
+    pc = P1[:n, p // 2]
+    rng = np.random.default_rng(p)
+    r = rng.standard_normal(2 * p + 1)
+    re, ro = np.append(r[:p] + r[::-1][:p], r[p]), r[:p] - r[::-1][:p]
+    o = np.zeros(n)
+    se, so = he.T @ re, ho.T @ ro
+    o[:nh], o[::-1][:nh] = se + so, se - so
+    if p % 2 == 0:
+        o[p // 2] = pc @ re
+    np.testing.assert_allclose(o, P1.T @ r, atol=1e-13)
+    cv = rng.standard_normal(n)
+    ce, co = cv[:nh] + cv[::-1][:nh], cv[:nh] - cv[::-1][:nh]
+    fe = he @ ce + (pc * cv[p // 2] if p % 2 == 0 else 0.)
+    fo = ho @ co
+    f = np.zeros(2 * p + 1)
+    f[:p], f[::-1][:p], f[p] = fe[:p] + fo, fe[:p] - fo, fe[p]
+    np.testing.assert_allclose(f, P1 @ cv, atol=1e-13)
