@@ -2854,12 +2854,10 @@ int mgx_transfer_create(mgx_operator_t coarse, mgx_operator_t fine, const mgx_tr
   // Fused residual + restriction (mgx_brick.hip, mode 7): needs the fine level on the brick
   // schedule in its separable form, children in forest order (cell c is child c % 8 of parent
   // c / 8, so that a brick's cells are the children of PB^3 sibling parents) and a single rank.
-  // Degree 7: the in-LDS restriction / embedding sweeps of the one-parent bricks cost more than the transfer
-  // kernels they replace (measured V-cycle at 64^3 cells: 9.36 ms fused, 8.86 ms separate) -- no coarse blocks, so
-  // neither fused form runs.  (Degree 8 was in the same position while its fused forms spilled -- 13.7 / 13.3 ms in
-  // round 2; since the half-line restriction sweeps and the reordered prolongation form of round 3 they fit the
-  // registers: 11.13 ms fused against 11.65 ms separate.  p = 5, 6, 9 are 5-8 % faster fused.)
-  const bool fused_pays = p1_symmetric && (p != 7 || coarse->ctx->tun.force_fused_transfers);
+  // (Degree 7 ran the separate kernels until the line products of the embedding took their even-odd form in round 4:
+  // V-cycle at 64^3 cells 10.69 ms separate, 9.70 ms fused; before: 8.86 / 9.36 ms at the clocks of round 2.  Degree 8
+  // was in the same position while its fused forms spilled.  The option "force_fused_transfers" is a no-op now.)
+  const bool fused_pays = p1_symmetric;
   // (decomposed mesh: both levels decomposed alike -- not across an agglomeration -- and interface rows, above)
   if (fine->d.bricks.available() && fine->d.separable && (!fine->plan == !coarse->plan) && fused_pays &&
       !coarse->ctx->tun.no_fused_restrict && !(fine->plan && coarse->ctx->tun.no_fused_decomposed))

@@ -44,7 +44,7 @@ namespace mgx
     bool     no_fused_init    = false; // MGX_NO_FUSED_INIT    store the first Chebyshev iterate
     bool     no_fused_restrict = false; // MGX_NO_FUSED_RESTRICT  separate residual and restriction kernels
     bool     no_fused_prolong = false; // MGX_NO_FUSED_PROLONG prolongation as a kernel of its own
-    bool     force_fused_transfers = false; // fused restriction / prolongation also for p = 7 (where the separate kernels are faster)
+    bool     force_fused_transfers = false; // (no-op since round 4: the fused transfer forms run at every degree)
     bool     transfer_v1      = false; // MGX_TRANSFER_V1      first-version transfer kernels
     bool     restrict_atomic  = false; // MGX_RESTRICT_ATOMIC  one-launch restriction with atomics on every level
     uint32_t restrict_colour_min = 16384; // MGX_RESTRICT_COLOUR_MIN  coarse cells from which restriction runs by colour

@@ -93,10 +93,18 @@ namespace mgx
     static constexpr int WG_WAVE = 32 / (THREADS / 64);
     static constexpr int WGS     = WG_LDS < WG_WAVE ? (WG_LDS < 8 ? WG_LDS : 8) : (WG_WAVE < 8 ? WG_WAVE : 8);
     static constexpr int WAVES   = WGS * (THREADS / 64);
-    // registers: three lines of the sweeps, the partial sums in flight, item words; the gathered values and the
-    // operands of the write-out are live outside the sweeps only
-    static constexpr int REGS = (3 * G + JSURF) * ((int)sizeof(T) / 4) + IT + 40;
+    // registers: three lines of the sweeps, the partial sums in flight, the values kept across the sweeps by the
+    // Chebyshev forms, item words.  (Without the IT values in the estimate p = 7 was held to 168 registers for a third
+    // workgroup per CU and spilled 28 ... 212 B per lane: residual form 223 us, old-from-rhs form 247 us per colour
+    // launch of 64^3 cells against 115 us of the plain form.)
+    // p = 7, 8: the line blocks of the sweeps (N = 8, 9 values, their even-odd halves and results) on top -- fp32 p = 8
+    // held to 168 registers spilled 52 B per lane in the old-from-rhs form: 118 against 92 us per colour launch
+    static constexpr int REGS = (3 * G + JSURF + IT + ((P == 7 || P == 8) ? 4 * (P + 1) : 0)) * ((int)sizeof(T) / 4) + IT + 40;
+#ifdef MGX_M2_RMAX // A/B builds
+    static constexpr int RMAX = MGX_M2_RMAX;
+#else
     static constexpr int RMAX = REGS > 168 ? 2 : (REGS > 128 ? 3 : 4);
+#endif
     static constexpr int MINW = (WAVES + 3) / 4 < RMAX ? (WAVES + 3) / 4 : RMAX;
   };
 
