@@ -397,6 +397,11 @@ namespace mgx
               asm volatile("" : "+v"(dv[DTAB ? it : 0]));
           }
 #ifndef MGX_MACRO_NOSWEEP // diagnostic build without the sweeps (wrong results): memory phases alone
+        if (kSlicedSweeps<P, MODE>)
+          brick_sweeps_sliced<P, T>(
+            tid, U, W, B, c0, c1, c2, [&](int i) { MGX_STAMP_IT(4 + i); }, [&]() { __syncthreads(); });
+        else
+          {
         // ---- x sweep: line l = (y,z), contiguous; M u -> W, K u -> U in place ----
         if (tid < LINES)
           {
@@ -540,6 +545,7 @@ namespace mgx
 #pragma unroll
             for (int j = 0; j < G; ++j)
               W[l + j * (G * G)] = fma(c2, r[j], o[j]);
+          }
           }
 #endif
         __syncthreads();

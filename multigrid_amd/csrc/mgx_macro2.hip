@@ -434,7 +434,13 @@ namespace mgx
           }
         MGX_STAMP_IT(4);
 #ifndef MGX_MACRO_NOSWEEP // diagnostic build without the sweeps (wrong results): memory phases alone
-        brick_sweeps<P, T>(tid, U, W, M, K, c0, c1, c2, [&](int k) { MGX_STAMP_IT(5 + k); });
+        // (this pipeline: from p = 9 on -- its plain form loses 8 % at p = 7 and 2 % at p = 8 with the slices, the
+        // old-from-rhs form gains 7 % at p = 9 and nothing below)
+        if (kSlicedSweeps<P, MODE> && P >= 9)
+          brick_sweeps_sliced<P, T>(
+            tid, U, W, B, c0, c1, c2, [&](int k) { MGX_STAMP_IT(5 + k); }, [&]() { lds_barrier(); });
+        else
+          brick_sweeps<P, T>(tid, U, W, M, K, c0, c1, c2, [&](int k) { MGX_STAMP_IT(5 + k); });
 #endif
         lds_barrier();
         MGX_STAMP_IT(7);

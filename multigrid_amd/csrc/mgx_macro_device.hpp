@@ -135,6 +135,186 @@ namespace mgx
   __device__ __forceinline__ double next_lane(double v) { return __shfl_down(v, 1); }
   __device__ __forceinline__ float  next_lane(float v) { return __shfl_down(v, 1); }
 
+  // ------------------------------------------------------------------------------------------
+  // Sliced sweeps (high degrees).  The two even-odd matrices of a sweep are 2 x 41 doubles at p = 8: 164 scalar
+  // registers where ~100 exist, and what does not fit is parked lane by lane in vector registers (v_writelane /
+  // v_readlane: 431 + 241 of the 2775 vector instructions of the p = 8 Chebyshev form, more at p = 9).  Here every
+  // sweep is two phases, one matrix each, and a phase reads its matrix through a pointer the compiler cannot
+  // connect with the other phases' (coef_reload: constant address space, so the loads stay scalar): nothing is
+  // kept across phases or across bricks, the 41 doubles of a phase fit.
+  //   x: W = M u, U = K u;   y: s = K W, W = M W, U = c0 M U + c1 s;   z: W = c2 K W + M U
+  // ------------------------------------------------------------------------------------------
+  // degrees that run the sliced sweeps (MGX_MACRO_SLICED_FROM: A/B builds)
+#ifndef MGX_MACRO_SLICED_FROM
+#define MGX_MACRO_SLICED_FROM 7
+#endif
+  // (not in the fused transfer forms: with the registers of the restriction / interpolation sweeps next to them the
+  // sliced sweeps spill -- p = 8 residual + restriction: 412 B per lane)
+  template <int P, int MODE>
+  constexpr bool kSlicedSweeps = P >= MGX_MACRO_SLICED_FROM && MODE != kResidualRestrict && MODE != kChebFirstProlong;
+
+  template <typename T>
+  __device__ __forceinline__ const EOMat<T> &coef_reload(const EOMat<T> *m)
+  {
+    typedef const EOMat<T> __attribute__((address_space(4))) *ConstPtr;
+    ConstPtr q = (ConstPtr)(uintptr_t)m;
+    asm volatile("" : "+s"(q));
+    return *(const EOMat<T> *)q;
+  }
+
+  template <int P, typename T, typename Mark, typename Barrier>
+  __device__ __forceinline__ void brick_sweeps_sliced(int tid, T *__restrict__ U, T *__restrict__ W, const Basis1D<T> *__restrict__ B,
+                                                      T c0, T c1, T c2, Mark mark, Barrier barrier)
+  {
+    using C           = MCfg<P, T>;
+    constexpr int G   = C::G, NT = C::THREADS, LINES = C::LINES, N = P + 1, NB = C::NB;
+    constexpr int REM = LINES - NT;
+    const bool    ln  = tid < LINES, rm = REM > 0 && tid < REM * NB;
+    const int     rl  = NT + tid / NB, rc = tid % NB; // cell-split pass: line and cell block of this lane
+    // seam of the cell-split pass: the block's first output belongs to the previous block's lane
+    auto seam = [&](T(&y)[N]) {
+      const T yn = next_lane(y[0]);
+      if (rc + 1 < NB)
+        y[P] += yn;
+    };
+    // (the lines of the cell-split pass after the whole lines, in phases of their own: their values are not live
+    // next to a whole line's)
+    // ---- x ----
+    if (ln)
+      {
+        T in[G], o[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          in[j] = U[tid * G + j];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+          {
+            const EOMat<T> &A   = coef_reload(ph == 0 ? &B->mass : &B->lapl);
+            T              *dst = ph == 0 ? W : U;
+            macro_apply<P, T>(A, in, o);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+              dst[tid * G + j] = o[j];
+          }
+      }
+    if (rm)
+      {
+        T         seg[N], y[N];
+        const int base = rl * G + rc * P;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = U[base + i];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+          {
+            const EOMat<T> &A   = coef_reload(ph == 0 ? &B->mass : &B->lapl);
+            T              *dst = ph == 0 ? W : U;
+            cell_apply<P, T>(A, seg, y);
+            seam(y);
+#pragma unroll
+            for (int i = 1; i < N; ++i)
+              dst[base + i] = y[i];
+            if (rc == 0)
+              dst[base] = y[0];
+          }
+      }
+    barrier();
+    mark(0);
+    // ---- y ----
+    if (ln)
+      {
+        T         a[G], s2[G], t2[G];
+        const int lb = (tid / G) * (G * G) + tid % G;
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          a[j] = W[lb + j * G];
+        macro_apply<P, T>(coef_reload(&B->lapl), a, s2);
+        const EOMat<T> &M = coef_reload(&B->mass);
+        macro_apply<P, T>(M, a, t2);
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          W[lb + j * G] = t2[j];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          a[j] = U[lb + j * G];
+        macro_apply<P, T>(M, a, t2);
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          U[lb + j * G] = fma(c0, t2[j], c1 * s2[j]);
+      }
+    if (rm)
+      {
+        T         seg[N], y[N], z[N], r[N];
+        const int base = (rl / G) * (G * G) + rl % G + rc * P * G;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = W[base + i * G];
+        cell_apply<P, T>(coef_reload(&B->lapl), seg, z);
+        const EOMat<T> &M = coef_reload(&B->mass);
+        cell_apply<P, T>(M, seg, y);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = U[base + i * G];
+        cell_apply<P, T>(M, seg, r);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          z[i] = fma(c0, r[i], c1 * z[i]);
+        seam(y);
+        seam(z);
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+          {
+            W[base + i * G] = y[i];
+            U[base + i * G] = z[i];
+          }
+        if (rc == 0)
+          {
+            W[base] = y[0];
+            U[base] = z[0];
+          }
+      }
+    barrier();
+    mark(1);
+    // ---- z ----
+    if (ln)
+      {
+        T a[G], r[G], o[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          a[j] = W[tid + j * (G * G)];
+        macro_apply<P, T>(coef_reload(&B->lapl), a, r);
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          a[j] = U[tid + j * (G * G)];
+        macro_apply<P, T>(coef_reload(&B->mass), a, o);
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          W[tid + j * (G * G)] = fma(c2, r[j], o[j]);
+      }
+    if (rm)
+      {
+        T         seg[N], y[N], q[N];
+        const int base = rl + rc * P * (G * G);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = W[base + i * (G * G)];
+        cell_apply<P, T>(coef_reload(&B->lapl), seg, q);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          seg[i] = U[base + i * (G * G)];
+        cell_apply<P, T>(coef_reload(&B->mass), seg, y);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          y[i] = fma(c2, q[i], y[i]);
+        seam(y);
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+          W[base + i * (G * G)] = y[i];
+        if (rc == 0)
+          W[base] = y[0];
+      }
+  }
+
   // item table word: bits 0..9 entity slot of the brick, 10..22 brick point, 23..31 offset in the entity
   __device__ __forceinline__ uint32_t item_slot(uint32_t m) { return m & 1023u; }
   __device__ __forceinline__ uint32_t item_point(uint32_t m) { return (m >> 10) & 8191u; }
