@@ -1,6 +1,6 @@
 """Phase timeline of the macro-element brick kernel (diagnostic build: make -C multigrid_amd/csrc
 MACROFLAGS=-DMGX_MACRO_STAMPS).  Prints median cycles per phase over the workgroups of the last
-colour launch.  usage: macro_stamps.py [cells] [vmult|cheb|prolong]
+colour launch.  usage: macro_stamps.py [cells] [vmult|cheb|prolong] [degree]
 (prolong: a V-cycle with Chebyshev degree 1, whose last finest-level launch is the prolongation form, mode 9)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,13 +8,14 @@ import numpy as np
 import multigrid_amd as mg
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 mode = sys.argv[2] if len(sys.argv) > 2 else "vmult"
+degree = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 ns, nr = cells, 0
 while ns % 2 == 0 and ns > 1:
     ns //= 2; nr += 1
 # (prolong: the level below the finest one on the one-launch schedule, whose transfers are kernels of their own: the
 # stamped launches of the fused transfer forms then all belong to the finest level)
 ctx = mg.Context(0, options={"free_one_max": 8192} if mode == "prolong" else None)
-cube = mg.Cube(4, ns, nr)
+cube = mg.Cube(degree, ns, nr)
 l = cube.max_level
 op = mg.LaplaceOperator.from_cube(ctx, cube, l)
 x = ctx.vector(cube.n_dofs(l), data=cube.seeded_vector(l, 42))
