@@ -407,6 +407,45 @@ namespace mgx
   // acc receives P cv on the G^3 points of the brick.  Exact embedding: every fine point takes the
   // value of the coarse finite-element function (MGTransferMatrixFree::prolongate).
   // ------------------------------------------------------------------------------------------
+  // one parent: f[a] = sum_i P1[a][i] c[i], a over its 2p+1 fine points, in the even-odd form of restrict_half
+  template <int P, typename T>
+  __device__ __forceinline__ void prolong_half(const T *__restrict__ pe, const T (&c)[P + 1], T (&f)[2 * P + 1])
+  {
+    constexpr int NH = (P + 1) / 2, TOT = (2 * P + 1) * NH + ((P % 2 == 0) ? P + 1 : 0);
+    constexpr int ROW = 2 * NH + (P % 2 == 0 ? 1 : 0);
+    const T      *he = pe, *ho = pe + (P + 1) * NH, *pc = pe + (2 * P + 1) * NH;
+    T             ce[NH], co[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+      {
+        ce[i] = c[i] + c[P - i];
+        co[i] = c[i] - c[P - i];
+      }
+    const T cc = c[P / 2];
+#pragma unroll
+    for (int a = 0; a <= P; ++a)
+      {
+        T se = he[a * NH] * ce[0];
+#pragma unroll
+        for (int i = 1; i < NH; ++i)
+          se = fma(he[a * NH + i], ce[i], se);
+        if (P % 2 == 0)
+          se = fma(pc[a], cc, se);
+        if (a < P)
+          {
+            T so = ho[a * NH] * co[0];
+#pragma unroll
+            for (int i = 1; i < NH; ++i)
+              so = fma(ho[a * NH + i], co[i], so);
+            f[a]         = se + so;
+            f[2 * P - a] = se - so;
+          }
+        else
+          f[P] = se;
+        scalar_operand_slice<ROW, TOT>(a);
+      }
+  }
+
   // f = P1 c per parent, in the even-odd form of restrict_half (pe = Basis1D::P1eo): f[a] and f[2p-a] from the sums and
   // differences of the coarse values at mirrored nodes
   template <int P, typename T>

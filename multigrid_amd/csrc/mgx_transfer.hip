@@ -22,6 +22,7 @@
 //     with both operands read from LDS made the kernels LDS-bandwidth bound: 2 LDS reads per FMA.)
 //     The z sweep works directly on the registers the patch values were prefetched into (restriction)
 //     or are stored from (prolongation); only the two intermediate arrays live in LDS.
+#include "mgx_brick_device.hpp" // restrict_half / prolong_half
 #include "mgx_internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -134,7 +135,7 @@ namespace mgx
     __shared__ T        t1[N * N * M]; // [k][j][a]
     const int      tid = threadIdx.x;
     const uint32_t G   = gridDim.x;
-    const T       *p1  = B->P1; // p1[a * N + i], wave-uniform
+    const T       *pe  = B->P1eo; // the embedding in even-odd form (mgx_brick_device.hpp restrict_half), wave-uniform
 
     PatchLine line[NL];
     bool      has[NL];
@@ -217,18 +218,11 @@ namespace mgx
 #pragma unroll
         for (int it = 0; it < NL; ++it)
           {
-            T r[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k)
-              r[k] = T(0);
+            T r[N], xw[M];
 #pragma unroll
             for (int c = 0; c < M; ++c)
-              {
-                const T x = sh[it][zslot(c)] == 31u ? T(0) : v[it][c] * (T(1) / T(1u << sh[it][zslot(c)]));
-#pragma unroll
-                for (int k = 0; k < N; ++k)
-                  r[k] = fma(p1[c * N + k], x, r[k]);
-              }
+              xw[c] = sh[it][zslot(c)] == 31u ? T(0) : v[it][c] * (T(1) / T(1u << sh[it][zslot(c)]));
+            restrict_half<P, T>(pe, xw, r);
             if (has[it])
               {
                 const int l = tid + it * TH;
@@ -249,15 +243,7 @@ namespace mgx
 #pragma unroll
             for (int b = 0; b < M; ++b)
               x[b] = t2[(k * M + b) * M + a];
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-              {
-                T s = p1[j] * x[0];
-#pragma unroll
-                for (int b = 1; b < M; ++b)
-                  s = fma(p1[b * N + j], x[b], s);
-                r[j] = s;
-              }
+            restrict_half<P, T>(pe, x, r);
 #pragma unroll
             for (int j = 0; j < N; ++j)
               t1[(k * N + j) * M + a] = r[j];
@@ -271,15 +257,7 @@ namespace mgx
 #pragma unroll
             for (int a = 0; a < M; ++a)
               x[a] = t1[l * M + a];
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-              {
-                T s = p1[i] * x[0];
-#pragma unroll
-                for (int a = 1; a < M; ++a)
-                  s = fma(p1[a * N + i], x[a], s);
-                r[i] = s;
-              }
+            restrict_half<P, T>(pe, x, r);
             const uint32_t b0 = ctb[buf][crow], b1 = ctb[buf][crow + 1], b2 = ctb[buf][crow + 2];
             if (COLOURED)
               {
@@ -340,7 +318,7 @@ namespace mgx
     __shared__ T        t2[N * M * M]; // [k][b][a]
     const int      tid = threadIdx.x;
     const uint32_t G   = gridDim.x;
-    const T       *p1  = B->P1;
+    const T       *pe  = B->P1eo; // the embedding in even-odd form (mgx_brick_device.hpp prolong_half)
 
     PatchLine line[NL];
     bool      has[NL];
@@ -419,15 +397,11 @@ namespace mgx
         // x on the prefetched coarse line: t1[k][j][a] = sum_i P1[a][i] u[i]
         if (cl)
           {
+            T f[M];
+            prolong_half<P, T>(pe, cv, f);
 #pragma unroll
             for (int a = 0; a < M; ++a)
-              {
-                T s = p1[a * N] * cv[0];
-#pragma unroll
-                for (int i = 1; i < N; ++i)
-                  s = fma(p1[a * N + i], cv[i], s);
-                t1[tid * M + a] = s;
-              }
+              t1[tid * M + a] = f[a];
           }
         T fcur[NL][NA];
         if (ADD)
@@ -450,15 +424,11 @@ namespace mgx
 #pragma unroll
             for (int j = 0; j < N; ++j)
               x[j] = t1[(k * N + j) * M + a];
+            T f[M];
+            prolong_half<P, T>(pe, x, f);
 #pragma unroll
             for (int b = 0; b < M; ++b)
-              {
-                T s = p1[b * N] * x[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j)
-                  s = fma(p1[b * N + j], x[j], s);
-                t2[(k * M + b) * M + a] = s;
-              }
+              t2[(k * M + b) * M + a] = f[b];
           }
         __syncthreads();
         // z into registers, owner writes
@@ -476,17 +446,15 @@ namespace mgx
 #pragma unroll
             for (int e = 0; e < 5; ++e)
               w[e] = tbl[buf][25 * e + line[it].sxy];
+            T f[M];
+            prolong_half<P, T>(pe, x, f);
 #pragma unroll
             for (int c = 0; c < M; ++c)
               {
-                T s = p1[c * N] * x[0];
-#pragma unroll
-                for (int k = 1; k < N; ++k)
-                  s = fma(p1[c * N + k], x[k], s);
                 const uint32_t ww = w[zslot(c)];
                 if (pw_owned(ww))
                   fine[pw_index(ww) + (uint32_t)(zoff(c) * line[it].nxy + line[it].oxy)] =
-                    ADD ? fcur[it][c % NA] + s : s;
+                    ADD ? fcur[it][c % NA] + f[c] : f[c];
               }
           }
         __syncthreads();
