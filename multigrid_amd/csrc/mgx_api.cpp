@@ -139,6 +139,8 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"macro_wg_per_cu_x16", nullptr, &macro_wg_x16},
     {"no_diag_table", &no_diag_table, nullptr},
     {"no_macro_v2", &no_macro_v2, nullptr},
+    {"no_general_bricks", &no_general_bricks, nullptr},
+    {"general_brick_min", nullptr, &general_brick_min},
     {"roctx", &roctx, nullptr},
     {"no_fused_init", &no_fused_init, nullptr},
     {"no_fused_restrict", &no_fused_restrict, nullptr},
@@ -647,6 +649,14 @@ namespace
           });
       }
     ProfileBracket pb(op, 0);
+    if (op->d.gbricks.fr.available() && !op->plan)
+      {
+        // general operator on its brick schedule: one launch over the bricks, one over the DoFs on brick surfaces
+        launch_general_bricks(s, op->d, dst, src);
+        launch_surf_finish(s, op->d, 0, 0, op->d.gbricks.fr.n_surf_dofs, dst, src, dst, nullptr, nullptr, nullptr, 0., 0., 0.,
+                           nullptr, 0, &op->d.gbricks.fr);
+        return MGX_OK;
+      }
     if (op->d.asm_start)
       {
         // ordered assembly: the cell loop writes every entry of dst (and the identity rows with it when
@@ -1542,6 +1552,50 @@ int mgx_operator_create(mgx_context_t ctx, const mgx_operator_desc *desc, mgx_op
       else
         MGX_TRACE("operator_create: per-cell kernel (%s)", why.c_str());
     }
+  // Brick form of the general tensor branch (mgx_kernels.hip, brick_general_kernel): p = 4, one rank, vectors and
+  // coefficient array below the 4 GB of a 32-bit element offset, cells in bricks (hyper_shell and every structured
+  // mapped mesh of mgx_cube): the one-launch schedule of the macro-element kernel -- every entity on a brick surface
+  // private -- with its finish kernel.  vmult only; the other forms of a general operator keep the per-cell kernel.
+  if (general && p == 4 && !desc->exchange && !tun.no_bricks && !tun.no_general_bricks && desc->n_dofs < 0x3FFFFFFFu &&
+      (uint64_t)desc->n_dofs * number_size(d.number) < 0xFFFFFFF0ull &&
+      desc->n_cells / 64 >= tun.general_brick_min)
+    {
+      BrickHost   bh;
+      std::string why;
+      FreeHost    fh;
+      std::vector<uint32_t> map;
+      build_item_map(p, map);
+      if (build_bricks(p, desc->n_cells, desc->n_dofs, desc->idx27, desc->idx27_plain, nullptr, nullptr, 0, false, bh, why) &&
+          build_free_schedule(p, bh, desc->n_dofs, nullptr, 0, false, 1, map, fh) && fh.n_groups == 1 &&
+          (size_t)bh.n_bricks * fh.n_surf * number_size(d.number) < 0xFFFFFFF0ull)
+        {
+          BrickData &g = d.gbricks;
+          g.n_bricks   = bh.n_bricks;
+          FreeSchedule &fr = g.fr;
+          fr.n_classes = 1;
+          fr.n_groups  = 1;
+          fr.group_start[0] = 0;
+          fr.group_start[1] = bh.n_bricks;
+          fr.n_surf        = fh.n_surf;
+          fr.n_surf_dofs   = (uint32_t)fh.surf_dof.size();
+          fr.n_surf_shared = 0;
+          fh.surf_dof.push_back(0);
+          fh.surf_pos.push_back(0);
+          auto up = [&](uint32_t *&dev, const std::vector<uint32_t> &v) {
+            if (hipMalloc((void **)&dev, sizeof(uint32_t) * v.size()) != hipSuccess)
+              return false;
+            return hipMemcpy(dev, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice) == hipSuccess;
+          };
+          MGX_REQUIRE(up(g.order_dev, bh.order) && up(g.item_map, map) && up(fr.surf_off, fh.surf_off) && up(fr.surf_dof, fh.surf_dof) &&
+                        up(fr.surf_start, fh.surf_start) && up(fr.surf_pos, fh.surf_pos) && up(fr.ent, fh.ent),
+                      "mgx_operator_create: out of device memory (brick schedule of the general operator)");
+          MGX_HIP(hipMalloc(&fr.priv, (size_t)bh.n_bricks * fh.n_surf * number_size(d.number) + 16));
+          MGX_TRACE("operator_create: general branch on %u bricks, %u private values per brick, %u private DoFs", bh.n_bricks,
+                    fr.n_surf, fr.n_surf_dofs);
+        }
+      else
+        MGX_TRACE("operator_create: general branch without bricks (%s)", why.c_str());
+    }
   // Ordered assembly for the per-cell kernels: levels without a brick schedule and without cell
   // colours.  For every DoF the positions (cell (p+1)^3 + local index) of its contributions in
   // ascending cell order, from the compressed index table (read_dof_values_compressed,
@@ -1804,6 +1858,14 @@ int mgx_operator_destroy(mgx_operator_t op)
   (void)hipFree(op->d.bricks.fr.surf_dof);
   (void)hipFree(op->d.bricks.fr.surf_start);
   (void)hipFree(op->d.bricks.fr.surf_pos);
+  (void)hipFree(op->d.gbricks.item_map);
+  (void)hipFree(op->d.gbricks.order_dev);
+  (void)hipFree(op->d.gbricks.fr.ent);
+  (void)hipFree(op->d.gbricks.fr.surf_off);
+  (void)hipFree(op->d.gbricks.fr.priv);
+  (void)hipFree(op->d.gbricks.fr.surf_dof);
+  (void)hipFree(op->d.gbricks.fr.surf_start);
+  (void)hipFree(op->d.gbricks.fr.surf_pos);
   (void)hipFree(op->d.diag_items);
   (void)hipFree(op->d.diag_items2);
   (void)hipFree(op->cg_partials);

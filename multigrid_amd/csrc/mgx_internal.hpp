@@ -40,6 +40,8 @@ namespace mgx
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
     bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
     bool     roctx            = false; // profiler ranges with the reference's LIKWID region names (mgx_range_push/pop, per-level phases of the V-cycle)
+    bool     no_general_bricks = false; // general tensor branch: per-cell kernel + ordered assembly also where the brick form exists (A/B, tests)
+    uint32_t general_brick_min = 2048;  // ... bricks from which vmult of a general operator runs in brick form (one workgroup per brick, 512 resident: below four rounds of workgroups the per-cell kernel with its 16 waves per CU is faster)
     bool     no_macro_v2      = false; // first pipeline of the macro-element kernel (gather after the sweeps) for every form; A/B of mgx_macro2.hip
     bool     no_fused_init    = false; // MGX_NO_FUSED_INIT    store the first Chebyshev iterate
     bool     no_fused_restrict = false; // MGX_NO_FUSED_RESTRICT  separate residual and restriction kernels
@@ -127,6 +129,7 @@ namespace mgx
     uint32_t *item_map  = nullptr; // device [(NB p + 1)^3]: write-out order of the macro-element kernel
     uint32_t *item_map2 = nullptr; // device: the same items, interior of the brick first (second pipeline, mgx_macro2.hip)
     std::vector<uint32_t> order; // host: colour-sorted position -> brick index in cell order
+    uint32_t *order_dev = nullptr; // device copy (general operator: brick_general_kernel finds its cells through it)
     bool      available() const { return n_bricks > 0; }
     FreeSchedule fr; // reduced-colour schedule of the plain / residual / Chebyshev forms (may be absent)
   };
@@ -163,6 +166,7 @@ namespace mgx
     uint32_t *asm_pos       = nullptr; // device: cell (p+1)^3 + local index (k n + j) n + i
     void     *cell_scratch  = nullptr; // device [n_cells (p+1)^3], number type
     BrickData bricks;
+    BrickData gbricks; // general tensor branch, p = 4, one rank: one-launch schedule of brick_general_kernel (fr, item_map)
     bool      cells_form    = false; // Tunables::cells_form of the context the operator was created on
     uint32_t  wide_max      = 1024;  // Tunables::wide_max
     uint32_t  macro_wg_x16  = 0;     // Tunables::macro_wg_x16
@@ -254,6 +258,8 @@ namespace mgx
   void launch_cell_loop(hipStream_t s, const OperatorData &op, void *dst, const void *src, const void *tail_src = nullptr,
                         uint32_t n_head = 0,
                         const ChebPost *post = nullptr);
+  // general operator, brick form (p = 4, OperatorData::gbricks; mgx_kernels.hip brick_general_kernel)
+  void launch_general_bricks(hipStream_t s, const OperatorData &op, void *dst, const void *src);
   // mode 0: dst = ordered sums of op.cell_scratch (tail as above), mode 1: dst += them
   void launch_assemble(hipStream_t s, const OperatorData &op, int mode, void *dst, const void *tail_src, uint32_t n_head);
   // brick cell loop with fused post-operation (mgx_brick.hip); mode = BrickMode
@@ -278,7 +284,8 @@ namespace mgx
   // constrained / n_constrained (Chebyshev forms): rows where A x = x, updated by the same launch
   void launch_surf_finish(hipStream_t s, const OperatorData &op, int mode, uint32_t first, uint32_t count, void *carrier,
                           const void *x, void *out, const void *a, const void *dinv, const void *old, double f1, double f2,
-                          double f0, const uint32_t *constrained = nullptr, uint32_t n_constrained = 0);
+                          double f0, const uint32_t *constrained = nullptr, uint32_t n_constrained = 0,
+                          const FreeSchedule *schedule = nullptr); // schedule: another one than op.bricks.fr
   // macro-element form of the separable brick loop (mgx_macro.hip), one translation unit per number
   // type; false: mode / degree not covered (the caller falls back to the cell-by-cell form)
   bool launch_macro_loop_f64(hipStream_t s, const OperatorData &op, int mode, const void *src, const void *a,

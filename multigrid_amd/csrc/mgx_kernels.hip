@@ -15,6 +15,7 @@
 // The DoF gather/scatter uses the reference's 27-entry compressed index table
 // (common/vector_access_reduced.h:11-505, restated in SURVEY.md Appendix A): thread (j,k) loads
 // the x-line {left vertex/edge/face entry, p-1 contiguous interior entries, right entry}.
+#include "mgx_macro_device.hpp" // buffer-descriptor access (brick_general_kernel)
 #include "mgx_internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -558,6 +559,277 @@ namespace mgx
       }
   }
 
+  // ------------------------------------------------------------------------------------------
+  // Brick form of the general quadrature-point operation (round 4; vmult only, p <= 4, one rank).  The kernel above
+  // hands the (p+1)^3 results of every cell to the ordered assembly through a scratch array: 2 x 15.6 B per DoF at
+  // p = 4 next to the 94 B of the coefficient stream.  Here a workgroup takes a brick of 4 x 4 x 4 cells (the brick
+  // tables of mgx_bricks.cpp, built from the index tables of any mesh whose cells come in bricks: the hyper_shell
+  // meshes do) and adds the cells' results up in an LDS array of the brick's (4p+1)^3 points: eight rounds of the
+  // eight cells of one parity class (2 i + r_x, 2 j + r_y, 2 k + r_z) -- they share no point, plain adds, fixed order.
+  // Write-out as in the macro-element kernel on its one-launch schedule (mgx_macro.hip, FREE with one class): item
+  // by item in the order of the item table, interior entities straight to the vector, entities on the brick surface
+  // to the brick's private block; k_surf_finish adds the blocks up per DoF in a fixed order.  Cell 64 b + r + 8 s is
+  // the cell of parity r in slot s = (i, j, k) of brick b = order[position in the schedule] (Morton order inside the
+  // brick, verified by build_bricks).
+  // ------------------------------------------------------------------------------------------
+  template <int P, typename T, bool PERQ>
+  __global__ void __launch_bounds__(256)
+    brick_general_kernel(T *__restrict__ dst, const T *__restrict__ src, const uint32_t *__restrict__ idx27,
+                         const uint32_t *__restrict__ ent, const uint32_t *__restrict__ surf_off,
+                         const uint32_t *__restrict__ item_map, const uint32_t *__restrict__ order, uint32_t n_bricks,
+                         const Basis1D<T> *__restrict__ B,
+                         const T *__restrict__ coef_q, T c0, T c1, T c2, T c3, T c4, T c5, T *__restrict__ priv, uint32_t n_surf, uint32_t vec_bytes)
+  {
+    constexpr int N = P + 1, LN = N | 1, PL = N * LN, N3 = N * N * N, CELL = N * N * LN;
+    constexpr int NB = 4, G = NB * P + 1, NPTS = G * G * G, NE = 729, SLOTS = 8, TPC = N * N, NT = 256;
+    static_assert(SLOTS * TPC <= NT, "eight cells of n^2 threads per round");
+    __shared__ T        W[NPTS];
+    __shared__ T        U[SLOTS * CELL], GX[SLOTS * CELL], GY[SLOTS * CELL];
+    __shared__ uint32_t E[NE], S[NE];
+    const int      tid   = threadIdx.x;
+    const uint32_t brick = blockIdx.x;
+    if (brick >= n_bricks)
+      return;
+    for (int i = tid; i < NPTS; i += NT)
+      W[i] = T(0);
+    for (int i = tid; i < NE; i += NT)
+      {
+        E[i] = ent[(size_t)brick * NE + i];
+        S[i] = surf_off[i];
+      }
+    const int  slot = tid / TPC, t = tid - slot * TPC, a = t % N, b = t / N;
+    const bool active = slot < SLOTS;
+    const int  sl = active ? slot : 0;
+    T         *Uc = U + sl * CELL, *Xc = GX + sl * CELL, *Yc = GY + sl * CELL;
+    const int  xl = (b * N + a) * LN, yl = b * PL + a, zl = b * LN + a;
+    // (the tables are in the order of the brick schedule -- launch groups of build_bricks --, the cells in mesh order)
+    const uint32_t cell0 = 64u * order[brick];
+    // Two workgroups of four waves per CU hide no latency by themselves: every round's operands are requested a round
+    // ahead through buffer descriptors (the compiler leaves such loads where they are written): the three index words
+    // of the thread's x-line two rounds ahead, the five source values and the 6 n coefficients of its z-line one round ahead
+    // (constrained entity: offset out of range, reads zero; two sets of coefficient registers in turn).
+    const rsrc_t rs_src = make_rsrc(src, vec_bytes);
+    const rsrc_t rs_idx = make_rsrc(idx27 + 27u * (size_t)cell0, 64u * 27u * 4u);
+    const rsrc_t rs_cq  = make_rsrc(PERQ ? coef_q + (size_t)cell0 * 6 * N3 : coef_q, PERQ ? 64u * 6u * (uint32_t)N3 * (uint32_t)sizeof(T) : 0u);
+    int cyc, oy, czc, oz;
+    node_code<P>(a, cyc, oy);
+    node_code<P>(b, czc, oz);
+    const uint32_t loff = (uint32_t)((cyc == 1 ? P - 1 : 1) * oz + oy);       // line_index(): offset of the line in its entities
+    const uint32_t iw0  = (uint32_t)(3 * (3 * czc + cyc)) * 4u;               // byte offset of its three index words in a cell's 27
+    auto idx_issue = [&](int r, uint32_t(&w)[3]) {
+      const uint32_t o = active && r < 8 ? (uint32_t)(r + 8 * sl) * 27u * 4u + iw0 : kOob;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        w[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_idx, o == kOob ? kOob : o + 4u * k, 0, 0);
+    };
+    auto src_issue = [&](const uint32_t(&w)[3], T(&v)[N]) {
+      v[0] = buf_ld(rs_src, w[0] != kInvalid ? (w[0] + loff) * (uint32_t)sizeof(T) : kOob, T());
+#pragma unroll
+      for (int i = 0; i < P - 1; ++i)
+        v[1 + i] = buf_ld(rs_src, w[1] != kInvalid ? (w[1] + loff * (uint32_t)(P - 1) + (uint32_t)i) * (uint32_t)sizeof(T) : kOob, T());
+      v[P] = buf_ld(rs_src, w[2] != kInvalid ? (w[2] + loff) * (uint32_t)sizeof(T) : kOob, T());
+    };
+    auto coef_issue = [&](int r, T(&c)[PERQ ? 6 * N : 1]) {
+#ifdef MGX_GB_NOCOEF // diagnostic build (wrong results): no coefficient stream
+      for (int k = 0; k < (PERQ ? 6 * N : 1); ++k)
+        c[k] = T(1);
+      return;
+#endif
+      if (PERQ)
+        {
+          const uint32_t o = active && r < 8 ? ((uint32_t)(r + 8 * sl) * 6u * (uint32_t)N3 + (uint32_t)(b * N + a)) * (uint32_t)sizeof(T) : kOob;
+#pragma unroll
+          for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+              c[PERQ ? 6 * k + e : 0] = buf_ld(rs_cq, o == kOob ? kOob : o + (uint32_t)((e * N3 + k * N * N) * (int)sizeof(T)), T());
+        }
+    };
+    uint32_t iw[3], iwn[3];
+    T        gv[N], cfa[PERQ ? 6 * N : 1], cfb[PERQ ? 6 * N : 1];
+    idx_issue(0, iw);
+    idx_issue(1, iwn);
+    src_issue(iw, gv); // (waits for the index words of round 0)
+    coef_issue(0, cfa);
+    __syncthreads();
+    // one round: cf = this round's coefficients (requested a whole round ago), cfn receives the next round's
+    T dummy = T(0);
+    auto round = [&](int r, T(&cf)[PERQ ? 6 * N : 1], T(&cfn)[PERQ ? 6 * N : 1]) {
+        T rr[N], q[N], gz[N];
+        if (active) // nodal -> quadrature along x
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = gv[i];
+          }
+        // the source values of the next round (its index words were requested a round ago), index words of the round after
+        src_issue(iwn, gv);
+        idx_issue(r + 2, iwn);
+        coef_issue(r + 1, cfn);
+        if (active)
+          {
+            mv<N, T>(B->S, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[xl + i] = q[i];
+          }
+        __syncthreads();
+        if (active) // along y
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Uc[yl + i * LN];
+            mv<N, T>(B->S, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[yl + i * LN] = q[i];
+          }
+        __syncthreads();
+        if (active) // along z; z-derivative of this z-line in registers
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Uc[zl + i * PL];
+            mv<N, T>(B->S, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[zl + i * PL] = q[i];
+            mv<N, T>(B->D, q, gz);
+          }
+        __syncthreads();
+        if (active) // x- and y-derivatives, to the z-line owners through LDS
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              q[i] = Uc[xl + i];
+            mv<N, T>(B->D, q, rr);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Xc[xl + i] = rr[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              q[i] = Uc[yl + i * LN];
+            mv<N, T>(B->D, q, rr);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Yc[yl + i * LN] = rr[i];
+          }
+        __syncthreads();
+        if (active) // the tensor at the N points of this z-line
+          {
+            const T wab = B->w[a] * B->w[b];
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+              {
+                T t0, t1, t2, t3, t4, t5;
+                if (PERQ)
+                  {
+                    t0 = cf[PERQ ? 6 * k : 0], t1 = cf[PERQ ? 6 * k + 1 : 0], t2 = cf[PERQ ? 6 * k + 2 : 0];
+                    t3 = cf[PERQ ? 6 * k + 3 : 0], t4 = cf[PERQ ? 6 * k + 4 : 0], t5 = cf[PERQ ? 6 * k + 5 : 0];
+#ifdef MGX_GB_UNUSEDCOEF // diagnostic build (wrong results): the stream is loaded, waited for in the last phase only
+                    dummy += t0 + t1 + t2 + t3 + t4 + t5;
+                    t0 = t1 = t2 = T(1), t3 = t4 = t5 = T(0);
+#endif
+                  }
+                else
+                  {
+                    const T w = wab * B->w[k];
+                    t0 = c0 * w, t1 = c1 * w, t2 = c2 * w, t3 = c3 * w, t4 = c4 * w, t5 = c5 * w;
+                  }
+                const T gx = Xc[zl + k * PL], gy = Yc[zl + k * PL], g = gz[k];
+                Xc[zl + k * PL] = t0 * gx + t3 * gy + t4 * g;
+                Yc[zl + k * PL] = t3 * gx + t1 * gy + t5 * g;
+                gz[k]           = t4 * gx + t5 * gy + t2 * g;
+              }
+            mvT<N, T>(B->D, gz, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              gz[i] = q[i];
+          }
+        __syncthreads();
+        if (active) // transposed x-derivative
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Xc[xl + i];
+            mvT<N, T>(B->D, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[xl + i] = q[i];
+          }
+        __syncthreads();
+        if (active) // transposed y-derivative, accumulated
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Yc[yl + i * LN];
+            mvT<N, T>(B->D, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[yl + i * LN] += q[i];
+          }
+        __syncthreads();
+        if (active) // add the z part, quadrature -> nodal along z
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Uc[zl + i * PL] + gz[i];
+            mvT<N, T>(B->S, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[zl + i * PL] = q[i];
+          }
+        __syncthreads();
+        if (active) // along y
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Uc[yl + i * LN];
+            mvT<N, T>(B->S, rr, q);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              Uc[yl + i * LN] = q[i];
+          }
+        __syncthreads();
+        if (active) // along x, added to the brick array: cells of one parity class share no point
+          {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              rr[i] = Uc[xl + i];
+            mvT<N, T>(B->S, rr, q);
+            const int cx = 2 * (sl & 1) + (r & 1), cy = 2 * ((sl >> 1) & 1) + ((r >> 1) & 1), cz = 2 * (sl >> 2) + (r >> 2);
+            const int pt = ((P * cz + b) * G + (P * cy + a)) * G + P * cx;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              W[pt + i] += q[i];
+          }
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int r = 0; r < 8; r += 2)
+      {
+        round(r, cfa, cfb);
+        round(r + 1, cfb, cfa);
+      }
+    if (dummy == T(12345.678))
+      dst[0] = dummy;
+    // write-out: items in the order of the item table (word: bits 0..9 entity slot, 10..22 brick point, 23..31 offset
+    // inside the entity); constrained entities have no entry
+    T *pb = priv + (size_t)brick * n_surf;
+    for (int it = tid; it < NPTS; it += NT)
+      {
+        const uint32_t m = item_map[it], sw = m & 1023u, pnt = (m >> 10) & 8191u, off = m >> 23;
+        const uint32_t w = E[sw], so = S[sw];
+        if (w == kInvalid)
+          continue;
+        const T v = W[pnt];
+        if (so != kInvalid)
+          pb[so + off] = v;
+        else
+          dst[(w & 0x3FFFFFFFu) + off] = v;
+      }
+  }
+
   // Diagonal of the general cell matrix (local_compute_diagonal :770-800, restated in closed form):
   // d_i = sum_q C(q) : grad phi_i(q) grad phi_i(q) with grad phi_i(q) from the 1D values S and
   // nodal derivatives G = D S at the quadrature points.  One thread per cell DoF line (j, k).
@@ -1092,6 +1364,29 @@ namespace mgx
       {
         MGX_DISPATCH_P(op.p, cell_loop_t<P, float>(s, op, dst, src, tail_src, n_head, post));
       }
+  }
+
+  // the general operator on its brick schedule (brick_general_kernel): interior DoFs to dst, the bricks' private
+  // blocks to op.gbricks.fr.priv; the caller completes the surface DoFs with launch_surf_finish on that schedule
+  void launch_general_bricks(hipStream_t s, const OperatorData &op, void *dst, const void *src)
+  {
+    const BrickData &g = op.gbricks;
+    auto run = [&](auto number) {
+      using T = decltype(number);
+      if (op.coef_q)
+        hipLaunchKernelGGL((brick_general_kernel<4, T, true>), dim3(g.n_bricks), dim3(256), 0, s, (T *)dst, (const T *)src, op.idx27,
+                           g.fr.ent, g.fr.surf_off, g.item_map, g.order_dev, g.n_bricks, (const Basis1D<T> *)op.basis, (const T *)op.coef_q,
+                           (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T *)g.fr.priv, g.fr.n_surf, (uint32_t)((size_t)op.n_dofs * sizeof(T)));
+      else
+        hipLaunchKernelGGL((brick_general_kernel<4, T, false>), dim3(g.n_bricks), dim3(256), 0, s, (T *)dst, (const T *)src, op.idx27,
+                           g.fr.ent, g.fr.surf_off, g.item_map, g.order_dev, g.n_bricks, (const Basis1D<T> *)op.basis, (const T *)nullptr,
+                           (T)op.coef[0], (T)op.coef[1], (T)op.coef[2], (T)op.coef[3], (T)op.coef[4], (T)op.coef[5],
+                           (T *)g.fr.priv, g.fr.n_surf, (uint32_t)((size_t)op.n_dofs * sizeof(T)));
+    };
+    if (op.number == 1)
+      run(double());
+    else
+      run(float());
   }
 
   // lists[k] .. lists[k + 1]: device cell lists of n_lists launches whose cells share no DoF (plain

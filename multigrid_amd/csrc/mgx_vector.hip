@@ -692,13 +692,13 @@ namespace mgx
 
   void launch_surf_finish(hipStream_t s, const OperatorData &op, int mode, uint32_t first, uint32_t count, void *carrier,
                           const void *x, void *out, const void *a, const void *dinv, const void *old, double f1, double f2,
-                          double f0, const uint32_t *constrained, uint32_t n_constrained)
+                          double f0, const uint32_t *constrained, uint32_t n_constrained, const FreeSchedule *schedule)
   {
     if (mode < 2)
       n_constrained = 0; // the identity rows of the plain and residual forms are the caller's
     if (count + n_constrained == 0)
       return;
-    const FreeSchedule &bd = op.bricks.fr;
+    const FreeSchedule &bd = schedule ? *schedule : op.bricks.fr;
     if (!old)
       old = out;
     if (!x)

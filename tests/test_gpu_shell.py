@@ -149,6 +149,42 @@ def test_colour_by_colour_launches_of_the_general_branch(monkeypatch, geometry, 
     c_atomic.close()
 
 
+@pytest.mark.parametrize("mesh,nr,problem,number", [(("shell", 6), 3, "shell", "f64"), (("shell", 12), 2, "shell", "f64"),
+                                                    (("shell", 6), 3, "cube", "f32"), (("box", "sheared"), 3, "cube", "f64"),
+                                                    (("box", "shell_sector"), 3, "shell", "f64")])
+def test_brick_form_of_the_general_operator(mesh, nr, problem, number):
+    """vmult of a general-tensor operator at p = 4 on its brick schedule (brick_general_kernel: the cells of a brick added
+    up in LDS, brick surfaces through private blocks and the finish kernel; production from 2048 bricks on, forced
+    here): against the oracle on the same mesh, against the per-cell kernel with ordered assembly, bitwise reproducible"""
+    cb = mg.Context(0, options={"general_brick_min": 1})
+    cc = mg.Context(0, options={"no_general_bricks": 1})
+    if mesh[0] == "shell":
+        cube = mg.Cube(4, n_refine=nr, shell=mesh[1], problem=problem)
+        orc = Oracle(4, degree=3, n_cycles=1, mesh=cube, problem=problem)
+    else:
+        cube = mg.Cube(4, n_refine=nr, box=(1, 1, 1), origin=-0.9, h0=1.9, geometry=mesh[1], problem=problem)
+        orc = oracle_for(cube, 4, 1, nr, geometry=mesh[1], problem=problem, origin=-0.9, h0=1.9)
+    num, dt, tol = (mg.F32, np.float32, 2e-6) if number == "f32" else (mg.F64, np.float64, 1e-12)
+    l = cube.max_level
+    x = cube.seeded_vector(l, 5)
+    res = []
+    for c in (cb, cc):
+        op = mg.LaplaceOperator.from_cube(c, cube, l, num)
+        src, dst, again = c.vector(x.size, num, x.astype(dt)), c.vector(x.size, num), c.vector(x.size, num)
+        op.vmult(dst, src)
+        op.vmult(again, src)
+        assert np.array_equal(dst.download(), again.download())
+        res.append(dst.download().astype(np.float64))
+        op.clear()
+    assert rel(res[0], res[1]) < tol
+    if orc is not None:
+        assert rel(res[0], orc.vmult(l, x)) < (1e-5 if number == "f32" else 1e-12)
+        orc.close()
+    cube.close()
+    cb.close()
+    cc.close()
+
+
 @pytest.mark.parametrize("n_coarse,p,nr,problem", [(6, 4, 2, "shell"), (12, 4, 1, "shell"), (6, 2, 3, "shell"), (12, 3, 2, "cube"),
                                                    (6, 5, 1, "shell"), (6, 1, 3, "cube")])
 def test_hyper_shell_solver_against_oracle(ctx, n_coarse, p, nr, problem):
