@@ -72,7 +72,7 @@ int mgx_context_create(mgx_context_t *ctx, int device);
  * "brick_wide_max": cross-check builds only,) "macro_wg_per_cu_x16", "no_diag_table", "no_fused_init", "no_fused_restrict",
  * "no_fused_prolong", "force_fused_transfers", "transfer_v1", "restrict_atomic", "exchange_unfused",
  * "no_graph", "dg_no_overlap", "dg_unmerged_restrict", "no_fused_decomposed", "no_fused_assembly", "no_fused_residual", "no_restrict_scratch",
- * "no_macro_v2", "no_general_bricks" (with the threshold "general_brick_min"), "roctx".  "rccl_selftest" lets a one-rank communicator name itself as its own
+ * "no_macro_v2", "no_general_bricks" (with the threshold "general_brick_min"), "fused_prolong_min_bricks", "roctx".  "rccl_selftest" lets a one-rank communicator name itself as its own
  * neighbour (emulation of a rank on one GPU; the sums it produces are wrong by construction).
  * Unknown name: MGX_ERR_INVALID_ARGUMENT. */
 int mgx_context_set_option(mgx_context_t ctx, const char *name, double value);

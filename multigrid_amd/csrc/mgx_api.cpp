@@ -141,6 +141,7 @@ bool mgx::Tunables::set(const std::string &name, double value)
     {"no_macro_v2", &no_macro_v2, nullptr},
     {"no_general_bricks", &no_general_bricks, nullptr},
     {"general_brick_min", nullptr, &general_brick_min},
+    {"fused_prolong_min_bricks", nullptr, &fused_prolong_min_bricks},
     {"roctx", &roctx, nullptr},
     {"no_fused_init", &no_fused_init, nullptr},
     {"no_fused_restrict", &no_fused_restrict, nullptr},
@@ -3536,7 +3537,10 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
       mgx_operator_t Af = S->matrix[level];
       const bool     fused_prolong = S->transfer[level]->d.coarse_blocks && Af->d.bricks.item_map && !Af->d.cells_form &&
                                  Af->d.separable && !S->ctx->tun.no_fused_prolong && S->smooth[level]->info.degree >= 1 && !one_launch &&
-                                 (uint64_t)Af->d.n_dofs * number_size(Af->d.number) < 0xFFFFFFF0ull;
+                                 (uint64_t)Af->d.n_dofs * number_size(Af->d.number) < 0xFFFFFFF0ull &&
+                                 // (a level on the two-class schedule runs its Chebyshev steps in two launches + finish; the fused
+                                 // prolongation form needs the eight colours, each as long as a brick's latency chain there)
+                                 (!Af->d.bricks.fr.available() || Af->plan || Af->d.bricks.n_bricks >= S->ctx->tun.fused_prolong_min_bricks);
       if (fused_prolong)
         {
           Stopwatch sw(S, level, 5);
