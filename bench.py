@@ -587,7 +587,7 @@ def main():
         per_launch_bytes = ALG[form] * n_dofs / n_col
         ach = per_launch_bytes / (avg * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "mgx::brick_macro%s_kernel<%d,%s,%s> (finest level, per colour launch)"
-                % ("2" if form in (0, 1) and not any(o.startswith("no_macro_v2") for o in args.option) else "", args.degree, "double" if (vnum == mg.F64 or form == 0) else "float", NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                % ("2" if (form in (0, 1, 6) or (form in (5, 7) and args.degree <= 4)) and not any(o.startswith("no_macro_v2") for o in args.option) else "", args.degree, "double" if (vnum == mg.F64 or form == 0) else "float", NAMES[form]), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 "
                                    "per the gfx950 correction; same kernel sources as this build)" % TRAFFIC_FILE)
