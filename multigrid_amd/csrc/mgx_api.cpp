@@ -3538,11 +3538,11 @@ static int v_cycle_eager(mgx_solver_t S, int level, int my_n_cycles)
       const bool     fused_prolong = S->transfer[level]->d.coarse_blocks && Af->d.bricks.item_map && !Af->d.cells_form &&
                                  Af->d.separable && !S->ctx->tun.no_fused_prolong && S->smooth[level]->info.degree >= 1 && !one_launch &&
                                  (uint64_t)Af->d.n_dofs * number_size(Af->d.number) < 0xFFFFFFF0ull &&
-                                 // (a level on the two-class schedule runs its Chebyshev steps in two launches + finish; the fused
+                                 // (a level on the two-class schedule -- decomposed or not -- runs its Chebyshev steps in two launches + finish; the fused
                                  // prolongation form needs the eight colours, each as long as a brick's latency chain there.  p <= 4
                                  // only: at p = 8 the prolongation kernel costs 0.18 ms on the 17 M-DoF level and the fused form wins,
                                  // 0.945 against 1.004 ms)
-                                 (!Af->d.bricks.fr.available() || Af->plan || Af->d.p > 4 || Af->d.bricks.n_bricks >= S->ctx->tun.fused_prolong_min_bricks);
+                                 (!Af->d.bricks.fr.available() || Af->d.p > 4 || Af->d.bricks.n_bricks >= S->ctx->tun.fused_prolong_min_bricks);
       if (fused_prolong)
         {
           Stopwatch sw(S, level, 5);

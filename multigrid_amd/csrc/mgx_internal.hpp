@@ -40,7 +40,7 @@ namespace mgx
     uint32_t macro_wg_x16     = 0;     // MGX_MACRO_WG_PER_CU_X16  macro kernel grid, in 1/16 workgroups per CU [resident]
     bool     no_diag_table    = false; // MGX_NO_DIAG_TABLE    stream the inverse diagonal in the fused Chebyshev forms
     bool     roctx            = false; // profiler ranges with the reference's LIKWID region names (mgx_range_push/pop, per-level phases of the V-cycle)
-    uint32_t fused_prolong_min_bricks = 16385; // one rank, p <= 4, levels on a reduced-colour schedule with fewer bricks: prolongation as a kernel of its own + first post-smoothing step on that schedule (17 M-DoF level of C2: 0.894 against 0.905 ms; 0: fused everywhere)
+    uint32_t fused_prolong_min_bricks = 8192; // p <= 4, levels on a reduced-colour schedule with fewer bricks (per rank): prolongation as a kernel of its own + first post-smoothing step on that schedule (17 M-DoF level of C2: 0.894 against 0.905 ms; emulated rank at 8 GPUs 2.417 against 2.446 ms; a 67 M-DoF rank level, 16 384 bricks, is faster fused: 5.42 against 5.48 ms; 0: fused everywhere)
     bool     no_general_bricks = false; // general tensor branch: per-cell kernel + ordered assembly also where the brick form exists (A/B, tests)
     uint32_t general_brick_min = 2048;  // ... bricks from which vmult of a general operator runs in brick form (one workgroup per brick, 512 resident: below four rounds of workgroups the per-cell kernel with its 16 waves per CU is faster)
     bool     no_macro_v2      = false; // first pipeline of the macro-element kernel (gather after the sweeps) for every form; A/B of mgx_macro2.hip

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 namespace mgx
 {
@@ -475,9 +476,25 @@ namespace mgx
     auto grid_of = [&](int slot, const void *kernel) {
       if (t.pipe_grid[slot] == 0)
         {
-          int per_cu = 1;
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, C::THREADS, 0) != hipSuccess || per_cu < 1)
-            per_cu = 1;
+          // (one query at a time: eight ranks running as threads of one process asked for the same kernel at the same
+          // moment and all got hipErrorUnknown from the runtime; a failed query must not leave its error behind for
+          // the caller's hipGetLastError either)
+          static std::mutex occupancy_mutex;
+          int               per_cu = 1;
+          {
+            std::lock_guard<std::mutex> lock(occupancy_mutex);
+            hipError_t                  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, C::THREADS, 0);
+            if (e != hipSuccess)
+              {
+                (void)hipGetLastError();
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, C::THREADS, 0);
+              }
+            if (e != hipSuccess || per_cu < 1)
+              {
+                (void)hipGetLastError();
+                per_cu = 1;
+              }
+          }
           t.pipe_grid[slot] = (uint32_t)per_cu * t.n_cus;
         }
       return std::min<uint32_t>(c.n_cells, t.pipe_grid[slot]);

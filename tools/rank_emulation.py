@@ -25,7 +25,8 @@ def timed(ctx, fn, k):
 
 nr = int(np.log2(cells))
 procs = mg.process_grid(N)
-ctx = mg.Context(0, options={"rccl_selftest": 1})
+# further context options: RANK_EMULATION_OPTS="name=value,..."
+ctx = mg.Context(0, options=dict({"rccl_selftest": 1}, **{k: float(v) for k, v in (o.split("=") for o in os.environ.get("RANK_EMULATION_OPTS", "").split(",") if o)}))
 buf = (C.c_uint8 * 128)()
 mg.check(ctx.lib.mgx_rccl_unique_id(buf))
 mg.check(ctx.lib.mgx_context_set_rccl(ctx.h, 0, 1, buf))
